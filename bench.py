@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of Libra's vision hot path on MI355X (BASELINE.json configs[1]).
+
+A "step" = one pass of the hot path over one synthetic batch resident in HBM:
+    ViT-L/14@336 forward (all 24 layers, 25 hidden states)  ->  feature select [-2,-3]
+    -> VQ encode (quant_conv GEMM + LFQ sign/pack -> token ids)
+    -> backward of a fixed cotangent on the 2048-d feature through the ViT (dgrad + wgrad of every
+       parameter that feeds it; bf16 grads), + RCCL gradient all-reduce when N > 1 (data parallel, weak scaling)
+bs = 32 images / GPU, bf16, random-init weights, synthetic N(0,1) pixels.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the bf16 MFMA GEMM, per-launch
+times from events on the launch stream in a separate instrumented step) and "cpu_baseline" (the CPU oracle
+timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VIT_L = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
+             patch_size=14)
+GFLOP_FWD_PER_IMG = 381.9
+GFLOP_LAYER = 15.884               # one encoder layer forward
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def build(device, batch, embed_dim=512):
+    from transformers import CLIPVisionConfig
+    from libra_amd.clip import CLIPVisionModel
+    from libra_amd.libra import ImageTokenizer
+    torch.manual_seed(42)
+    clip = CLIPVisionModel(CLIPVisionConfig(**VIT_L))
+    # the reference initialiser leaves biases at 0 and LN at (1,0); perturb so every term is numerically live
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in clip.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    clip = clip.to(torch.bfloat16).to(device)
+    cfg = {"params": {"ddconfig": {"encoder_name": "clip_vit_l_336", "select_layer": [-2, -3]}, "embed_dim": embed_dim,
+                      "codebook_size": 512, "num_codebook": 2}, "max_vision_token_length": 578}
+    tok = ImageTokenizer(cfg, token_offset=32000, vision_model=clip)
+    with torch.no_grad():
+        tok.model.quant_conv.weight.normal_(0, 2048 ** -0.5, generator=None)
+        tok.model.quant_conv.bias.normal_(0, 0.05)
+    tok = tok.to(torch.bfloat16).to(device)
+    # fwd/bwd config: the ViT's parameters take gradients (extension over the reference)
+    clip.requires_grad_(True)
+    tok.model.encoder.allow_grad = True
+    g = torch.Generator().manual_seed(42)
+    pixel = torch.randn(batch, 3, 336, 336, generator=g).to(torch.bfloat16).to(device)
+    cot = torch.randn(batch, 576, 2048, generator=g).to(torch.bfloat16).to(device)
+    return clip, tok, pixel, cot
+
+
+def make_step(clip, tok, pixel, cot, world):
+    from libra_amd.dp import BucketedGradReducer
+    params = [p for p in clip.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        feat, h2d, idx, ids, _, _ = tok.model.encode_flat(pixel, offset=32000, boi=32512, eoi=32513, want_ids=True,
+                                                         want_quant=False)
+        feat.backward(cot)
+        if world > 1:
+            red = BucketedGradReducer(bucket_bytes=64 << 20)
+            red.add({str(i): p.grad for i, p in enumerate(params) if p.grad is not None})
+            out = red.finish()
+            for i, p in enumerate(params):
+                if p.grad is not None:
+                    p.grad = out[str(i)]
+        return ids
+    return step
+
+
+def cpu_baseline(sample_iters=3):
+    """The CPU oracle (oracle/vit_oracle.py, proven equal to the reference's modules on the golden fixtures) timed on
+    this box's host cores: ViT-L/14@336 fwd+bwd, B=1, fp32."""
+    from oracle import vit_oracle as VO
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    sd = VO.random_vit_state_dict(hidden=1024, inter=4096, layers=24, patch=14, image=336, seed=42)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(1, 3, 336, 336, generator=g)
+    ct = torch.randn(1, 576, 2048, generator=g)
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        hs = VO.vit_hidden_states(sd, x, patch=14, heads=16, layers=24)
+        f = VO.feature_select(hs, [-2, -3], square=False)
+        (f * ct).sum().backward()
+    one()
+    t0 = time.perf_counter()
+    for _ in range(sample_iters):
+        one()
+    dt = (time.perf_counter() - t0) / sample_iters
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"ViT-L/14@336 fwd+bwd (feature cotangent), B=1, fp32, {sample_iters} timed iters after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    clip, tok, pixel, cot = build(device, args.batch)
+    step = make_step(clip, tok, pixel, cot, world)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms = dt / args.steps * 1e3
+    ips = args.batch * world * args.steps / dt
+
+    # ---- roofline leg: one instrumented step, events around every GEMM launch on the launch stream ----
+    from libra_amd import kernels as K
+    with K.LaunchProfile() as prof:
+        step()
+    recs = prof.finish()
+    gem = [(w, t) for k, w, t in recs if k == "gemm"]
+    gflop = sum(w for w, _ in gem) / 1e9
+    gms = sum(t for _, t in gem)
+    achieved = gflop / gms if gms > 0 else 0.0        # GFLOP/ms == TFLOP/s
+    gflop_step_img = GFLOP_FWD_PER_IMG + 2 * (GFLOP_FWD_PER_IMG - GFLOP_LAYER)   # bwd skips the unused last layer
+    roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1),
+            "gemm_ms_per_step": round(gms, 2),
+            "whole_step_frac": round(ips / world * gflop_step_img / 1e3 / PEAK_BF16_TFLOPS, 4)}
+
+    out = {"metric": "images/sec/GPU fwd+bwd (ViT+bridge, 336px, seq2048) at 1/2/4/8 MI355X", "value": round(ips, 2),
+           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs=32/GPU (LLM frozen)",
+                      "global_batch": args.batch * world, "image": "3x336x336", "vit_tokens": 577,
+                      "parallelism": f"dp{world}", "algorithmic_gflop_per_image": round(gflop_step_img, 1),
+                      "value_per_gpu": round(ips / world, 2)},
+           "roofline": roof}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

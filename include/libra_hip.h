@@ -1,0 +1,135 @@
+/*
+ * libra_hip.h — C ABI of the MI355X (gfx950) kernels for Libra's vision-to-LLM hot path.
+ *
+ * The reference (YifanXu74/Libra) has no FFI: its hot path is plain PyTorch ops inside
+ * libra/models/{clip,libra,llama}.  This library is what sits *under* the Python module surface
+ * (SURVEY.md §8b): every entry point replaces the torch-op sequence of the cited reference lines.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers borrowed for the duration of the enqueue; the library never
+ *     allocates, frees, synchronises or keeps global mutable state;
+ *   - bf16 tensors are raw uint16 storage, row-major, leading dimensions in ELEMENTS;
+ *   - `stream` is a hipStream_t (NULL = default stream); work is only enqueued;
+ *   - return value: LIBRA_OK (0) or a negative LIBRA_ERR_* code; nothing is launched on error.
+ *     (The Python host raises ValueError / RuntimeError from these, mirroring the reference's
+ *     shape-check exceptions, e.g. libra/models/libra/modeling_libra.py:374-403.)
+ */
+#ifndef LIBRA_HIP_H
+#define LIBRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIBRA_OK 0
+#define LIBRA_ERR_SHAPE (-1)   /* unsupported / inconsistent shape */
+#define LIBRA_ERR_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned / null */
+#define LIBRA_ERR_LAUNCH (-3)  /* HIP refused the launch */
+
+/* ABI version, bumped on any signature change. */
+int libra_hip_abi_version(void);
+
+/* ---- bf16 GEMM, C[M,N] = epi(A[M,K] . B[N,K]^T), fp32 accumulate ---------------------------------
+ * Replaces every nn.Linear / F.linear / 1x1-conv on the path: CLIP q/k/v/out_proj, fc1, fc2
+ * (libra/models/clip/modeling_clip.py:299-301,:361,:375-377), the patch-embedding conv as an im2col
+ * GEMM (:195), quant_conv (libra/models/libra/taming/models/vqgan.py:108), and their autograd
+ * dgrad/wgrad products.  K % 64 == 0; lda/ldb/ldc/ldr/ldaux % 8 == 0; 16-byte aligned pointers.
+ * epilogue, in order:  v = (acc + bias[n]) * (n < alpha_cols ? alpha : 1);  [store preact];
+ *                      quick_gelu(bf16(v));  * qgelu'(aux);  + resid;  round to bf16.                                                     */
+#define LIBRA_GEMM_BIAS 1            /* + bias[N] (bf16) */
+#define LIBRA_GEMM_QUICK_GELU 2      /* x*sigmoid(1.702x)   (HF ACT2FN["quick_gelu"], modeling_clip.py:376) */
+#define LIBRA_GEMM_RESIDUAL 4        /* + resid[M,N] (bf16, ldr) — residual add of modeling_clip.py:413,:418 */
+#define LIBRA_GEMM_MUL_QGELU_GRAD 8  /* * d/dx quick_gelu(aux[M,N])  (backward of the fc1 activation) */
+#define LIBRA_GEMM_STORE_PREACT 16   /* also store the pre-activation (bf16) to preact[M,N] (saved for backward) */
+int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, const void* bias, const void* resid, int64_t ldr,
+                       const void* aux, int64_t ldaux, void* preact, int64_t ldpre, float alpha,
+                       int64_t alpha_cols, int flags, void* stream);
+
+/* ---- LayerNorm over the last dim (nn.LayerNorm, eps 1e-5: modeling_clip.py:386-388,:866) ---------
+ * x,y [rows,D] bf16 contiguous, gamma/beta [D] bf16, mean/rstd [rows] fp32 (saved for backward, may be
+ * NULL).  D % 8 == 0, D <= 8192.                                                                     */
+int libra_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                        float* rstd, int64_t rows, int64_t D, float eps, void* stream);
+/* dx [rows,D] bf16 (optionally dx += dres, the residual-branch gradient, bf16 [rows,D]);
+ * dgamma/dbeta: fp32 [D] accumulators the caller zeroes (atomically accumulated), may be NULL.      */
+int libra_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                        int64_t rows, int64_t D, void* stream);
+
+/* ---- patch embedding front end (CLIPVisionEmbeddings.forward, modeling_clip.py:193-228) -----------
+ * im2col of non-overlapping PxP patches: pixel [B,C,H,W] bf16 -> cols [B*(H/P)*(W/P), Kpad] bf16 with
+ * column (c,ky,kx) = c*P*P + ky*P + kx, zero-padded to Kpad (% 64 == 0).                            */
+int libra_patch_im2col(const void* pixel, void* cols, int64_t B, int64_t C, int64_t H, int64_t W,
+                       int64_t P, int64_t Kpad, void* stream);
+/* col2im-free backward helper is not needed: d(pixel) = dcols scattered back by the same index map. */
+int libra_patch_col2im(const void* dcols, void* dpixel, int64_t B, int64_t C, int64_t H, int64_t W,
+                       int64_t P, int64_t Kpad, void* stream);
+/* emb[b,0] = cls + pos[0]; emb[b,1+p] = patches[b*Np+p] + pos[1+p]  (bf16 [B,T,D], T = Np+1), then
+ * hs0 = LayerNorm(emb) (the `pre_layrnorm`, modeling_clip.py:893).  mean/rstd may be NULL.          */
+int libra_vit_embed_ln(const void* patches, const void* cls, const void* pos, const void* gamma,
+                       const void* beta, void* emb, void* hs0, float* mean, float* rstd, int64_t B,
+                       int64_t T, int64_t D, float eps, void* stream);
+
+/* ---- bf16 2-D transpose with zero padding: out[c, r] = in[r, c], r < rows; out[c, rows..rows_pad) = 0
+ * in: [rows, cols] ld_in; out: [cols, rows_pad] ld_out; `batch` independent problems at element
+ * strides in_bstride / out_bstride (% 8 == 0).  Used to build the K-contiguous operands of the dgrad /
+ * wgrad GEMMs and the V^T operand of attention.  Optionally accumulates the column sums of `in`
+ * (== bias gradient) into colsum_f32[cols] (fp32, caller-zeroed, atomics) when non-NULL.            */
+int libra_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows,
+                         int64_t cols, int64_t rows_pad, float* colsum_f32, int64_t batch,
+                         int64_t in_bstride, int64_t out_bstride, void* stream);
+
+/* ---- ViT self-attention, flash style (CLIPAttention.forward, modeling_clip.py:287-363) -------------
+ * qkv [B*T, 3*H*64] bf16 (q | k | v, head h at columns h*64 of each third; q UNscaled), vt = V^T
+ * [H*64, vt_ld] bf16 with token (b,t) at column b*T_pad + t (T_pad % 8 == 0, keys t >= T ignored).
+ * out [B*T, H*64] bf16, lse [B,H,T] fp32 (natural-log-sum-exp of the scaled scores; may be NULL).
+ * head_dim is fixed at 64 (CLIP ViT-L/14).                                                          */
+int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, const void* vt, int64_t ld_vt, int64_t T_pad,
+                       void* out, int64_t ld_out, float* lse, int64_t B, int64_t T, int64_t H,
+                       float scale, void* stream);
+/* D = rowsum(dO * O) per (image, head, token): delta [B,H,T] fp32.                                   */
+int libra_vit_attn_delta(const void* out, const void* dout, int64_t ld, float* delta, int64_t B,
+                         int64_t T, int64_t H, void* stream);
+/* Backward (autograd of modeling_clip.py:308-348): from qkv, dO [B*T,H*64], lse and delta produce
+ * dqkv [B*T, 3*H*64] (dq/dk already multiplied by `scale`, i.e. gradients w.r.t. the UNscaled q, k).
+ * qkt = [Q^T ; K^T] as a [2*H*64, ld_t] matrix and dot_t = dO^T [H*64, ld_t], token (b,t) at column
+ * b*T_pad + t, zero padded (libra_transpose_bf16).  Deterministic: two passes, no atomics.          */
+int libra_vit_attn_bwd(const void* qkv, int64_t ld_qkv, const void* qkt, const void* dot_t, int64_t ld_t,
+                       int64_t T_pad, const void* dout, int64_t ld_out, const float* lse,
+                       const float* delta, void* dqkv, int64_t ld_dqkv, int64_t B, int64_t T, int64_t H,
+                       float scale, void* stream);
+
+/* ---- vision-tower feature select (CLIPVisionTower.feature_select, clip_encoder.py:31-45) -----------
+ * feat[b*(T-1)+p, j*D + d] = hs_j[b, 1+p, d] for j < n_sel (<= 4): channel concat, CLS dropped.      */
+int libra_feature_select(const void* const* hs, int64_t n_sel, void* feat, int64_t B, int64_t T,
+                         int64_t D, void* stream);
+/* backward scatter: dhs_j[b,1+p,:] (+)= dfeat[..., j*D:(j+1)*D]; CLS rows get 0 unless accumulate.  */
+int libra_feature_select_bwd(const void* dfeat, void* const* dhs, const int* accumulate, int64_t n_sel,
+                             int64_t B, int64_t T, int64_t D, void* stream);
+
+/* ---- LFQ sign-quantise + pack (LFQ.forward eval branch, lookup_free_quantization.py:185-208, and
+ *      ImageTokenizer.encode, image_tokenizer.py:77-86) -------------------------------------------
+ * h [rows, E] bf16 (rows = B*hw, the quant_conv output); w_in [Q*9, E], b_in [Q*9] bf16 or NULL when
+ * E == Q*9 (no projection).  x = bf16(h . w_in^T + b_in); bit = x > 0; index_q = sum bit * 2^(8-j).
+ * Outputs (any may be NULL): indices int64 [rows, Q];  ids int64 [Q, B, hw+2] = offset+index framed by
+ * BOI/EOI;  xpre bf16 [rows, Q*9] (the pre-sign value, for margin reports);
+ * quant bf16 [rows, E] = project_out(+-1) (w_out [E, Q*9], b_out [E]; or +-1 itself when no projection). */
+int libra_lfq_encode(const void* h, const void* w_in, const void* b_in, const void* w_out,
+                     const void* b_out, int64_t* indices, int64_t* ids, void* xpre, void* quant,
+                     int64_t B, int64_t hw, int64_t E, int64_t Q, int64_t offset, int64_t boi,
+                     int64_t eoi, void* stream);
+
+/* ---- small elementwise helpers -------------------------------------------------------------------*/
+/* out_bf16[i] = bf16(in_f32[i])  (parameter-gradient accumulators -> bf16 .grad) */
+int libra_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* y = a + b (bf16, n % 8 == 0 not required) */
+int libra_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBRA_HIP_H */

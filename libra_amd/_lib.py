@@ -1,0 +1,84 @@
+"""ctypes loader for the gfx950 C-ABI library (include/libra_hip.h).
+
+There is NO fallback: if ``libra_amd/lib/liblibra_hip.so`` is missing or a symbol is absent the
+import fails loudly.  Build it with ``make -C libra_amd/csrc`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblibra_hip.so")
+
+OK, ERR_SHAPE, ERR_ALIGN, ERR_LAUNCH = 0, -1, -2, -3
+
+_P, _I64, _F, _I = C.c_void_p, C.c_int64, C.c_float, C.c_int
+
+# name -> argtypes, exactly the prototypes of include/libra_hip.h
+SIGNATURES = {
+    "libra_hip_abi_version": [],
+    "libra_gemm_bf16_nt": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
+                           _F, _I64, _I, _P],
+    "libra_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
+    "libra_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
+    "libra_patch_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "libra_patch_col2im": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "libra_vit_embed_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
+    "libra_transpose_bf16": [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_vit_attn_fwd": [_P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
+    "libra_vit_attn_delta": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_vit_attn_bwd": [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
+    "libra_feature_select": [_P, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_feature_select_bwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "libra_lfq_encode": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "libra_f32_to_bf16": [_P, _P, _I64, _P],
+    "libra_add_bf16": [_P, _P, _P, _I64, _P],
+}
+
+ABI_VERSION = 1
+
+
+class LibraHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU / PyTorch fallback exists). "
+            "Build it with `make -C libra_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    v = lib.libra_hip_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {v}, host expects {ABI_VERSION}; rebuild it")
+    return lib
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc: int, what: str):
+    """Map C-ABI error codes onto the exception types the reference raises for the same conditions
+    (ValueError for shape mismatches, modeling_libra.py:374-403)."""
+    if rc == OK:
+        return
+    if rc == ERR_SHAPE:
+        raise ValueError(f"{what}: unsupported or inconsistent shape")
+    if rc == ERR_ALIGN:
+        raise ValueError(f"{what}: null / misaligned pointer or leading dimension")
+    raise LibraHipError(f"{what}: HIP launch failed (rc={rc})")

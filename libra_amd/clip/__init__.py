@@ -1,0 +1,6 @@
+# mirrors /root/reference/libra/models/clip/__init__.py
+from transformers import CLIPImageProcessor  # CPU preprocessing is out of scope; HF's class is the same vendored code
+
+from .modeling_clip import CLIPVisionConfig, CLIPVisionModel
+
+__all__ = ["CLIPVisionModel", "CLIPImageProcessor", "CLIPVisionConfig"]

@@ -1,0 +1,246 @@
+// bf16 "NT" GEMM for gfx950:  C[M,N] = epilogue( A[M,K] · B[N,K]^T )      (fp32 accumulate)
+//
+// Both operands are K-contiguous (a torch Linear: x[M,K], weight[N,K]), which is the natural MFMA
+// feed: every 32x32x16 fragment is one 16-byte LDS read per lane.  The same kernel serves the
+// forward linears, dgrad (with a K-contiguous transposed weight copy) and wgrad (with transposed
+// activation / gradient copies) — see libra_amd/ops.py.
+//
+// Structure (MI355X-first, not a CUDA tiling):
+//   * 128x128x64 block tile, 256 threads = 4 wave64, each wave a 64x64 quadrant = 2x2 MFMA 32x32 tiles
+//     (64 fp32 accumulators / lane), v_mfma_f32_32x32x16_bf16.
+//   * operands go HBM -> LDS with 16-byte direct-to-LDS loads (global_load_lds_dwordx4, no VGPR
+//     round trip).  The LDS image is lane-linear, so the bank swizzle is applied to the *source*
+//     address and mirrored on the fragment read:  chunk' = chunk ^ ((row >> 1) & 7)  (128-B rows).
+//     That makes every ds_read_b128 16-lane group hit 16 distinct 16-B slots (conflict free).
+//   * double-buffered LDS (2 x 32 KiB), one barrier per K tile, next tile's loads in flight under the
+//     current tile's 16 MFMAs per wave.
+//   * block ids are remapped XCD-aware (8 private L2s) + grouped along M so a weight panel stays L2 hot.
+//   * epilogue: accumulators -> LDS as a 128x128 fp32 tile (reusing the 64 KiB staging space), then
+//     row-contiguous 16-byte bf16 stores with fused bias / column scale / quick-GELU / GELU-grad /
+//     residual.
+//
+// Requirements (checked by the C entry point): K % 64 == 0, row strides % 8 == 0 elements, pointers
+// 16-byte aligned.  M and N are arbitrary (tail rows are clamped on load and masked on store).
+#include "hip_common.hpp"
+#include "../../include/libra_hip.h"
+
+namespace libra {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;           // 16 KiB per operand tile
+constexpr int GEMM_LDS = 4 * TILE_BYTES;          // A0 B0 A1 B1 = 64 KiB (== 128*128*4 epilogue tile)
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B; bf16_t* C;
+    const bf16_t* bias; const bf16_t* resid; const bf16_t* aux; bf16_t* preact;
+    long lda, ldb, ldc, ldr, ldaux, ldpre;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    float alpha; int alpha_cols;
+    int flags;
+};
+
+// Stage one 128x64 operand tile: wave w copies rows [32w, 32w+32) with four 1-KiB direct-to-LDS
+// instructions.  LDS position p = lane (16-B units within the 1 KiB = 8 rows x 8 chunks) holds the
+// source chunk (p & 7) ^ swz(row).
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int row0, int nrows,
+                                           int k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 32 + j * 8 + (lane >> 3);
+        int gr = row0 + r;
+        gr = gr < nrows ? gr : nrows - 1;                       // clamp the M/N tail (masked at the store)
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const bf16_t* src = g + (long)gr * ld + k0 + c * 8;
+        glds16(src, lds_tile + (wave * 32 + j * 8) * 128);
+    }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
+    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+    const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- tile coordinates: XCD-contiguous, then grouped 8 M-tiles deep ----
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int u = xcd_remap(blockIdx.x, ntiles);
+    constexpr int GM = 8;
+    const int width = GM * p.tiles_n;
+    const int grp = u / width;
+    const int first_m = grp * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (u % width) % gsz;
+    const int tn = (u % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    stage_tile(p.A, p.lda, m0, p.M, 0, smem, wave, lane);
+    stage_tile(p.B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+
+    const int frow = lane & 31;     // fragment row within a 32-row MFMA tile
+    const int fk = lane >> 5;       // which 8-wide k chunk of the 16-deep MFMA step
+
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();            // tile kt landed everywhere; everyone is done reading the other buffer
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            char* nb = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(p.A, p.lda, m0, p.M, (kt + 1) * BK, nb, wave, lane);
+            stage_tile(p.B, p.ldb, n0, p.N, (kt + 1) * BK, nb + TILE_BYTES, wave, lane);
+        }
+        const char* sa = smem + cur * 2 * TILE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = lds_frag(sa, wm * 64 + i * 32 + frow, ks * 2 + fk);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = lds_frag(sb, wn * 64 + j * 32 + frow, ks * 2 + fk);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: acc -> LDS fp32 [128][128] -> fused ops -> 16-byte row-contiguous stores ----
+    __syncthreads();
+    float* ct = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // 32x32 C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = wn * 64 + j * 32 + (lane & 31);
+                ct[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    const int cgrp = tid & 15;               // 8-column group owned by this thread (fixed across rows)
+    const int gn = n0 + cgrp * 8;
+    if (gn >= p.N) return;
+    const bool full8 = (gn + 8 <= p.N);
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.flags & LIBRA_GEMM_BIAS) {
+        if (full8) {
+            unpack8(*(const u32x4*)(p.bias + gn), bias);
+        } else {
+            for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
+        }
+    }
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f;
+
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 16 + (tid >> 4);
+        const int gm = m0 + row;
+        if (gm >= p.M) break;
+        float v[8];
+        const f32x4 lo = *(const f32x4*)(ct + row * BN + cgrp * 8);
+        const f32x4 hi = *(const f32x4*)(ct + row * BN + cgrp * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
+        if (p.flags & LIBRA_GEMM_STORE_PREACT) {
+            // the reference rounds the Linear output to bf16 before the activation sees it
+            bf16_t* pd = p.preact + (long)gm * p.ldpre + gn;
+            if (full8) *(u32x4*)pd = pack8(v);
+            else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
+        }
+        if (p.flags & LIBRA_GEMM_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(bf2f(f2bf(v[e])));
+        }
+        if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
+            float a[8];
+            if (full8) unpack8(*(const u32x4*)(p.aux + (long)gm * p.ldaux + gn), a);
+            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.aux[(long)gm * p.ldaux + gn + e]) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f(a[e]);
+        }
+        if (p.flags & LIBRA_GEMM_RESIDUAL) {
+            float a[8];
+            if (full8) unpack8(*(const u32x4*)(p.resid + (long)gm * p.ldr + gn), a);
+            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.resid[(long)gm * p.ldr + gn + e]) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+        }
+        bf16_t* dst = p.C + (long)gm * p.ldc + gn;
+        if (full8) {
+            *(u32x4*)dst = pack8(v);
+        } else {
+            for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
+        }
+    }
+}
+
+}  // namespace libra
+
+using namespace libra;
+
+extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                  int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                  int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                  float alpha, int64_t alpha_cols, int flags, void* stream) {
+    if (M <= 0 || N <= 0) return LIBRA_OK;                       // empty problem: nothing to do
+    if (!A || !B || !C || K <= 0 || (K % BK) != 0) return LIBRA_ERR_SHAPE;
+    if ((lda % 8) || (ldb % 8) || lda < K || ldb < K || ldc < N) return LIBRA_ERR_SHAPE;
+    if (((uintptr_t)A | (uintptr_t)B) & 15) return LIBRA_ERR_ALIGN;
+    const bool vec_ok = (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0);
+    if (!vec_ok) return LIBRA_ERR_ALIGN;
+    if ((flags & LIBRA_GEMM_BIAS) && (!bias || ((uintptr_t)bias & 15))) return LIBRA_ERR_ALIGN;
+    if ((flags & LIBRA_GEMM_RESIDUAL) && (!resid || (ldr % 8) || ((uintptr_t)resid & 15))) return LIBRA_ERR_ALIGN;
+    if ((flags & LIBRA_GEMM_MUL_QGELU_GRAD) && (!aux || (ldaux % 8) || ((uintptr_t)aux & 15))) return LIBRA_ERR_ALIGN;
+    if ((flags & LIBRA_GEMM_STORE_PREACT) && (!preact || (ldpre % 8) || ldpre < N || ((uintptr_t)preact & 15))) return LIBRA_ERR_ALIGN;
+    if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return LIBRA_ERR_SHAPE;
+
+    GemmArgs p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
+    p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldpre = ldpre;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+    p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_set = true;
+    }
+    const long nblk = (long)p.tiles_m * p.tiles_n;
+    if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), GEMM_LDS,
+                       (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+}

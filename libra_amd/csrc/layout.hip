@@ -1,0 +1,277 @@
+// Layout / data-movement kernels (all HBM-bound): bf16 transpose (+column sums), patch im2col / col2im,
+// vision-tower feature select (+backward), fp32->bf16, bf16 add.
+#include "hip_common.hpp"
+#include "../../include/libra_hip.h"
+
+namespace libra {
+
+// ---- transpose: out[c, r] = in[r, c]; 64x64 tiles through LDS; reads and writes are both 16-byte
+// row-contiguous accesses.  Optionally accumulates the column sums of `in` (bias gradients).
+constexpr int TT = 64;
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ld_in,
+                                                             bf16_t* __restrict__ out, long ld_out, int rows,
+                                                             int cols, int rows_pad, float* __restrict__ colsum,
+                                                             long in_bstride, long out_bstride) {
+    __shared__ bf16_t tile[TT][TT + 2];          // +2 elements: odd dword stride -> conflict-free column reads
+    in += (long)blockIdx.z * in_bstride;
+    out += (long)blockIdx.z * out_bstride;
+    const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
+    const int tid = threadIdx.x;
+    // load: thread -> (row = tid/8 + 32*p, 8 columns at (tid%8)*8)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (tid >> 3) + 32 * p;
+        const int cc = (tid & 7) * 8;
+        const int gr = r0 + r, gc = c0 + cc;
+        bf16_t v[8];
+        if (gr < rows && gc + 8 <= cols) {
+            *(u32x4*)v = *(const u32x4*)(in + (long)gr * ld_in + gc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (gr < rows && gc + e < cols) ? in[(long)gr * ld_in + gc + e] : (bf16_t)0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][cc + e] = v[e];
+    }
+    __syncthreads();
+    if (colsum) {
+        // thread t < 64 sums column t of the tile (rows beyond `rows` were zero-filled)
+        if (tid < TT && c0 + tid < cols) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TT; ++r) s += bf2f(tile[r][tid]);
+            atomicAdd(colsum + c0 + tid, s);
+        }
+    }
+    // store: thread -> (out row = column c = tid/8 + 32*p, 8 consecutive r at (tid%8)*8)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = (tid >> 3) + 32 * p;
+        const int rr = (tid & 7) * 8;
+        const int gc = c0 + c, gr = r0 + rr;
+        if (gc >= cols || gr >= rows_pad) continue;
+        bf16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[rr + e][c];
+        if (gr + 8 <= rows_pad) {
+            *(u32x4*)(out + (long)gc * ld_out + gr) = *(u32x4*)v;
+        } else {
+            for (int e = 0; e < 8 && gr + e < rows_pad; ++e) out[(long)gc * ld_out + gr + e] = v[e];
+        }
+    }
+}
+
+// ---- im2col for non-overlapping PxP patches. One thread per 8 output columns.
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const bf16_t* __restrict__ pix, bf16_t* __restrict__ cols,
+                                                           int C, int H, int W, int P, int Kpad, long total8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int k8 = Kpad >> 3;
+    const long row = i / k8;
+    const int kc = (int)(i - row * k8) * 8;
+    const int gw = W / P, gh = H / P;
+    const int np = gw * gh;
+    const long b = row / np;
+    const int pidx = (int)(row - b * np);
+    const int gy = pidx / gw, gx = pidx - gy * gw;
+    const int K = C * P * P;
+    bf16_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kc + e;
+        bf16_t val = 0;
+        if (k < K) {
+            const int c = k / (P * P);
+            const int rem = k - c * P * P;
+            const int ky = rem / P, kx = rem - ky * P;
+            val = pix[((b * C + c) * H + gy * P + ky) * (long)W + gx * P + kx];
+        }
+        v[e] = val;
+    }
+    *(u32x4*)(cols + row * Kpad + kc) = *(u32x4*)v;
+}
+
+// inverse index map (each pixel belongs to exactly one patch): dpix[b,c,y,x] = dcols[row(b,y/P,x/P), k(c,y%P,x%P)]
+__global__ __launch_bounds__(256) void patch_col2im_kernel(const bf16_t* __restrict__ dcols, bf16_t* __restrict__ dpix,
+                                                           int C, int H, int W, int P, int Kpad, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W);
+    const long t = i / W;
+    const int y = (int)(t % H);
+    const long t2 = t / H;
+    const int c = (int)(t2 % C);
+    const long b = t2 / C;
+    const int gw = W / P, gh = H / P;
+    const int gy = y / P, gx = x / P;
+    bf16_t v = 0;
+    if (gy < gh && gx < gw) {
+        const long row = (b * gh + gy) * gw + gx;
+        const int k = c * P * P + (y - gy * P) * P + (x - gx * P);
+        v = dcols[row * Kpad + k];
+    }
+    dpix[i] = v;
+}
+
+// ---- feature select: feat[b*(T-1)+p, j*D + d] = hs_j[b, 1+p, d]
+struct SelPtrs { const bf16_t* p[4]; };
+struct SelPtrsW { bf16_t* p[4]; int acc[4]; };
+
+__global__ __launch_bounds__(256) void feature_select_kernel(SelPtrs hs, int n_sel, bf16_t* __restrict__ feat, int T,
+                                                             int D, long total8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int d8 = D >> 3;
+    const long per_row = (long)n_sel * d8;
+    const long row = i / per_row;
+    const int rem = (int)(i - row * per_row);
+    const int j = rem / d8;
+    const int dc = (rem - j * d8) * 8;
+    const long b = row / (T - 1);
+    const int p = (int)(row - b * (T - 1));
+    const u32x4 v = *(const u32x4*)(hs.p[j] + ((b * T + 1 + p) * (long)D + dc));
+    *(u32x4*)(feat + row * ((long)n_sel * D) + (long)j * D + dc) = v;
+}
+
+__global__ __launch_bounds__(256) void feature_select_bwd_kernel(const bf16_t* __restrict__ dfeat, SelPtrsW dhs,
+                                                                 int n_sel, int T, int D, long total8) {
+    // one thread per (b, t, j, 8 d) of the OUTPUT so CLS rows get their zeros too
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int d8 = D >> 3;
+    const long per_row = (long)n_sel * d8;
+    const long row = i / per_row;                  // row over B*T
+    const int rem = (int)(i - row * per_row);
+    const int j = rem / d8;
+    const int dc = (rem - j * d8) * 8;
+    const long b = row / T;
+    const int t = (int)(row - b * T);
+    bf16_t* dst = dhs.p[j] + row * (long)D + dc;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    if (t > 0) unpack8(*(const u32x4*)(dfeat + (b * (T - 1) + t - 1) * ((long)n_sel * D) + (long)j * D + dc), g);
+    if (dhs.acc[j]) {
+        float o[8];
+        unpack8(*(const u32x4*)dst, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += o[e];
+    }
+    *(u32x4*)dst = pack8(g);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(in[i]);
+}
+
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ y, long n) {
+    const long i8 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i8 >= n) return;
+    if (i8 + 8 <= n) {
+        float x[8], z[8];
+        unpack8(*(const u32x4*)(a + i8), x);
+        unpack8(*(const u32x4*)(b + i8), z);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += z[e];
+        *(u32x4*)(y + i8) = pack8(x);
+    } else {
+        for (long i = i8; i < n; ++i) y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+    }
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH; }
+
+}  // namespace libra
+
+using namespace libra;
+
+extern "C" int libra_hip_abi_version(void) { return 1; }
+
+extern "C" int libra_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows,
+                                    int64_t cols, int64_t rows_pad, float* colsum, int64_t batch,
+                                    int64_t in_bstride, int64_t out_bstride, void* stream) {
+    if (cols <= 0 || rows_pad <= 0 || batch <= 0) return LIBRA_OK;
+    if (rows < 0 || rows_pad < rows || ld_in < cols || ld_out < rows_pad || batch > 65535) return LIBRA_ERR_SHAPE;
+    if ((ld_in % 8) || (ld_out % 8) || (in_bstride % 8) || (out_bstride % 8)) return LIBRA_ERR_ALIGN;
+    if (!in || !out || !al16(in) || !al16(out)) return LIBRA_ERR_ALIGN;
+    dim3 grid((unsigned)((cols + TT - 1) / TT), (unsigned)((rows_pad + TT - 1) / TT), (unsigned)batch);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (long)ld_in,
+                       (bf16_t*)out, (long)ld_out, (int)rows, (int)cols, (int)rows_pad, colsum, (long)in_bstride,
+                       (long)out_bstride);
+    return launched();
+}
+
+extern "C" int libra_patch_im2col(const void* pixel, void* cols, int64_t B, int64_t C, int64_t H, int64_t W,
+                                  int64_t P, int64_t Kpad, void* stream) {
+    if (B <= 0) return LIBRA_OK;
+    if (P <= 0 || H % P || W % P || Kpad < C * P * P || (Kpad % 64)) return LIBRA_ERR_SHAPE;
+    if (!pixel || !cols || !al16(cols)) return LIBRA_ERR_ALIGN;
+    const long total8 = B * (H / P) * (W / P) * (Kpad / 8);
+    hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pixel, (bf16_t*)cols, (int)C, (int)H, (int)W, (int)P, (int)Kpad, total8);
+    return launched();
+}
+
+extern "C" int libra_patch_col2im(const void* dcols, void* dpixel, int64_t B, int64_t C, int64_t H, int64_t W,
+                                  int64_t P, int64_t Kpad, void* stream) {
+    if (B <= 0) return LIBRA_OK;
+    if (P <= 0 || H % P || W % P || Kpad < C * P * P) return LIBRA_ERR_SHAPE;
+    if (!dcols || !dpixel) return LIBRA_ERR_ALIGN;
+    const long total = B * C * H * W;
+    hipLaunchKernelGGL(patch_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dcols, (bf16_t*)dpixel, (int)C, (int)H, (int)W, (int)P, (int)Kpad, total);
+    return launched();
+}
+
+extern "C" int libra_feature_select(const void* const* hs, int64_t n_sel, void* feat, int64_t B, int64_t T,
+                                    int64_t D, void* stream) {
+    if (B <= 0) return LIBRA_OK;
+    if (n_sel < 1 || n_sel > 4 || T < 2 || (D % 8)) return LIBRA_ERR_SHAPE;
+    if (!hs || !feat || !al16(feat)) return LIBRA_ERR_ALIGN;
+    SelPtrs s;
+    for (int j = 0; j < 4; ++j) {
+        s.p[j] = j < n_sel ? (const bf16_t*)hs[j] : nullptr;
+        if (j < n_sel && (!hs[j] || !al16(hs[j]))) return LIBRA_ERR_ALIGN;
+    }
+    const long total8 = B * (T - 1) * n_sel * (D / 8);
+    hipLaunchKernelGGL(feature_select_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       s, (int)n_sel, (bf16_t*)feat, (int)T, (int)D, total8);
+    return launched();
+}
+
+extern "C" int libra_feature_select_bwd(const void* dfeat, void* const* dhs, const int* accumulate, int64_t n_sel,
+                                        int64_t B, int64_t T, int64_t D, void* stream) {
+    if (B <= 0) return LIBRA_OK;
+    if (n_sel < 1 || n_sel > 4 || T < 2 || (D % 8)) return LIBRA_ERR_SHAPE;
+    if (!dfeat || !dhs || !al16(dfeat)) return LIBRA_ERR_ALIGN;
+    SelPtrsW s;
+    for (int j = 0; j < 4; ++j) {
+        s.p[j] = j < n_sel ? (bf16_t*)dhs[j] : nullptr;
+        s.acc[j] = (j < n_sel && accumulate) ? accumulate[j] : 0;
+        if (j < n_sel && (!dhs[j] || !al16(dhs[j]))) return LIBRA_ERR_ALIGN;
+    }
+    const long total8 = B * T * n_sel * (D / 8);
+    hipLaunchKernelGGL(feature_select_bwd_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)dfeat, s, (int)n_sel, (int)T, (int)D, total8);
+    return launched();
+}
+
+extern "C" int libra_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+    if (n <= 0) return LIBRA_OK;
+    if (!in || !out) return LIBRA_ERR_ALIGN;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       (bf16_t*)out, (long)n);
+    return launched();
+}
+
+extern "C" int libra_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+    if (n <= 0) return LIBRA_OK;
+    if (!a || !b || !y || !al16(a) || !al16(b) || !al16(y)) return LIBRA_ERR_ALIGN;
+    const long nt = (n + 7) / 8;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long)n);
+    return launched();
+}

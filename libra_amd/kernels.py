@@ -1,0 +1,316 @@
+"""Thin, typed host wrappers over the C-ABI kernels (include/libra_hip.h).
+
+PyTorch is used only for device memory (the caching allocator), streams and dtype bookkeeping;
+every arithmetic step below is a HIP kernel launch on the *current* stream (re-read on every call:
+autograd runs backward on its own thread).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import ctypes as C
+import torch
+
+from . import _lib
+
+GEMM_BIAS, GEMM_QUICK_GELU, GEMM_RESIDUAL, GEMM_MUL_QGELU_GRAD, GEMM_STORE_PREACT = 1, 2, 4, 8, 16
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t: torch.Tensor, name: str, dtype=BF16):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != dtype or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D row-major cuda {dtype} tensor, got {tuple(t.shape)} "
+                         f"strides {t.stride()} {t.dtype} {t.device}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+            bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, quick_gelu: bool = False,
+            qgelu_grad_of: Optional[torch.Tensor] = None, preact_out: Optional[torch.Tensor] = None,
+            alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ b[N,K]^T).  `k` limits the contraction to the first k columns."""
+    _chk2d(a, "a"); _chk2d(b, "b")
+    M, Ka = a.shape
+    N, Kb = b.shape
+    K = k if k is not None else Ka
+    if K > Ka or K > Kb or (k is None and Ka != Kb):
+        raise ValueError(f"gemm_nt: inner dims differ: a {tuple(a.shape)} b {tuple(b.shape)} k={k}")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    if out.shape != (M, N):
+        raise ValueError(f"gemm_nt: out is {tuple(out.shape)}, expected {(M, N)}")
+    flags = 0
+    if bias is not None:
+        if bias.numel() != N or bias.dtype != BF16:
+            raise ValueError("gemm_nt: bias must be bf16 [N]")
+        flags |= GEMM_BIAS
+    ldr = ldaux = ldpre = 0
+    if resid is not None:
+        _chk2d(resid, "resid")
+        if resid.shape != (M, N):
+            raise ValueError("gemm_nt: resid shape")
+        flags |= GEMM_RESIDUAL; ldr = resid.stride(0)
+    if qgelu_grad_of is not None:
+        _chk2d(qgelu_grad_of, "qgelu_grad_of")
+        if qgelu_grad_of.shape != (M, N):
+            raise ValueError("gemm_nt: qgelu_grad_of shape")
+        flags |= GEMM_MUL_QGELU_GRAD; ldaux = qgelu_grad_of.stride(0)
+    if preact_out is not None:
+        _chk2d(preact_out, "preact_out")
+        if preact_out.shape != (M, N):
+            raise ValueError("gemm_nt: preact_out shape")
+        flags |= GEMM_STORE_PREACT; ldpre = preact_out.stride(0)
+    if quick_gelu:
+        flags |= GEMM_QUICK_GELU
+    rc = _lib.lib().libra_gemm_bf16_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                       out.stride(0), M, N, K, _ptr(bias), _ptr(resid), ldr, _ptr(qgelu_grad_of),
+                                       ldaux, _ptr(preact_out), ldpre, float(alpha), int(alpha_cols), flags,
+                                       _stream())
+    _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, save_stats: bool = True,
+                  out: Optional[torch.Tensor] = None):
+    _chk2d(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("layernorm_fwd: x must be contiguous")
+    rows, D = x.shape
+    y = torch.empty_like(x) if out is None else out
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().libra_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(mean),
+                                        _ptr(rstd), rows, D, float(eps), _stream())
+    _lib.check(rc, f"layernorm_fwd rows={rows} D={D}")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=None, out=None):
+    """dx = LN'(dy) [+ dres]; dgamma/dbeta are fp32 [D] accumulators (added to), or None."""
+    _chk2d(dy, "dy"); _chk2d(x, "x")
+    rows, D = x.shape
+    if dy.shape != x.shape or not (dy.is_contiguous() and x.is_contiguous()):
+        raise ValueError("layernorm_bwd: dy/x must be contiguous and equal-shaped")
+    dx = torch.empty_like(x) if out is None else out
+    rc = _lib.lib().libra_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), rows,
+                                        D, _stream())
+    _lib.check(rc, f"layernorm_bwd rows={rows} D={D}")
+    return dx
+
+
+def transpose(x: torch.Tensor, rows_pad: Optional[int] = None, *, colsum: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[c, r] = x[r, c]; columns [rows, rows_pad) of out are zero.  colsum (fp32 [cols]) += column sums of x."""
+    _chk2d(x, "x")
+    rows, cols = x.shape
+    rows_pad = rows if rows_pad is None else rows_pad
+    if out is None:
+        out = torch.empty((cols, rows_pad), dtype=BF16, device=x.device)
+    _chk2d(out, "out")
+    rc = _lib.lib().libra_transpose_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols,
+                                         rows_pad, _ptr(colsum), 1, 0, 0, _stream())
+    _lib.check(rc, f"transpose {rows}x{cols}")
+    return out
+
+
+def transpose_tokens(x: torch.Tensor, B: int, T: int, T_pad: int, *, out: Optional[torch.Tensor] = None):
+    """x [B*T, C] (a column slice is fine) -> out [C, B*T_pad] with token (b,t) at column b*T_pad+t, zero padded."""
+    _chk2d(x, "x")
+    cols = x.shape[1]
+    if x.shape[0] != B * T:
+        raise ValueError("transpose_tokens: rows != B*T")
+    if out is None:
+        out = torch.empty((cols, B * T_pad), dtype=BF16, device=x.device)
+    rc = _lib.lib().libra_transpose_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), T, cols, T_pad,
+                                         None, B, T * x.stride(0), T_pad, _stream())
+    _lib.check(rc, "transpose_tokens")
+    return out
+
+
+def patch_im2col(pixel: torch.Tensor, P: int, Kpad: int) -> torch.Tensor:
+    if pixel.dim() != 4 or pixel.dtype != BF16 or not pixel.is_contiguous():
+        raise ValueError("patch_im2col: pixel must be contiguous bf16 [B,C,H,W]")
+    B, Cc, H, W = pixel.shape
+    cols = torch.empty((B * (H // P) * (W // P), Kpad), dtype=BF16, device=pixel.device)
+    rc = _lib.lib().libra_patch_im2col(pixel.data_ptr(), cols.data_ptr(), B, Cc, H, W, P, Kpad, _stream())
+    _lib.check(rc, "patch_im2col")
+    return cols
+
+
+def patch_col2im(dcols: torch.Tensor, B: int, Cc: int, H: int, W: int, P: int) -> torch.Tensor:
+    _chk2d(dcols, "dcols")
+    dpix = torch.empty((B, Cc, H, W), dtype=BF16, device=dcols.device)
+    rc = _lib.lib().libra_patch_col2im(dcols.data_ptr(), dpix.data_ptr(), B, Cc, H, W, P, dcols.stride(0), _stream())
+    _lib.check(rc, "patch_col2im")
+    return dpix
+
+
+def vit_embed_ln(patches, cls, pos, gamma, beta, B: int, T: int, eps: float, *, save: bool = True):
+    _chk2d(patches, "patches")
+    D = patches.shape[1]
+    dev = patches.device
+    emb = torch.empty((B * T, D), dtype=BF16, device=dev) if save else None
+    hs0 = torch.empty((B * T, D), dtype=BF16, device=dev)
+    mean = torch.empty(B * T, dtype=torch.float32, device=dev) if save else None
+    rstd = torch.empty(B * T, dtype=torch.float32, device=dev) if save else None
+    rc = _lib.lib().libra_vit_embed_ln(patches.data_ptr(), cls.data_ptr(), pos.data_ptr(), gamma.data_ptr(),
+                                       beta.data_ptr(), _ptr(emb), hs0.data_ptr(), _ptr(mean), _ptr(rstd), B, T, D,
+                                       float(eps), _stream())
+    _lib.check(rc, "vit_embed_ln")
+    return emb, hs0, mean, rstd
+
+
+def vit_attn_fwd(qkv: torch.Tensor, vt: torch.Tensor, B: int, T: int, H: int, T_pad: int, scale: float, *,
+                 need_lse: bool = True):
+    _chk2d(qkv, "qkv"); _chk2d(vt, "vt")
+    out = torch.empty((B * T, H * 64), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device) if need_lse else None
+    rc = _lib.lib().libra_vit_attn_fwd(qkv.data_ptr(), qkv.stride(0), vt.data_ptr(), vt.stride(0), T_pad,
+                                       out.data_ptr(), out.stride(0), _ptr(lse), B, T, H, float(scale), _stream())
+    _lib.check(rc, "vit_attn_fwd")
+    return out, lse
+
+
+def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, T_pad: int, scale: float) -> torch.Tensor:
+    _chk2d(qkv, "qkv"); _chk2d(out, "out"); _chk2d(dout, "dout")
+    dev = qkv.device
+    HD = H * 64
+    delta = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+    rc = _lib.lib().libra_vit_attn_delta(out.data_ptr(), dout.data_ptr(), out.stride(0), delta.data_ptr(), B, T, H,
+                                         _stream())
+    _lib.check(rc, "vit_attn_delta")
+    if dout.stride(0) != out.stride(0):
+        raise ValueError("vit_attn_bwd: out/dout leading dims differ")
+    qkt = transpose_tokens(qkv[:, : 2 * HD], B, T, T_pad)
+    dot = transpose_tokens(dout, B, T, T_pad)
+    dqkv = torch.empty_like(qkv)
+    rc = _lib.lib().libra_vit_attn_bwd(qkv.data_ptr(), qkv.stride(0), qkt.data_ptr(), dot.data_ptr(), qkt.stride(0),
+                                       T_pad, dout.data_ptr(), dout.stride(0), lse.data_ptr(), delta.data_ptr(),
+                                       dqkv.data_ptr(), dqkv.stride(0), B, T, H, float(scale), _stream())
+    _lib.check(rc, "vit_attn_bwd")
+    return dqkv
+
+
+def feature_select(hs: Sequence[torch.Tensor], B: int, T: int) -> torch.Tensor:
+    """hs: list of [B*T, D] bf16 contiguous -> [B*(T-1), len(hs)*D] (CLS dropped, channel concat)."""
+    n = len(hs)
+    D = hs[0].shape[-1]
+    for h in hs:
+        if h.dtype != BF16 or not h.is_contiguous() or h.numel() != B * T * D:
+            raise ValueError("feature_select: hidden states must be contiguous bf16 [B*T, D]")
+    feat = torch.empty((B * (T - 1), n * D), dtype=BF16, device=hs[0].device)
+    arr = (C.c_void_p * n)(*[h.data_ptr() for h in hs])
+    rc = _lib.lib().libra_feature_select(arr, n, feat.data_ptr(), B, T, D, _stream())
+    _lib.check(rc, "feature_select")
+    return feat
+
+
+def feature_select_bwd(dfeat: torch.Tensor, dhs: Sequence[torch.Tensor], accumulate: Sequence[bool], B: int, T: int):
+    n = len(dhs)
+    D = dhs[0].shape[-1]
+    if dfeat.dtype != BF16 or not dfeat.is_contiguous() or dfeat.numel() != B * (T - 1) * n * D:
+        raise ValueError("feature_select_bwd: dfeat must be contiguous bf16 [B*(T-1), n*D]")
+    arr = (C.c_void_p * n)(*[h.data_ptr() for h in dhs])
+    acc = (C.c_int * n)(*[int(a) for a in accumulate])
+    rc = _lib.lib().libra_feature_select_bwd(dfeat.data_ptr(), arr, acc, n, B, T, D, _stream())
+    _lib.check(rc, "feature_select_bwd")
+
+
+def lfq_encode(h: torch.Tensor, w_in, b_in, w_out, b_out, *, B: int, hw: int, Q: int, offset: int, boi: int,
+               eoi: int, want_ids: bool = True, want_xpre: bool = False, want_quant: bool = False):
+    _chk2d(h, "h")
+    if not h.is_contiguous() or h.shape[0] != B * hw:
+        raise ValueError("lfq_encode: h must be contiguous [B*hw, E]")
+    E = h.shape[1]
+    dev = h.device
+    indices = torch.empty((B * hw, Q), dtype=torch.int64, device=dev)
+    ids = torch.empty((Q, B, hw + 2), dtype=torch.int64, device=dev) if want_ids else None
+    xpre = torch.empty((B * hw, Q * 9), dtype=BF16, device=dev) if want_xpre else None
+    quant = torch.empty((B * hw, E), dtype=BF16, device=dev) if want_quant else None
+    rc = _lib.lib().libra_lfq_encode(h.data_ptr(), _ptr(w_in), _ptr(b_in), _ptr(w_out), _ptr(b_out),
+                                     indices.data_ptr(), _ptr(ids), _ptr(xpre), _ptr(quant), B, hw, E, Q, offset, boi,
+                                     eoi, _stream())
+    _lib.check(rc, "lfq_encode")
+    return indices, ids, xpre, quant
+
+
+def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    rc = _lib.lib().libra_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    _lib.check(rc, "f32_to_bf16")
+    return out
+
+
+def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a += b (bf16, contiguous)."""
+    if a.shape != b.shape or not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("add_: contiguous equal shapes required")
+    rc = _lib.lib().libra_add_bf16(a.data_ptr(), b.data_ptr(), a.data_ptr(), a.numel(), _stream())
+    _lib.check(rc, "add_bf16")
+    return a
+
+
+# ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
+class LaunchProfile:
+    """Context manager: while active, every gemm_nt / vit_attn_* call is bracketed by events on the current
+    stream (the stream the kernel is launched on) and (kind, work, ms) is available after .finish()."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        LaunchProfile.active = self
+        return self
+
+    def __exit__(self, *a):
+        LaunchProfile.active = None
+
+    def bracket(self, kind, work):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append([kind, work, s, e])
+        return s, e
+
+    def finish(self):
+        torch.cuda.synchronize()
+        return [(k, w, s.elapsed_time(e)) for k, w, s, e in self.records]
+
+
+def _profiled(kind, work_fn):
+    def deco(fn):
+        def wrapper(*a, **kw):
+            prof = LaunchProfile.active
+            if prof is None:
+                return fn(*a, **kw)
+            s, e = prof.bracket(kind, work_fn(*a, **kw))
+            s.record()
+            r = fn(*a, **kw)
+            e.record()
+            return r
+        wrapper.__name__ = fn.__name__
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
+
+
+def _gemm_flops(a, b, **kw):
+    k = kw.get("k") or a.shape[1]
+    return 2.0 * a.shape[0] * b.shape[0] * k
+
+
+gemm_nt = _profiled("gemm", _gemm_flops)(gemm_nt)

@@ -1,0 +1,89 @@
+"""VQModel (encode path) — mirror of /root/reference/libra/models/libra/taming/models/vqgan.py:26-114.
+
+``encode`` = CLIP tower -> quant_conv (1x1 conv == GEMM with bias) -> LFQ, all on gfx950 kernels.
+The conv decoder / ``decode*`` / training_step parts of the reference class are image *generation*
+and tokenizer *training* code that Libra's train path never reaches: they are not
+implemented, and ``load_state_dict`` reports the skipped ``decoder.`` / ``post_quant_conv.`` keys.
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .clip_encoder import CLIPVisionTower
+from .lookup_free_quantization import LFQ
+
+
+class VQModel(nn.Module):
+    def __init__(self, ddconfig, embed_dim, lossconfig=None, ckpt_path=None, ignore_keys=[], image_key="image",
+                 colorize_nlabels=None, monitor=None, codebook_size=512, num_codebook=2, disable_loss=False,
+                 vision_model=None):
+        super().__init__()
+        self.image_key = image_key
+        self.encoder_name = ddconfig.get("encoder_name", "default")
+        self.use_clip = "clip" in self.encoder_name
+        if not self.use_clip and vision_model is None:
+            raise NotImplementedError("only the CLIP-tower encoder is on the Libra hot path (vqgan.py:44-56; the "
+                                      "conv Encoder is dead code there)")
+        select_layer = ddconfig.get("select_layer", -2)
+        self.encoder = CLIPVisionTower(vision_tower=self.encoder_name, square_output=True, select_layer=select_layer,
+                                       model=vision_model)
+        self.quantize = LFQ(dim=embed_dim, codebook_size=codebook_size, num_codebooks=num_codebook,
+                            entropy_loss_weight=0.1, commitment_loss_weight=1., diversity_gamma=2.5)
+        n_sel = len(self.encoder._select_list())
+        self.quant_conv = nn.Conv2d(self.encoder.vision_tower.config.hidden_size * n_sel, embed_dim, 1)
+        self.embed_dim = embed_dim
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        skipped = [k for k in sd if k.startswith(("decoder.", "post_quant_conv."))]
+        for k in skipped:
+            del sd[k]
+        self.load_state_dict(sd, strict=True)
+        print(f"Restored from {path} ({len(skipped)} decoder-side keys skipped: generation path not built)")
+
+    def encode_flat(self, x, *, offset=0, boi=0, eoi=0, want_ids=False, want_quant=True, want_xpre=False):
+        """Fused entry: -> (feat [B,hw,C], h2d [B*hw,E], indices [B*hw,Q], ids|None, xpre|None, quant2d|None)."""
+        feat = self.encoder.forward_flat(x)                              # [B, hw, C]
+        B, hw, Cf = feat.shape
+        w = self.quant_conv.weight.view(self.embed_dim, Cf)
+        h2d = K.gemm_nt(feat.view(B * hw, Cf), w, bias=self.quant_conv.bias)          # vqgan.py:108
+        idx, ids, xpre, q2d = self.quantize.encode_flat(h2d, B, hw, offset=offset, boi=boi, eoi=eoi,
+                                                        want_ids=want_ids, want_quant=want_quant, want_xpre=want_xpre)
+        return feat, h2d, idx, ids, xpre, q2d
+
+    @torch.no_grad()
+    def encode(self, x, return_encoder_feat=False):
+        feat, h2d, idx, _, _, q2d = self.encode_flat(x)
+        B, hw, Cf = feat.shape
+        g = int(round(hw ** 0.5))
+        quant = q2d.view(B, g, g, self.embed_dim).permute(0, 3, 1, 2)
+        info = idx.view(B, g, g, self.quantize.num_codebooks)
+        emb_loss = self.quantize.zero * 0.1 + self.quantize.zero * 1.
+        if return_encoder_feat:
+            return quant, emb_loss, info, feat.view(B, g, g, Cf).permute(0, 3, 1, 2)
+        return quant, emb_loss, info
+
+    def encode_without_quant(self, x):
+        feat = self.encoder.forward_flat(x)
+        B, hw, Cf = feat.shape
+        g = int(round(hw ** 0.5))
+        h2d = K.gemm_nt(feat.view(B * hw, Cf), self.quant_conv.weight.view(self.embed_dim, Cf), bias=self.quant_conv.bias)
+        return h2d.view(B, g, g, self.embed_dim).permute(0, 3, 1, 2), None, None
+
+    def decode(self, *a, **k):
+        raise NotImplementedError("VQ decode (image generation) is SURVEY §8f item 2 — not on the training hot path")
+
+    decode_code = decode

@@ -1,0 +1,232 @@
+"""Forward / backward schedule of the CLIP ViT encoder on the gfx950 kernels.
+
+This is the host-side "graph" of the hot path a1-a7 of SURVEY.md §8: which kernel runs on which
+buffer, what is saved for backward, and which K-contiguous operand copies the NT GEMM needs
+(transposed weights for dgrad, transposed activations/gradients for wgrad).  All math is in
+``libra_amd/csrc``; torch supplies memory and streams only.
+
+Reference semantics being reproduced (file:line relative to /root/reference/libra/models/clip):
+  modeling_clip.py:193-228 embeddings, :893 pre_layrnorm, :390-428 encoder layer (pre-LN residual),
+  :287-363 attention (q scaled by hd^-0.5, softmax over keys), :374-378 MLP with quick_gelu,
+  :664-694 collection of all hidden states.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+P = "vision_model."
+
+
+@dataclass
+class VitDims:
+    hidden: int
+    inter: int
+    layers: int
+    heads: int
+    patch: int
+    image: int
+    channels: int = 3
+    eps: float = 1e-5
+
+    @property
+    def grid(self):
+        return self.image // self.patch
+
+    @property
+    def tokens(self):
+        return self.grid * self.grid + 1
+
+    @property
+    def kpe(self):           # im2col width, padded to the GEMM's K granule
+        return K.round_up(self.channels * self.patch * self.patch, 64)
+
+    @property
+    def t_pad(self):         # token padding of the transposed (token-contiguous) attention operands
+        return K.round_up(self.tokens, 64)
+
+
+class _Packed:
+    """Device-side operand copies derived from the parameters (rebuilt when a parameter changes):
+    fused [q;k;v] weight/bias, the zero-padded patch-embedding matrix, and — for backward — the
+    transposed (K-contiguous for dgrad) weights."""
+
+    def __init__(self):
+        self.key = None
+        self.fwd = None
+        self.bwd = None
+
+
+def _versions(params: Dict[str, torch.Tensor]):
+    return tuple((p.data_ptr(), p._version) for p in params.values())
+
+
+def pack_forward(params: Dict[str, torch.Tensor], dims: VitDims):
+    D = dims.hidden
+    out = {"layers": []}
+    wpe = params[P + "embeddings.patch_embedding.weight"].detach().reshape(D, -1)
+    wpad = torch.zeros((D, dims.kpe), dtype=BF16, device=wpe.device)
+    wpad[:, : wpe.shape[1]] = wpe
+    out["wpe"] = wpad
+    for i in range(dims.layers):
+        pre = f"{P}encoder.layers.{i}.self_attn."
+        out["layers"].append({
+            "wqkv": torch.cat([params[pre + f"{n}_proj.weight"].detach() for n in "qkv"], 0).contiguous(),
+            "bqkv": torch.cat([params[pre + f"{n}_proj.bias"].detach() for n in "qkv"], 0).contiguous(),
+        })
+    return out
+
+
+def pack_backward(params, dims: VitDims, fwd):
+    out = {"layers": []}
+    out["wpe_t"] = K.transpose(fwd["wpe"])                                   # [kpe, D]
+    for i in range(dims.layers):
+        pre = f"{P}encoder.layers.{i}."
+        out["layers"].append({
+            "wqkv_t": K.transpose(fwd["layers"][i]["wqkv"]),                  # [D, 3D]
+            "wo_t": K.transpose(params[pre + "self_attn.out_proj.weight"].detach()),
+            "w1_t": K.transpose(params[pre + "mlp.fc1.weight"].detach()),     # [D, I]
+            "w2_t": K.transpose(params[pre + "mlp.fc2.weight"].detach()),     # [I, D]
+        })
+    return out
+
+
+def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: VitDims, *, save: bool,
+            n_layers: Optional[int] = None):
+    """-> (hidden_states: list of L+1 tensors [B*T, D] bf16, saved-for-backward dict or None)."""
+    if pixel.dim() != 4 or pixel.shape[1] != dims.channels or pixel.shape[2] != dims.image or pixel.shape[3] != dims.image:
+        raise ValueError(f"pixel_values must be [B,{dims.channels},{dims.image},{dims.image}], got {tuple(pixel.shape)}")
+    B = pixel.shape[0]
+    T, D, H = dims.tokens, dims.hidden, dims.heads
+    if D // H != 64 or D % H:
+        raise ValueError("the gfx950 ViT attention kernel is specialised for head_dim 64 (CLIP ViT-L/14)")
+    scale = 64 ** -0.5
+    L = dims.layers if n_layers is None else n_layers
+    pixel = pixel.to(BF16).contiguous()
+    cols = K.patch_im2col(pixel, dims.patch, dims.kpe)
+    patches = K.gemm_nt(cols, packed["wpe"])
+    emb, x, mean0, rstd0 = K.vit_embed_ln(patches, params[P + "embeddings.class_embedding"],
+                                          params[P + "embeddings.position_embedding.weight"],
+                                          params[P + "pre_layrnorm.weight"], params[P + "pre_layrnorm.bias"], B, T,
+                                          dims.eps, save=save)
+    hs: List[torch.Tensor] = [x]
+    saved = {"B": B, "cols": cols, "emb": emb, "mean0": mean0, "rstd0": rstd0, "layers": []} if save else None
+    for i in range(L):
+        pre = f"{P}encoder.layers.{i}."
+        pk = packed["layers"][i]
+        xn1, m1, r1 = K.layernorm_fwd(x, params[pre + "layer_norm1.weight"], params[pre + "layer_norm1.bias"], dims.eps,
+                                      save_stats=save)
+        qkv = K.gemm_nt(xn1, pk["wqkv"], bias=pk["bqkv"])
+        vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, dims.t_pad)
+        o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, dims.t_pad, scale, need_lse=save)
+        x_mid = K.gemm_nt(o, params[pre + "self_attn.out_proj.weight"], bias=params[pre + "self_attn.out_proj.bias"],
+                          resid=x)
+        xn2, m2, r2 = K.layernorm_fwd(x_mid, params[pre + "layer_norm2.weight"], params[pre + "layer_norm2.bias"],
+                                      dims.eps, save_stats=save)
+        hpre = torch.empty((B * T, dims.inter), dtype=BF16, device=x.device) if save else None
+        act = K.gemm_nt(xn2, params[pre + "mlp.fc1.weight"], bias=params[pre + "mlp.fc1.bias"], quick_gelu=True,
+                        preact_out=hpre)
+        x_out = K.gemm_nt(act, params[pre + "mlp.fc2.weight"], bias=params[pre + "mlp.fc2.bias"], resid=x_mid)
+        if save:
+            saved["layers"].append(dict(x=x, xn1=xn1, m1=m1, r1=r1, qkv=qkv, o=o, lse=lse, x_mid=x_mid, xn2=xn2,
+                                        m2=m2, r2=r2, hpre=hpre, act=act))
+        x = x_out
+        hs.append(x)
+    return hs, saved
+
+
+def _wgrad(dy_t: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
+    """dW[N_out, K_in] = dY^T[N_out, M] . X[M, K_in]  as an NT GEMM over the token-contiguous copies."""
+    x_t = K.transpose(x, m_pad)
+    return K.gemm_nt(dy_t, x_t)
+
+
+def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
+             *, need_pixel_grad: bool = True):
+    """Given d(loss)/d(hidden_states[i]) (None = zero) return (d_pixel or None, {param name: bf16 grad}).
+
+    Residual-stream gradient flows from the last layer that has a non-zero cotangent downwards; layers
+    above it are skipped entirely (their gradient is exactly zero)."""
+    B = saved["B"]
+    T, D, H, I = dims.tokens, dims.hidden, dims.heads, dims.inter
+    M = B * T
+    m_pad = K.round_up(M, 64)
+    scale = 64 ** -0.5
+    dev = saved["cols"].device
+    grads: Dict[str, torch.Tensor] = {}
+    L = len(saved["layers"])
+    top = max((i for i, g in enumerate(dhs) if g is not None), default=-1)
+    if top < 0:
+        return None, grads
+    dx = dhs[top].reshape(M, D).to(BF16).contiguous().clone()
+    f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    for i in range(min(top, L) - 1, -1, -1):
+        pre = f"{P}encoder.layers.{i}."
+        s = saved["layers"][i]
+        pb = packed_bwd["layers"][i]
+        # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
+        db2 = f32(D)
+        dxo_t = K.transpose(dx, m_pad, colsum=db2)                               # [D, Mp]
+        grads[pre + "mlp.fc2.weight"] = _wgrad(dxo_t, s["act"], m_pad)
+        grads[pre + "mlp.fc2.bias"] = K.f32_to_bf16(db2)
+        dh = K.gemm_nt(dx, pb["w2_t"], qgelu_grad_of=s["hpre"])                  # [M, I] = (dx W2) * gelu'(hpre)
+        db1 = f32(I)
+        dh_t = K.transpose(dh, m_pad, colsum=db1)
+        grads[pre + "mlp.fc1.weight"] = _wgrad(dh_t, s["xn2"], m_pad)
+        grads[pre + "mlp.fc1.bias"] = K.f32_to_bf16(db1)
+        dxn2 = K.gemm_nt(dh, pb["w1_t"])                                         # [M, D]
+        dg2, dbt2 = f32(D), f32(D)
+        dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
+                                 dgamma=dg2, dbeta=dbt2)
+        grads[pre + "layer_norm2.weight"] = K.f32_to_bf16(dg2)
+        grads[pre + "layer_norm2.bias"] = K.f32_to_bf16(dbt2)
+        # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
+        dbo = f32(D)
+        dxm_t = K.transpose(dx_mid, m_pad, colsum=dbo)
+        grads[pre + "self_attn.out_proj.weight"] = _wgrad(dxm_t, s["o"], m_pad)
+        grads[pre + "self_attn.out_proj.bias"] = K.f32_to_bf16(dbo)
+        do = K.gemm_nt(dx_mid, pb["wo_t"])                                       # [M, D]
+        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, dims.t_pad, scale)
+        dbqkv = f32(3 * D)
+        dqkv_t = K.transpose(dqkv, m_pad, colsum=dbqkv)
+        dwqkv = _wgrad(dqkv_t, s["xn1"], m_pad)                                  # [3D, D]
+        dbq = K.f32_to_bf16(dbqkv)
+        for j, n in enumerate("qkv"):
+            grads[pre + f"self_attn.{n}_proj.weight"] = dwqkv[j * D:(j + 1) * D]
+            grads[pre + f"self_attn.{n}_proj.bias"] = dbq[j * D:(j + 1) * D]
+        dxn1 = K.gemm_nt(dqkv, pb["wqkv_t"])
+        dg1, dbt1 = f32(D), f32(D)
+        dx = K.layernorm_bwd(dxn1, s["x"], params[pre + "layer_norm1.weight"], s["m1"], s["r1"], dres=dx_mid,
+                             dgamma=dg1, dbeta=dbt1)
+        grads[pre + "layer_norm1.weight"] = K.f32_to_bf16(dg1)
+        grads[pre + "layer_norm1.bias"] = K.f32_to_bf16(dbt1)
+        if dhs[i] is not None:
+            K.add_(dx, dhs[i].reshape(M, D).to(BF16).contiguous())
+    # ---- embeddings: hs0 = LN(emb); emb = [cls ; patches] + pos
+    dg0, db0 = f32(D), f32(D)
+    demb = K.layernorm_bwd(dx, saved["emb"], params[P + "pre_layrnorm.weight"], saved["mean0"], saved["rstd0"],
+                           dgamma=dg0, dbeta=db0)
+    grads[P + "pre_layrnorm.weight"] = K.f32_to_bf16(dg0)
+    grads[P + "pre_layrnorm.bias"] = K.f32_to_bf16(db0)
+    demb3 = demb.view(B, T, D)
+    # tiny batch reductions (B x 577 x 1024 -> 577 x 1024): plumbing, not the hot path
+    dpos = demb3.float().sum(0)
+    grads[P + "embeddings.position_embedding.weight"] = dpos.to(BF16)
+    grads[P + "embeddings.class_embedding"] = demb3[:, 0].float().sum(0).to(BF16)
+    dpatch = demb3[:, 1:].reshape(B * (T - 1), D)                                # contiguous copy
+    np_pad = K.round_up(B * (T - 1), 64)
+    dp_t = K.transpose(dpatch, np_pad)
+    cols_t = K.transpose(saved["cols"], np_pad)                                   # [kpe, Np]
+    dwpe = K.gemm_nt(dp_t, cols_t)                                                # [D, kpe]
+    kk = dims.channels * dims.patch * dims.patch
+    grads[P + "embeddings.patch_embedding.weight"] = dwpe[:, :kk].reshape(D, dims.channels, dims.patch, dims.patch)
+    dpixel = None
+    if need_pixel_grad:
+        dcols = K.gemm_nt(dpatch, packed_bwd["wpe_t"])                            # [Np, kpe]
+        dpixel = K.patch_col2im(dcols, B, dims.channels, dims.image, dims.image, dims.patch)
+    return dpixel, grads

@@ -27,7 +27,8 @@ def _save(name, tensors, meta):
     print(f"wrote {name}: {len(tensors)} tensors, {sz:.2f} MB")
 
 
-VIT_TINY = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+# head_dim must be 64 (as in CLIP ViT-L/14) for the gfx950 attention kernel the fixtures also check
+VIT_TINY = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
                 image_size=56, patch_size=14)
 
 

@@ -1,0 +1,252 @@
+"""Per-kernel parity of the gfx950 C-ABI kernels against plain fp32 math on the same bf16 inputs.
+
+Tolerance (stated once, used everywhere): an output element `o` (bf16) must satisfy
+    |o - ref| <= 1e-3 * max|ref|  +  2^-8 * |ref|
+i.e. the north-star 1e-3 max-norm bound plus one bf16 ulp for the final rounding of the element itself
+(a bf16 result cannot be closer than half an ulp to an fp32 reference).  Integer outputs are bit-exact.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def close(out, ref, rel=1e-3, what=""):
+    out = out.float().cpu().double()
+    ref = ref.float().cpu().double()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), what
+    tol = rel * ref.abs().max() + (2.0 ** -8) * ref.abs()
+    bad = (out - ref).abs() > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} outside tolerance, max err "
+                           f"{float((out - ref).abs().max()):.4g} vs max|ref| {float(ref.abs().max()):.4g}")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).cuda()
+
+
+@pytest.fixture(scope="module")
+def K():
+    from libra_amd import kernels
+    return kernels
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (256, 256, 128), (100, 72, 64), (1000, 1024, 1024),
+                                    (577, 3072, 1024), (130, 136, 192), (18464, 1024, 1024), (64, 4096, 1024)])
+def test_gemm_plain(K, M, N, K_):
+    a, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2)     # asymmetric random operands (transpose-detecting)
+    out = K.gemm_nt(a, b)
+    close(out, a.float() @ b.float().t(), what=f"gemm {M}x{N}x{K_}")
+
+
+def test_gemm_identity_layout(K):
+    # A = I (padded), B asymmetric: catches a row/col swap in the C fragment mapping
+    n = 128
+    a = torch.eye(n, dtype=BF, device="cuda")
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(BF).cuda()
+    out = K.gemm_nt(a, b)
+    assert torch.equal(out, b.t().contiguous())
+
+
+def test_gemm_epilogues(K):
+    M, N, K_ = 300, 264, 128
+    a, b = rnd(M, K_, seed=3), rnd(N, K_, seed=4, scale=0.2)
+    bias, res, aux = rnd(N, seed=5), rnd(M, N, seed=6), rnd(M, N, seed=7)
+    base = a.float() @ b.float().t()
+    close(K.gemm_nt(a, b, bias=bias), base + bias.float(), what="bias")
+    close(K.gemm_nt(a, b, bias=bias, resid=res), base + bias.float() + res.float(), what="bias+resid")
+    sc = torch.ones(N); sc[:100] = 0.125
+    close(K.gemm_nt(a, b, bias=bias, alpha=0.125, alpha_cols=100), (base + bias.float()) * sc.cuda(), what="alpha")
+    pre = torch.empty(M, N, dtype=BF, device="cuda")
+    out = K.gemm_nt(a, b, bias=bias, quick_gelu=True, preact_out=pre)
+    close(pre, base + bias.float(), what="preact")
+    p = pre.float()
+    close(out, p * torch.sigmoid(1.702 * p), what="quick_gelu(bf16 preact)")
+    x = aux.float()
+    s = torch.sigmoid(1.702 * x)
+    close(K.gemm_nt(a, b, qgelu_grad_of=aux), base * (s * (1 + 1.702 * x * (1 - s))), what="qgelu_grad")
+    # strided output / operand views (column slices of wider buffers)
+    wide = torch.zeros(M, N + 64, dtype=BF, device="cuda")
+    K.gemm_nt(a, b, out=wide[:, 64:])
+    close(wide[:, 64:], base, what="strided out")
+    assert float(wide[:, :64].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_shapes(K):
+    a, b = rnd(64, 96), rnd(64, 96)
+    with pytest.raises(ValueError):
+        K.gemm_nt(a, b)                       # K % 64 != 0
+    with pytest.raises(ValueError):
+        K.gemm_nt(rnd(64, 128), rnd(64, 64))  # inner dims differ
+    out = K.gemm_nt(rnd(0, 64), rnd(8, 64))   # empty problem is a no-op, like torch
+    assert out.shape == (0, 8)
+
+
+@pytest.mark.parametrize("rows,D", [(7, 128), (1000, 1024), (33, 2048), (18, 4096), (5, 64)])
+def test_layernorm_fwd_bwd(K, rows, D):
+    x, g, b, dy, dres = rnd(rows, D, seed=1), rnd(D, seed=2) * 0.1 + 1, rnd(D, seed=3), rnd(rows, D, seed=4), rnd(rows, D, seed=5)
+    g = g.to(BF)
+    y, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5)
+    xf = x.float().requires_grad_(True); gf = g.float().requires_grad_(True); bf = b.float().requires_grad_(True)
+    ref = F.layer_norm(xf, (D,), gf, bf, 1e-5)
+    close(y, ref.detach(), what="ln fwd")
+    ref.backward(dy.float())
+    dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    dx = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dg, dbeta=db)
+    close(dx, xf.grad + dres.float(), what="ln dx")
+    close(K.f32_to_bf16(dg), gf.grad, rel=2e-3, what="ln dgamma")
+    close(K.f32_to_bf16(db), bf.grad, rel=2e-3, what="ln dbeta")
+
+
+def test_transpose(K):
+    x = rnd(577, 200, seed=9)
+    cs = torch.zeros(200, device="cuda")
+    t = K.transpose(x, 640, colsum=cs)
+    assert t.shape == (200, 640)
+    assert torch.equal(t[:, :577], x.t())
+    assert float(t[:, 577:].abs().max()) == 0.0
+    close(cs, x.float().sum(0), what="colsum")
+    # batched token transpose of a column slice
+    B, T, Tp, C = 3, 17, 64, 256
+    big = rnd(B * T, 3 * C, seed=10)
+    out = K.transpose_tokens(big[:, 2 * C:], B, T, Tp)
+    assert out.shape == (C, B * Tp)
+    for b in range(B):
+        assert torch.equal(out[:, b * Tp: b * Tp + T], big[b * T:(b + 1) * T, 2 * C:].t())
+        assert float(out[:, b * Tp + T:(b + 1) * Tp].abs().max()) == 0.0
+
+
+def test_patch_im2col_col2im(K):
+    B, C, H, P = 2, 3, 56, 14
+    pix = rnd(B, C, H, H, seed=11)
+    cols = K.patch_im2col(pix, P, 640)
+    g = H // P
+    ref = pix.reshape(B, C, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, C * P * P)
+    assert torch.equal(cols[:, :588], ref)
+    assert float(cols[:, 588:].abs().max()) == 0.0
+    back = K.patch_col2im(cols, B, C, H, H, P)
+    assert torch.equal(back, pix)
+
+
+def test_embed_ln(K):
+    B, T, D = 3, 17, 128
+    patches, cls, pos = rnd(B * (T - 1), D, seed=1), rnd(D, seed=2), rnd(T, D, seed=3)
+    g, b = (rnd(D, seed=4) * 0.1 + 1).to(BF), rnd(D, seed=5)
+    emb, hs0, mean, rstd = K.vit_embed_ln(patches, cls, pos, g, b, B, T, 1e-5)
+    e = torch.cat([cls.float().expand(B, 1, D), patches.float().view(B, T - 1, D)], 1) + pos.float()
+    e = e.to(BF)
+    assert torch.equal(emb.view(B, T, D), e)
+    close(hs0.view(B, T, D), F.layer_norm(e.float(), (D,), g.float(), b.float(), 1e-5), what="pre-LN")
+
+
+def _attn_ref(qkv, B, T, H, scale):
+    D = H * 64
+    q, k, v = [t.float().view(B, T, H, 64).transpose(1, 2) for t in qkv.split(D, dim=1)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = torch.softmax(s, -1)
+    o = (p @ v).transpose(1, 2).reshape(B * T, D)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 17, 2), (1, 64, 1), (2, 65, 2), (1, 128, 1), (2, 129, 3), (2, 577, 16)])
+def test_attention_fwd(K, B, T, H):
+    D = H * 64
+    qkv = rnd(B * T, 3 * D, seed=T)
+    Tp = K.round_up(T, 64)
+    vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, Tp)
+    o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, Tp, 0.125)
+    ro, rl = _attn_ref(qkv, B, T, H, 0.125)
+    close(o, ro, rel=2e-3, what="attn out")        # P is fed to the MFMA in bf16 (as the reference's bmm does)
+    close(lse, rl, rel=1e-4, what="lse")
+
+
+def test_attention_fwd_spiky_rows(K):
+    # one huge logit per row forces the online-softmax rescale path hard (max jumps by >> 8 at a late tile)
+    B, T, H = 1, 200, 1
+    qkv = rnd(B * T, 192, seed=3)
+    qkv[:, 64:128][150] = qkv[:, 64:128][150] * 40
+    Tp = 256
+    vt = K.transpose_tokens(qkv[:, 128:], B, T, Tp)
+    o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, Tp, 0.125)
+    ro, rl = _attn_ref(qkv, B, T, H, 0.125)
+    close(o, ro, rel=2e-3, what="attn out spiky")
+    close(lse, rl, rel=1e-4, what="lse spiky")
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 17, 2), (1, 64, 1), (2, 129, 2), (1, 577, 4)])
+def test_attention_bwd(K, B, T, H):
+    D = H * 64
+    qkv = rnd(B * T, 3 * D, seed=T + 1)
+    do = rnd(B * T, D, seed=T + 2)
+    Tp = K.round_up(T, 64)
+    vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, Tp)
+    o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, Tp, 0.125)
+    dqkv = K.vit_attn_bwd(qkv, o, do, lse, B, T, H, Tp, 0.125)
+    ref_in = qkv.float().requires_grad_(True)
+    ro, _ = _attn_ref(ref_in, B, T, H, 0.125)
+    ro.backward(do.float())
+    for j, n in enumerate("qkv"):
+        close(dqkv[:, j * D:(j + 1) * D], ref_in.grad[:, j * D:(j + 1) * D], rel=4e-3, what=f"d{n}")
+
+
+def test_feature_select(K):
+    B, T, D = 2, 17, 128
+    a, b = rnd(B * T, D, seed=1), rnd(B * T, D, seed=2)
+    f = K.feature_select([a, b], B, T)
+    ref = torch.cat([a.view(B, T, D), b.view(B, T, D)], -1)[:, 1:].reshape(B * (T - 1), 2 * D)
+    assert torch.equal(f, ref)
+    da, db = torch.empty_like(a), rnd(B * T, D, seed=3)
+    db0 = db.clone()
+    K.feature_select_bwd(f, [da, db], [False, True], B, T)
+    assert float(da.view(B, T, D)[:, 0].abs().max()) == 0.0
+    assert torch.equal(da.view(B, T, D)[:, 1:], a.view(B, T, D)[:, 1:])
+    close(db.view(B, T, D)[:, 1:], (db0.float() + b.float()).view(B, T, D)[:, 1:], what="accumulate")
+
+
+@pytest.mark.parametrize("E", [18, 32, 512])
+def test_lfq_encode(K, E):
+    from oracle import vq_oracle as QO
+    B, hw, Q = 3, 16, 2
+    h = rnd(B * hw, E, seed=E)
+    sd = QO.random_vq_state_dict(c_feat=8, embed_dim=E, dtype=BF)
+    dev = {k: v.cuda() for k, v in sd.items()}
+    idx, ids, xpre, quant = K.lfq_encode(h, dev.get("quantize.project_in.weight"), dev.get("quantize.project_in.bias"),
+                                         dev.get("quantize.project_out.weight"), dev.get("quantize.project_out.bias"),
+                                         B=B, hw=hw, Q=Q, offset=32000, boi=32512, eoi=32513, want_ids=True,
+                                         want_xpre=True, want_quant=True)
+    # oracle in float64 with the same rounding point (x rounded to bf16 before the sign test)
+    hd = h.cpu().double()
+    if E != 18:
+        x = hd @ sd["quantize.project_in.weight"].double().t() + sd["quantize.project_in.bias"].double()
+    else:
+        x = hd
+    xb = x.float().to(BF)
+    bits = (xb.float() > 0).view(B * hw, Q, 9)
+    mask = (2 ** torch.arange(8, -1, -1)).long()
+    ref_idx = (bits.long() * mask).sum(-1)
+    margin = x.abs().view(B * hw, Q, 9)
+    got = idx.cpu()
+    mism = got != ref_idx
+    if mism.any():
+        # a disagreement is only admissible when the fp64 pre-sign value is within fp32 accumulation noise of 0
+        rows = mism.nonzero()
+        for r, q in rows.tolist():
+            gb = ((got[r, q] >> torch.arange(8, -1, -1)) & 1).bool()
+            diff = gb != bits[r, q]
+            assert float(margin[r, q][diff].max()) < 1e-5, ("LFQ bit flipped with a non-negligible margin", r, q)
+    assert int(mism.sum()) <= 1, f"{int(mism.sum())} index mismatches"
+    assert torch.equal(ids[:, :, 0].cpu(), torch.full((Q, B), 32512))
+    assert torch.equal(ids[:, :, -1].cpu(), torch.full((Q, B), 32513))
+    assert torch.equal(ids[:, :, 1:-1].cpu(), got.view(B, hw, Q).permute(2, 0, 1) + 32000)
+    sign = torch.where(((got.unsqueeze(-1) >> torch.arange(8, -1, -1)) & 1).bool(), 1.0, -1.0).view(B * hw, Q * 9)
+    if E != 18:
+        rq = sign.double() @ sd["quantize.project_out.weight"].double().t() + sd["quantize.project_out.bias"].double()
+        close(quant, rq.float(), what="quant")
+        close(xpre, x.float(), what="xpre")
+    else:
+        assert torch.equal(quant.float().cpu(), sign)
