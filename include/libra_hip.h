@@ -113,12 +113,12 @@ int libra_feature_select_bwd(const void* dfeat, void* const* dhs, const int* acc
 
 /* ---- LFQ sign-quantise + pack (LFQ.forward eval branch, lookup_free_quantization.py:185-208, and
  *      ImageTokenizer.encode, image_tokenizer.py:77-86) -------------------------------------------
- * h [rows, E] bf16 (rows = B*hw, the quant_conv output); w_in [Q*9, E], b_in [Q*9] bf16 or NULL when
+ * h [rows, E] bf16, row stride ld_h (rows = B*hw, the quant_conv output); w_in [Q*9, E], b_in [Q*9] bf16 or NULL when
  * E == Q*9 (no projection).  x = bf16(h . w_in^T + b_in); bit = x > 0; index_q = sum bit * 2^(8-j).
  * Outputs (any may be NULL): indices int64 [rows, Q];  ids int64 [Q, B, hw+2] = offset+index framed by
  * BOI/EOI;  xpre bf16 [rows, Q*9] (the pre-sign value, for margin reports);
  * quant bf16 [rows, E] = project_out(+-1) (w_out [E, Q*9], b_out [E]; or +-1 itself when no projection). */
-int libra_lfq_encode(const void* h, const void* w_in, const void* b_in, const void* w_out,
+int libra_lfq_encode(const void* h, int64_t ld_h, const void* w_in, const void* b_in, const void* w_out,
                      const void* b_out, int64_t* indices, int64_t* ids, void* xpre, void* quant,
                      int64_t B, int64_t hw, int64_t E, int64_t Q, int64_t offset, int64_t boi,
                      int64_t eoi, void* stream);

@@ -31,7 +31,7 @@ SIGNATURES = {
     "libra_vit_attn_bwd": [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
     "libra_feature_select": [_P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_feature_select_bwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _P],
-    "libra_lfq_encode": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "libra_lfq_encode": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
 }

@@ -90,7 +90,7 @@ class _VitFunction(torch.autograd.Function):
         names = model._param_names
         pd = dict(zip(names, params))
         dims = model._dims
-        need_grad = torch.is_grad_enabled() and (pixel_values.requires_grad or any(p.requires_grad for p in params))
+        need_grad = any(ctx.needs_input_grad)      # grad mode is always off inside Function.forward
         packed = model._packed_forward(pd)
         hs, saved = E.forward(pd, packed, pixel_values, dims, save=need_grad)
         B = pixel_values.shape[0]

@@ -16,7 +16,7 @@ constexpr int LFQ_MAX_CD = 36;     // Q*9, Q <= 4
 struct LfqArgs {
     const bf16_t* h; const bf16_t* w_in; const bf16_t* b_in; const bf16_t* w_out; const bf16_t* b_out;
     long long* indices; long long* ids; bf16_t* xpre; bf16_t* quant;
-    long rows; int B, hw, E, Q, CD;
+    long rows, ld_h; int B, hw, E, Q, CD;
     long long offset, boi, eoi;
     int has_proj;
 };
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void lfq_encode_kernel(const LfqArgs p) {
             for (int j = 0; j < LFQ_MAX_CD; ++j) x[j] = 0.f;
             for (int c = lane; c < nch; c += 64) {
                 float hv[8];
-                unpack8(*(const u32x4*)(p.h + row * E + c * 8), hv);
+                unpack8(*(const u32x4*)(p.h + row * p.ld_h + c * 8), hv);
 #pragma unroll
                 for (int j = 0; j < LFQ_MAX_CD; ++j) {
                     if (j < CD) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void lfq_encode_kernel(const LfqArgs p) {
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < LFQ_MAX_CD; ++j) x[j] = (j < CD) ? bf2f(p.h[row * E + j]) : 0.f;
+            for (int j = 0; j < LFQ_MAX_CD; ++j) x[j] = (j < CD) ? bf2f(p.h[row * p.ld_h + j]) : 0.f;
         }
         // every lane now holds all CD values
         unsigned long long bits = 0ull;
@@ -108,16 +108,16 @@ __global__ __launch_bounds__(256) void lfq_encode_kernel(const LfqArgs p) {
 
 using namespace libra;
 
-extern "C" int libra_lfq_encode(const void* h, const void* w_in, const void* b_in, const void* w_out,
+extern "C" int libra_lfq_encode(const void* h, int64_t ld_h, const void* w_in, const void* b_in, const void* w_out,
                                 const void* b_out, int64_t* indices, int64_t* ids, void* xpre, void* quant,
                                 int64_t B, int64_t hw, int64_t E, int64_t Q, int64_t offset, int64_t boi, int64_t eoi,
                                 void* stream) {
     const long rows = B * hw;
     if (rows <= 0) return LIBRA_OK;
     const int64_t CD = Q * 9;
-    if (Q < 1 || CD > LFQ_MAX_CD || E < CD) return LIBRA_ERR_SHAPE;
+    if (Q < 1 || CD > LFQ_MAX_CD || E < CD || ld_h < E) return LIBRA_ERR_SHAPE;
     const int has_proj = (E != CD);
-    if (has_proj && ((E % 8) || CD * E * 2 > 64 * 1024)) return LIBRA_ERR_SHAPE;
+    if (has_proj && ((E % 8) || (ld_h % 8) || CD * E * 2 > 64 * 1024)) return LIBRA_ERR_SHAPE;
     if (!h || (((uintptr_t)h) & 15)) return LIBRA_ERR_ALIGN;
     if (has_proj && (!w_in || !b_in || (((uintptr_t)w_in) & 15))) return LIBRA_ERR_ALIGN;
     if (quant && has_proj && (!w_out || !b_out)) return LIBRA_ERR_ALIGN;
@@ -125,7 +125,7 @@ extern "C" int libra_lfq_encode(const void* h, const void* w_in, const void* b_i
     a.h = (const bf16_t*)h; a.w_in = (const bf16_t*)w_in; a.b_in = (const bf16_t*)b_in;
     a.w_out = (const bf16_t*)w_out; a.b_out = (const bf16_t*)b_out;
     a.indices = (long long*)indices; a.ids = (long long*)ids; a.xpre = (bf16_t*)xpre; a.quant = (bf16_t*)quant;
-    a.rows = rows; a.B = (int)B; a.hw = (int)hw; a.E = (int)E; a.Q = (int)Q; a.CD = (int)CD;
+    a.rows = rows; a.ld_h = ld_h; a.B = (int)B; a.hw = (int)hw; a.E = (int)E; a.Q = (int)Q; a.CD = (int)CD;
     a.offset = offset; a.boi = boi; a.eoi = eoi; a.has_proj = has_proj;
     const size_t lds = has_proj ? (size_t)(CD * E * 2) : 16;
     static bool attr_set = false;

@@ -234,15 +234,15 @@ def feature_select_bwd(dfeat: torch.Tensor, dhs: Sequence[torch.Tensor], accumul
 def lfq_encode(h: torch.Tensor, w_in, b_in, w_out, b_out, *, B: int, hw: int, Q: int, offset: int, boi: int,
                eoi: int, want_ids: bool = True, want_xpre: bool = False, want_quant: bool = False):
     _chk2d(h, "h")
-    if not h.is_contiguous() or h.shape[0] != B * hw:
-        raise ValueError("lfq_encode: h must be contiguous [B*hw, E]")
+    if h.shape[0] != B * hw:
+        raise ValueError("lfq_encode: h must be [B*hw, E]")
     E = h.shape[1]
     dev = h.device
     indices = torch.empty((B * hw, Q), dtype=torch.int64, device=dev)
     ids = torch.empty((Q, B, hw + 2), dtype=torch.int64, device=dev) if want_ids else None
     xpre = torch.empty((B * hw, Q * 9), dtype=BF16, device=dev) if want_xpre else None
     quant = torch.empty((B * hw, E), dtype=BF16, device=dev) if want_quant else None
-    rc = _lib.lib().libra_lfq_encode(h.data_ptr(), _ptr(w_in), _ptr(b_in), _ptr(w_out), _ptr(b_out),
+    rc = _lib.lib().libra_lfq_encode(h.data_ptr(), h.stride(0), _ptr(w_in), _ptr(b_in), _ptr(w_out), _ptr(b_out),
                                      indices.data_ptr(), _ptr(ids), _ptr(xpre), _ptr(quant), B, hw, E, Q, offset, boi,
                                      eoi, _stream())
     _lib.check(rc, "lfq_encode")

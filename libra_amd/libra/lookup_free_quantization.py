@@ -75,7 +75,7 @@ class LFQ(nn.Module):
             raise NotImplementedError("image-shaped input [B, dim, h, w] expected on this path")
         B, E, H, W = x.shape
         assert E == self.dim, f'expected dimension of {self.dim} but received {E}'
-        h2d = x.permute(0, 2, 3, 1).reshape(B * H * W, E).contiguous().to(torch.bfloat16)
+        h2d = x.permute(0, 2, 3, 1).reshape(B * H * W, E).to(torch.bfloat16).contiguous()
         idx, _, _, q2d = self.encode_flat(h2d, B, H * W)
         quant = q2d.view(B, H, W, E).permute(0, 3, 1, 2)
         indices = idx.view(B, H, W, self.num_codebooks)

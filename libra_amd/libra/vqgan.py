@@ -54,12 +54,19 @@ class VQModel(nn.Module):
         self.load_state_dict(sd, strict=True)
         print(f"Restored from {path} ({len(skipped)} decoder-side keys skipped: generation path not built)")
 
+    def _quant_conv(self, feat2d, w):
+        E = self.embed_dim
+        out = None
+        if E % 8:                          # e.g. E == 18 (no LFQ projection): 16-byte row alignment for the GEMM store
+            out = torch.empty((feat2d.shape[0], K.round_up(E, 8)), dtype=feat2d.dtype, device=feat2d.device)[:, :E]
+        return K.gemm_nt(feat2d, w, bias=self.quant_conv.bias, out=out)
+
     def encode_flat(self, x, *, offset=0, boi=0, eoi=0, want_ids=False, want_quant=True, want_xpre=False):
         """Fused entry: -> (feat [B,hw,C], h2d [B*hw,E], indices [B*hw,Q], ids|None, xpre|None, quant2d|None)."""
         feat = self.encoder.forward_flat(x)                              # [B, hw, C]
         B, hw, Cf = feat.shape
         w = self.quant_conv.weight.view(self.embed_dim, Cf)
-        h2d = K.gemm_nt(feat.view(B * hw, Cf), w, bias=self.quant_conv.bias)          # vqgan.py:108
+        h2d = self._quant_conv(feat.view(B * hw, Cf), w)                                # vqgan.py:108
         idx, ids, xpre, q2d = self.quantize.encode_flat(h2d, B, hw, offset=offset, boi=boi, eoi=eoi,
                                                         want_ids=want_ids, want_quant=want_quant, want_xpre=want_xpre)
         return feat, h2d, idx, ids, xpre, q2d
@@ -80,7 +87,7 @@ class VQModel(nn.Module):
         feat = self.encoder.forward_flat(x)
         B, hw, Cf = feat.shape
         g = int(round(hw ** 0.5))
-        h2d = K.gemm_nt(feat.view(B * hw, Cf), self.quant_conv.weight.view(self.embed_dim, Cf), bias=self.quant_conv.bias)
+        h2d = self._quant_conv(feat.view(B * hw, Cf), self.quant_conv.weight.view(self.embed_dim, Cf))
         return h2d.view(B, g, g, self.embed_dim).permute(0, 3, 1, 2), None, None
 
     def decode(self, *a, **k):

@@ -17,11 +17,12 @@ __global__ void k(unsigned short* out, int mode) {
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)(v >> (16 * j));
 }
 int main() {
-    unsigned short* d; hipMalloc(&d, 64 * 4 * 2);
+    unsigned short* d; hipError_t e = hipMalloc(&d, 64 * 4 * 2); printf("malloc: %s\n", hipGetErrorString(e));
     for (int mode = 0; mode < 3; ++mode) {
         hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, mode);
         std::vector<unsigned short> h(256);
-        hipMemcpy(h.data(), d, 512, hipMemcpyDeviceToHost);
+        e = hipDeviceSynchronize(); printf("sync: %s\n", hipGetErrorString(e));
+        e = hipMemcpy(h.data(), d, 512, hipMemcpyDeviceToHost); printf("copy: %s\n", hipGetErrorString(e));
         printf("mode %d\n", mode);
         for (int l = 0; l < 64; ++l) printf("lane %2d: %4d %4d %4d %4d\n", l, h[l*4], h[l*4+1], h[l*4+2], h[l*4+3]);
     }
