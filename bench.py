@@ -85,7 +85,11 @@ def cpu_baseline(sample_iters=3):
     """The CPU oracle (oracle/vit_oracle.py, proven equal to the reference's modules on the golden fixtures) timed on
     this box's host cores: ViT-L/14@336 fwd+bwd, B=1, fp32."""
     from oracle import vit_oracle as VO
-    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))          # cores this container may actually use
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, 64))                        # torch CPU GEMMs stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(n)
     sd = VO.random_vit_state_dict(hidden=1024, inter=4096, layers=24, patch=14, image=336, seed=42)
     sd = {k: v.requires_grad_(True) for k, v in sd.items()}
@@ -99,13 +103,18 @@ def cpu_baseline(sample_iters=3):
         hs = VO.vit_hidden_states(sd, x, patch=14, heads=16, layers=24)
         f = VO.feature_select(hs, [-2, -3], square=False)
         (f * ct).sum().backward()
-    one()
     t0 = time.perf_counter()
-    for _ in range(sample_iters):
+    one()                                          # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    iters = max(1, min(sample_iters, int(20.0 / max(warm, 1e-3))))     # ~20 s of CPU work
+    t0 = time.perf_counter()
+    for _ in range(iters):
         one()
-    dt = (time.perf_counter() - t0) / sample_iters
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"ViT-L/14@336 fwd+bwd (feature cotangent), B=1, fp32, {sample_iters} timed iters after 1 warm-up"}
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"ViT-L/14@336 fwd+bwd (feature cotangent), B=1, fp32, {iters} timed iters after 1 warm-up "
+                      f"({warm:.1f} s)"}
 
 
 def main():
@@ -131,6 +140,10 @@ def main():
     clip, tok, pixel, cot = build(device, args.batch)
     step = make_step(clip, tok, pixel, cot, world)
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    note(f"built model; world={world} batch={args.batch}")
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -151,6 +164,7 @@ def main():
 
     ms = dt / args.steps * 1e3
     ips = args.batch * world * args.steps / dt
+    note(f"timed {args.steps} steps: {ms:.2f} ms/step, {ips:.1f} images/s")
 
     # ---- roofline leg: one instrumented step, events around every GEMM launch on the launch stream ----
     from libra_amd import kernels as K
@@ -178,6 +192,7 @@ def main():
                       "value_per_gpu": round(ips / world, 2)},
            "roofline": roof}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        note("timing the CPU oracle on the host cores ...")
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)

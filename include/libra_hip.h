@@ -55,10 +55,12 @@ int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, v
 int libra_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
                         float* rstd, int64_t rows, int64_t D, float eps, void* stream);
 /* dx [rows,D] bf16 (optionally dx += dres, the residual-branch gradient, bf16 [rows,D]);
- * dgamma/dbeta: fp32 [D] accumulators the caller zeroes (atomically accumulated), may be NULL.      */
+ * dgamma/dbeta: fp32 [D], ADDED to (deterministic two-stage reduction through `workspace`, no atomics),
+ * may both be NULL (then no workspace is needed).  D <= 4096.                                         */
+size_t libra_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
 int libra_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
                         const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                        int64_t rows, int64_t D, void* stream);
+                        void* workspace, size_t workspace_bytes, int64_t rows, int64_t D, void* stream);
 
 /* ---- patch embedding front end (CLIPVisionEmbeddings.forward, modeling_clip.py:193-228) -----------
  * im2col of non-overlapping PxP patches: pixel [B,C,H,W] bf16 -> cols [B*(H/P)*(W/P), Kpad] bf16 with

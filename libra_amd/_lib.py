@@ -20,8 +20,9 @@ SIGNATURES = {
     "libra_hip_abi_version": [],
     "libra_gemm_bf16_nt": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
                            _F, _I64, _I, _P],
+    "libra_layernorm_bwd_workspace_bytes": [_I64, _I64],
     "libra_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
-    "libra_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
+    "libra_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
     "libra_patch_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_patch_col2im": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_vit_embed_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
@@ -55,7 +56,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_size_t if name.endswith("_workspace_bytes") else C.c_int
     v = lib.libra_hip_abi_version()
     if v != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} has ABI version {v}, host expects {ABI_VERSION}; rebuild it")

@@ -132,17 +132,42 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_bwd_kernel(
         }
     }
     if (dgamma) {
+        // per-wave partial rows [part][2][D] (deterministic second stage: ln_param_reduce_kernel) — no atomics
+        float* pg = dgamma + ((long)(blockIdx.x * ROWS_PER_BLOCK + wave) * 2) * D;
+        float* pb = pg + D;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunks) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    atomicAdd(dgamma + c * 8 + e, ag[i][e]);
-                    atomicAdd(dbeta + c * 8 + e, ab[i][e]);
-                }
+                *(f32x4*)(pg + c * 8) = f32x4{ag[i][0], ag[i][1], ag[i][2], ag[i][3]};
+                *(f32x4*)(pg + c * 8 + 4) = f32x4{ag[i][4], ag[i][5], ag[i][6], ag[i][7]};
+                *(f32x4*)(pb + c * 8) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
+                *(f32x4*)(pb + c * 8 + 4) = f32x4{ab[i][4], ab[i][5], ab[i][6], ab[i][7]};
             }
         }
+    }
+}
+
+// out_gamma[d] += sum_p part[p][0][d];  out_beta[d] += sum_p part[p][1][d].  64 columns x 16 row groups per block.
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int D,
+                                                               float* __restrict__ out_gamma,
+                                                               float* __restrict__ out_beta) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int which = blockIdx.y;
+    const int col = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (col < D) {
+        for (int p = rg; p < nparts; p += 16) s += part[((long)p * 2 + which) * D + col];
+    }
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && col < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        float* o = which ? out_beta : out_gamma;
+        o[col] += t;
     }
 }
 
@@ -221,24 +246,45 @@ extern "C" int libra_layernorm_fwd(const void* x, const void* gamma, const void*
     });
 }
 
+static long ln_bwd_rows_per_block(long rows) {
+    // ~2 workgroups per CU worth of row strips
+    long rpb = (rows + 511) / 512;
+    return ((rpb + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * ROWS_PER_BLOCK;
+}
+
+extern "C" size_t libra_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) {
+    if (rows <= 0 || D <= 0) return 0;
+    const long rpb = ln_bwd_rows_per_block(rows);
+    const long grid = (rows + rpb - 1) / rpb;
+    return (size_t)grid * ROWS_PER_BLOCK * 2 * D * sizeof(float);
+}
+
 extern "C" int libra_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                   int64_t rows, int64_t D, void* stream) {
+                                   void* workspace, size_t workspace_bytes, int64_t rows, int64_t D, void* stream) {
     if (rows <= 0) return LIBRA_OK;
     if (D <= 0 || (D % 8) || D > 4096) return LIBRA_ERR_SHAPE;     // the whole row + partials stay in registers
     if (!dy || !x || !gamma || !mean || !rstd || !dx) return LIBRA_ERR_ALIGN;
     if (!al16(dy) || !al16(x) || !al16(gamma) || !al16(dx) || (dres && !al16(dres))) return LIBRA_ERR_ALIGN;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return LIBRA_ERR_ALIGN;
-    // ~2 blocks per CU worth of strips keeps the atomic traffic at a few hundred adds per column
-    long rpb = (rows + 511) / 512;
-    rpb = ((rpb + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * ROWS_PER_BLOCK;
+    const long rpb = ln_bwd_rows_per_block(rows);
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
-    return dispatch_nc((int)D, [&](auto nc) {
+    float* part = nullptr;
+    if (dgamma) {
+        if (!workspace || (((uintptr_t)workspace) & 15) || workspace_bytes < libra_layernorm_bwd_workspace_bytes(rows, D))
+            return LIBRA_ERR_ALIGN;
+        part = (float*)workspace;
+    }
+    const int rc = dispatch_nc((int)D, [&](auto nc) {
         hipLaunchKernelGGL((layernorm_bwd_kernel<decltype(nc)::value>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0,
                            (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, mean,
-                           rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, (long)rows, (int)D, (int)rpb);
+                           rstd, (const bf16_t*)dres, (bf16_t*)dx, part, (float*)nullptr, (long)rows, (int)D, (int)rpb);
         return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
     });
+    if (rc != LIBRA_OK || !dgamma) return rc;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((D + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream,
+                       part, (int)(grid * ROWS_PER_BLOCK), (int)D, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
 
 extern "C" int libra_vit_embed_ln(const void* patches, const void* cls, const void* pos, const void* gamma,

@@ -106,9 +106,13 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=Non
     if dy.shape != x.shape or not (dy.is_contiguous() and x.is_contiguous()):
         raise ValueError("layernorm_bwd: dy/x must be contiguous and equal-shaped")
     dx = torch.empty_like(x) if out is None else out
+    ws, ws_bytes = None, 0
+    if dgamma is not None:
+        ws_bytes = _lib.lib().libra_layernorm_bwd_workspace_bytes(rows, D)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     rc = _lib.lib().libra_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                        rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), rows,
-                                        D, _stream())
+                                        rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+                                        _ptr(ws), ws_bytes, rows, D, _stream())
     _lib.check(rc, f"layernorm_bwd rows={rows} D={D}")
     return dx
 

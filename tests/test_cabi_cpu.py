@@ -15,7 +15,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\bint\s+(libra_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t)\s+(libra_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         out[m.group(1)] = args
     return out
@@ -54,6 +54,8 @@ def test_host_prototypes_match_header(lib_path):
         for a, ct in zip(args, _lib.SIGNATURES[name]):
             if "*" in a:
                 assert ct is ctypes.c_void_p, (name, a)
+            elif a.startswith("size_t"):
+                assert ct is ctypes.c_size_t, (name, a)
             elif a.startswith("int64_t"):
                 assert ct is ctypes.c_int64, (name, a)
             elif a.startswith("float"):

@@ -8,12 +8,13 @@ __global__ void k(unsigned short* out, int mode) {
     int l = threadIdx.x;
     for (int i = l; i < 2048; i += 64) lds[i] = (unsigned short)i;
     __syncthreads();
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)lds;   // escape the array
     unsigned addr;
     if (mode == 0) addr = l * 8;                                   // lane i -> elements 4i..4i+3
     else if (mode == 1) addr = (l & 15) * 128 + (l >> 4) * 8;      // 16 rows of 64 elements; group g -> cols 4g..
     else addr = ((l & 3) * 4 + ((l >> 2) & 3) * 64 + (l >> 4) * 256) * 2;
     unsigned long long v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr + base) : "memory");
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)(v >> (16 * j));
 }
 int main() {
