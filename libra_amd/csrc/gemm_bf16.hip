@@ -21,6 +21,8 @@
 //
 // Requirements (checked by the C entry point): K % 64 == 0, row strides % 8 == 0 elements, pointers
 // 16-byte aligned.  M and N are arbitrary (tail rows are clamped on load and masked on store).
+#include <cmath>
+#include <cstdlib>
 #include "hip_common.hpp"
 #include "../../include/libra_hip.h"
 
@@ -209,6 +211,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
 
 using namespace libra;
 
+extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                     int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                     float alpha, int64_t alpha_cols, int flags, void* stream);
+
+// Tile-structure choice (speed only): the 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of
+// workgroups but runs 1 workgroup / CU (256 slots) against 2 / CU (512 slots) for the 128^2 kernel.
+static int pick_256(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    static int mode = -1;                          // LIBRA_GEMM_KERNEL = 128 | 256 forces a structure (benchmarks)
+    if (mode < 0) { const char* e = getenv("LIBRA_GEMM_KERNEL"); mode = e ? atoi(e) : 0; }
+    if (mode == 128) return 0;
+    if (M * lda >= (1LL << 31) || N * ldb >= (1LL << 31)) return 0;       // 32-bit source offsets in that kernel
+    if (mode == 256) return 1;
+    if (M < 256 || N < 256 || K < 256) return 0;
+    const double b256 = (double)((M + 255) / 256) * ((N + 255) / 256);
+    const double b128 = (double)((M + 127) / 128) * ((N + 127) / 128);
+    const double t256 = ceil(b256 / 256.0) * 4.0 / 1.5;                  // time units: waves x work per block / speed
+    const double t128 = ceil(b128 / 512.0) * 1.0;
+    return t256 <= t128;
+}
+
 extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                   int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                   int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
@@ -225,6 +248,9 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
     if ((flags & LIBRA_GEMM_STORE_PREACT) && (!preact || (ldpre % 8) || ldpre < N || ((uintptr_t)preact & 15))) return LIBRA_ERR_ALIGN;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return LIBRA_ERR_SHAPE;
 
+    if (pick_256(M, N, K, lda, ldb))
+        return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha,
+                                     alpha_cols, flags, stream);
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;

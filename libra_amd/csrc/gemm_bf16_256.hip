@@ -1,0 +1,284 @@
+// bf16 "NT" GEMM, 256x256x64 tile, 8-phase software pipeline (gfx950).  Same contract and epilogue as
+// gemm_bf16.hip's 128x128 kernel; used for problems large enough to fill the chip with 256^2 tiles.
+//
+// Why a second structure: the 128^2 / one-barrier-per-K-tile kernel moves 15.6 B of L2->LDS traffic per
+// kFLOP and drains its load queue at every barrier; it tops out near 0.9 PF/s.  Here
+//   * a workgroup is 8 wave64 (2 x 4), each wave owns a 128x64 output block (8 MFMA 32x32 accumulators =
+//     128 VGPRs) -> 7.8 B/kFLOP;
+//   * a K tile is FOUR 128x64 half-tiles (A_lo, A_hi, B_lo, B_hi; 16 KiB each, the same source-swizzled
+//     lane-linear LDS image as the small kernel), two K-tile buffers = 128 KiB LDS, 1 workgroup / CU;
+//   * every K tile is processed in 4 phases = the 4 (64x32) quadrants of the wave's block, each phase
+//     {LDS->register fragment reads + ONE half-tile of direct-to-LDS prefetch -> s_barrier -> 8 MFMA ->
+//     s_barrier}; fragments are reused across quadrants (A0,B0 | B1 | A1 | -) so a phase reads 12/4/8/0
+//     ds_read_b128;
+//   * the two wave groups (rows 0-127 / 128-255) run the phase sequence staggered by ONE barrier, so on
+//     every SIMD one wave issues LDS/VMEM work while its partner owns the matrix pipe (s_setprio 1);
+//   * the prefetch stream never drains: half-tiles are issued in the order A_lo(t+1) A_hi(t+1) B_lo(t+2)
+//     B_hi(t+2) and the only wait is a counted `s_waitcnt vmcnt(4)` once per K tile (phase 4), i.e. two
+//     half-tiles stay in flight across every barrier.  A buffer is re-staged only after the reads of it
+//     were retired before a barrier every wave has passed (B: lgkmcnt(0) before phase 2's barrier).
+#include "hip_common.hpp"
+#include "../../include/libra_hip.h"
+
+namespace libra {
+
+constexpr int HB = 16384;               // one 128x64 half-tile
+constexpr int KTB = 4 * HB;             // one K tile: A_lo A_hi B_lo B_hi
+constexpr int G256_LDS = 2 * KTB;       // 128 KiB
+constexpr int G256_THREADS = 512;
+
+struct Gemm256Args {
+    const bf16_t* A; const bf16_t* B; bf16_t* C;
+    const bf16_t* bias; const bf16_t* resid; const bf16_t* aux; bf16_t* preact;
+    long lda, ldb, ldc, ldr, ldaux, ldpre;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    float alpha; int alpha_cols;
+    int flags;
+};
+
+__device__ __forceinline__ float qgelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float qgelu_grad(float x) {
+    const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+#define LIBRA_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LIBRA_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const Gemm256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l31 = lane & 31, fk = lane >> 5;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int u = xcd_remap(blockIdx.x, ntiles);
+    constexpr int GM = 4;
+    const int width = GM * p.tiles_n;
+    const int grp = u / width;
+    const int first_m = grp * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (u % width) % gsz;
+    const int tn = (u % width) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- per-lane source offsets (elements) of this wave's 2 x 1-KiB pieces of every half-tile type
+    unsigned srcA[2][2], srcB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = wave * 16 + j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int ga = m0 + h * 128 + r; ga = ga < p.M ? ga : p.M - 1;
+            int gb = n0 + h * 128 + r; gb = gb < p.N ? gb : p.N - 1;
+            srcA[h][j] = (unsigned)ga * (unsigned)p.lda + c * 8;
+            srcB[h][j] = (unsigned)gb * (unsigned)p.ldb + c * 8;
+        }
+    const int ldst = wave * 16 * 128;      // this wave's byte offset inside any half-tile
+
+    auto stageA = [&](int h, int kt) {
+        char* dst = smem + (kt & 1) * KTB + h * HB + ldst;
+        const bf16_t* base = p.A + (long)kt * 64;
+        glds16(base + srcA[h][0], dst);
+        glds16(base + srcA[h][1], dst + 1024);
+    };
+    auto stageB = [&](int h, int kt) {
+        char* dst = smem + (kt & 1) * KTB + (2 + h) * HB + ldst;
+        const bf16_t* base = p.B + (long)kt * 64;
+        glds16(base + srcB[h][0], dst);
+        glds16(base + srcB[h][1], dst + 1024);
+    };
+
+    // ---- fragment read addressing: byte offset of (row = l31 (+32k), chunk = 2*ks + fk) inside a half-tile
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + ((((2 * ks + fk) ^ ((l31 >> 1) & 7))) << 4);
+    const int aoff = wr * HB;                                  // A half of this wave group
+    const int boff = (2 + (wc >> 1)) * HB + (wc & 1) * 64 * 128;   // B half + 64-row block of this wave
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K >> 6;
+
+    // ---- prologue: K tile 0 complete, B halves of K tile 1 in flight
+    stageA(0, 0); stageA(1, 0); stageB(0, 0); stageB(1, 0);
+    if (nk > 1) { stageB(0, 1); stageB(1, 1); LIBRA_VMCNT(4); } else { LIBRA_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                 // stagger the second wave group by one barrier
+
+    bf16x8 a[2][4], b0[4], b1[4];
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* buf = smem + (kt & 1) * KTB;
+        const char* sa = buf + aoff;
+        const char* sb = buf + boff;
+        // ================= phase 1: read B0, A0; prefetch A_lo(kt+1); quadrant (0,0) =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const bf16x8*)(sb + koff[ks]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[i][ks] = *(const bf16x8*)(sa + i * 4096 + koff[ks]);
+        if (kt + 1 < nk) stageA(0, kt + 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b0[ks], acc[i][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 2: read B1; prefetch A_hi(kt+1); quadrant (0,1) =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b1[ks] = *(const bf16x8*)(sb + 4096 + koff[ks]);
+        if (kt + 1 < nk) stageA(1, kt + 1);
+        LIBRA_LGKMCNT0();            // all B reads of this K tile retired before the barrier: B may be re-staged next phase
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b1[ks], acc[i][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 3: read A1; prefetch B_lo(kt+2); quadrant (1,1) =================
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[i][ks] = *(const bf16x8*)(sa + (2 + i) * 4096 + koff[ks]);
+        if (kt + 2 < nk) stageB(0, kt + 2);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b1[ks], acc[2 + i][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ================= phase 4: prefetch B_hi(kt+2); counted wait for K tile kt+1; quadrant (1,0) =================
+        if (kt + 2 < nk) { stageB(1, kt + 2); LIBRA_VMCNT(4); } else { LIBRA_VMCNT(0); }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b0[ks], acc[2 + i][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                 // re-align the two groups
+    __syncthreads();
+
+    // ---- epilogue: each wave round-trips its own 32x64 fp32 slabs through a private 8 KiB LDS region ----
+    float* ct = (float*)(smem + wave * 8192);
+    const int cg = lane & 7;                                   // 8-column group within the wave's 64 columns
+    const int gn = n0 + wc * 64 + cg * 8;
+    const bool ncol_ok = gn < p.N;
+    const bool full8 = gn + 8 <= p.N;
+    float bias[8], cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias[e] = 0.f; cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f; }
+    if ((p.flags & LIBRA_GEMM_BIAS) && ncol_ok) {
+        if (full8) unpack8(*(const u32x4*)(p.bias + gn), bias);
+        else for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
+    }
+    auto epi = [&](const f32x16& c0, const f32x16& c1, const int i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[((r & 3) + 8 * (r >> 2) + 4 * fk) * 64 + j * 32 + l31] = (j == 0 ? c0 : c1)[r];
+        // same-wave LDS write -> read (in-order per wave)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3);
+            const int gm = m0 + wr * 128 + i * 32 + row;
+            if (gm < p.M && ncol_ok) {
+                float v[8];
+                const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
+                const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
+                if (p.flags & LIBRA_GEMM_STORE_PREACT) {
+                    bf16_t* pd = p.preact + (long)gm * p.ldpre + gn;
+                    if (full8) *(u32x4*)pd = pack8(v);
+                    else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
+                }
+                if (p.flags & LIBRA_GEMM_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = qgelu(bf2f(f2bf(v[e])));
+                }
+                if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
+                    float x[8];
+                    if (full8) unpack8(*(const u32x4*)(p.aux + (long)gm * p.ldaux + gn), x);
+                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.aux[(long)gm * p.ldaux + gn + e]) : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad(x[e]);
+                }
+                if (p.flags & LIBRA_GEMM_RESIDUAL) {
+                    float x[8];
+                    if (full8) unpack8(*(const u32x4*)(p.resid + (long)gm * p.ldr + gn), x);
+                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.resid[(long)gm * p.ldr + gn + e]) : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += x[e];
+                }
+                bf16_t* dst = p.C + (long)gm * p.ldc + gn;
+                if (full8) *(u32x4*)dst = pack8(v);
+                else for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
+            }
+        }
+    };
+    epi(acc[0][0], acc[0][1], 0);
+    epi(acc[1][0], acc[1][1], 1);
+    epi(acc[2][0], acc[2][1], 2);
+    epi(acc[3][0], acc[3][1], 3);
+}
+
+}  // namespace libra
+
+using namespace libra;
+
+// Internal launcher (declared in gemm_bf16.hip): returns LIBRA_OK / LIBRA_ERR_LAUNCH. Arguments were validated.
+extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                     int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                     float alpha, int64_t alpha_cols, int flags, void* stream) {
+    Gemm256Args p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
+    p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldpre = ldpre;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (int)((N + 255) / 256);
+    p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+        attr_set = true;
+    }
+    const long nblk = (long)p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3((unsigned)nblk), dim3(G256_THREADS), G256_LDS, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+}
