@@ -49,6 +49,15 @@ int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, v
                        const void* aux, int64_t ldaux, void* preact, int64_t ldpre, float alpha,
                        int64_t alpha_cols, int flags, void* stream);
 
+/* split-K variant for wgrad-shaped problems (small M,N, very long K; no epilogue): K slices on the 256^2
+ * kernel, fp32 partial slabs in `workspace`, deterministic reduction to bf16 C.  plan() suggests the number
+ * of slices for a shape (1 = use libra_gemm_bf16_nt).  N % 8 == 0.                                   */
+int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K);
+size_t libra_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t splits);
+int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                              int64_t M, int64_t N, int64_t K, int64_t splits, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- LayerNorm over the last dim (nn.LayerNorm, eps 1e-5: modeling_clip.py:386-388,:866) ---------
  * x,y [rows,D] bf16 contiguous, gamma/beta [D] bf16, mean/rstd [rows] fp32 (saved for backward, may be
  * NULL).  D % 8 == 0, D <= 8192.                                                                     */

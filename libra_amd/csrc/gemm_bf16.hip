@@ -214,7 +214,8 @@ using namespace libra;
 extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                      int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
-                                     float alpha, int64_t alpha_cols, int flags, void* stream);
+                                     float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
+                                     void* stream);
 
 // Tile-structure choice (speed only): the 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of
 // workgroups but runs 1 workgroup / CU (256 slots) against 2 / CU (512 slots) for the 128^2 kernel.
@@ -227,9 +228,37 @@ static int pick_256(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
     if (M < 256 || N < 256 || K < 256) return 0;
     const double b256 = (double)((M + 255) / 256) * ((N + 255) / 256);
     const double b128 = (double)((M + 127) / 128) * ((N + 127) / 128);
-    const double t256 = ceil(b256 / 256.0) * 4.0 / 1.5;                  // time units: waves x work per block / speed
+    const double t256 = ceil(b256 / 256.0) * 1.6;                        // one 256^2 block = 4 x the work at ~1.25x the CU rate
     const double t128 = ceil(b128 / 512.0) * 1.0;
     return t256 <= t128;
+}
+
+// ---- split-K (wgrad-shaped problems: small M,N, very long K): the 256^2 kernel over K slices + a deterministic
+// fp32 slab reduction.  plan() returns the number of slices (1 = not worth it).
+extern "C" int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
+    if (M < 256 || N < 256 || K < 4096 || (M % 8) || (N % 8)) return 1;
+    const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    if (tiles > 128) return 1;
+    long s = 256 / tiles;
+    const long max_s = K / 64 / 8;                               // at least 8 K tiles per slice
+    if (s > max_s) s = max_s;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
+}
+extern "C" size_t libra_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t splits) {
+    return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+extern "C" int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                         int64_t M, int64_t N, int64_t K, int64_t splits, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0) return LIBRA_OK;
+    if (!A || !B || !C || K <= 0 || (K % BK) || splits < 2 || splits > K / BK) return LIBRA_ERR_SHAPE;
+    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (N % 8) || lda < K || ldb < K || ldc < N) return LIBRA_ERR_SHAPE;
+    if (M * lda >= (1LL << 31) || N * ldb >= (1LL << 31)) return LIBRA_ERR_SHAPE;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) return LIBRA_ERR_ALIGN;
+    if (!workspace || workspace_bytes < libra_gemm_splitk_workspace_bytes(M, N, splits)) return LIBRA_ERR_ALIGN;
+    return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 1.0f, 0, 0,
+                                 (float*)workspace, (int)splits, stream);
 }
 
 extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
@@ -250,7 +279,7 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
 
     if (pick_256(M, N, K, lda, ldb))
         return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha,
-                                     alpha_cols, flags, stream);
+                                     alpha_cols, flags, nullptr, 1, stream);
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;

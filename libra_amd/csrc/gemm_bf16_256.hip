@@ -35,6 +35,7 @@ struct Gemm256Args {
     int tiles_m, tiles_n;
     float alpha; int alpha_cols;
     int flags;
+    float* slab; int splitk;          // split-K: raw fp32 partial tiles to slab[split][M][N] (no epilogue)
 };
 
 __device__ __forceinline__ float qgelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
@@ -108,16 +109,18 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K >> 6;
+    const int nk_all = p.K >> 6;
+    const int kt0 = (int)((long)nk_all * blockIdx.y / p.splitk);
+    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / p.splitk);      // this split's K tiles are [kt0, nk)
 
     // ---- prologue: K tile 0 complete, B halves of K tile 1 in flight
-    stageA(0, 0); stageA(1, 0); stageB(0, 0); stageB(1, 0);
-    if (nk > 1) { stageB(0, 1); stageB(1, 1); LIBRA_VMCNT(4); } else { LIBRA_VMCNT(0); }
+    stageA(0, kt0); stageA(1, kt0); stageB(0, kt0); stageB(1, kt0);
+    if (kt0 + 1 < nk) { stageB(0, kt0 + 1); stageB(1, kt0 + 1); LIBRA_VMCNT(4); } else { LIBRA_VMCNT(0); }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                 // stagger the second wave group by one barrier
 
     bf16x8 a[2][4], b0[4], b1[4];
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const char* buf = smem + (kt & 1) * KTB;
         const char* sa = buf + aoff;
         const char* sb = buf + boff;
@@ -218,6 +221,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
                 float v[8];
                 const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
                 const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
+                if (p.slab) {
+                    float* sd = p.slab + ((long)blockIdx.y * p.M + gm) * p.N + gn;
+                    if (full8) { *(f32x4*)sd = lo; *(f32x4*)(sd + 4) = hi; }
+                    else for (int e = 0; e < 8 && gn + e < p.N; ++e) sd[e] = e < 4 ? lo[e] : hi[e - 4];
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
 #pragma unroll
@@ -257,6 +266,25 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     epi(acc[3][0], acc[3][1], 3);
 }
 
+// out[m][n] = bf16( sum_s slab[s][m][n] ), 8 elements per thread (deterministic split-K second stage)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int S, long MN, int N, bf16_t* __restrict__ C,
+                                                            long ldc) {
+    const long i8 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i8 >= MN) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const f32x4 a = *(const f32x4*)(slab + (long)s * MN + i8);
+        const f32x4 b = *(const f32x4*)(slab + (long)s * MN + i8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    }
+    const long m = i8 / N;
+    const int n = (int)(i8 - m * N);
+    *(u32x4*)(C + m * ldc + n) = pack8(v);
+}
+
 }  // namespace libra
 
 using namespace libra;
@@ -265,7 +293,8 @@ using namespace libra;
 extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                      int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
-                                     float alpha, int64_t alpha_cols, int flags, void* stream) {
+                                     float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
+                                     void* stream) {
     Gemm256Args p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
@@ -273,12 +302,21 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (int)((N + 255) / 256);
     p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
+    p.slab = slab; p.splitk = splitk < 1 ? 1 : splitk;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
         attr_set = true;
     }
     const long nblk = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3((unsigned)nblk), dim3(G256_THREADS), G256_LDS, (hipStream_t)stream, p);
-    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3((unsigned)nblk, (unsigned)p.splitk), dim3(G256_THREADS), G256_LDS,
+                       (hipStream_t)stream, p);
+    if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
+    if (slab) {
+        const long MN = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           slab, p.splitk, MN, (int)N, (bf16_t*)C, (long)ldc);
+        if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
+    }
+    return LIBRA_OK;
 }

@@ -51,6 +51,17 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     _chk2d(out, "out")
     if out.shape != (M, N):
         raise ValueError(f"gemm_nt: out is {tuple(out.shape)}, expected {(M, N)}")
+    plain = (bias is None and resid is None and not quick_gelu and qgelu_grad_of is None and preact_out is None
+             and alpha_cols == 0)
+    if plain and M > 0 and N > 0:
+        splits = _lib.lib().libra_gemm_splitk_plan(M, N, K)
+        if splits > 1:
+            nbytes = _lib.lib().libra_gemm_splitk_workspace_bytes(M, N, splits)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+            rc = _lib.lib().libra_gemm_bf16_nt_splitk(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                                      out.stride(0), M, N, K, splits, ws.data_ptr(), nbytes, _stream())
+            _lib.check(rc, f"gemm_nt_splitk M={M} N={N} K={K} S={splits}")
+            return out
     flags = 0
     if bias is not None:
         if bias.numel() != N or bias.dtype != BF16:

@@ -37,7 +37,8 @@ def K():
 
 
 @pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (256, 256, 128), (100, 72, 64), (1000, 1024, 1024),
-                                    (577, 3072, 1024), (130, 136, 192), (18464, 1024, 1024), (64, 4096, 1024)])
+                                    (577, 3072, 1024), (130, 136, 192), (18464, 1024, 1024), (64, 4096, 1024),
+                                    (1024, 1024, 18496), (512, 768, 8192), (4096, 4096, 512), (300, 520, 320)])
 def test_gemm_plain(K, M, N, K_):
     a, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2)     # asymmetric random operands (transpose-detecting)
     out = K.gemm_nt(a, b)
