@@ -44,6 +44,8 @@ int libra_hip_abi_version(void);
 #define LIBRA_GEMM_RESIDUAL 4        /* + resid[M,N] (bf16, ldr) — residual add of modeling_clip.py:413,:418 */
 #define LIBRA_GEMM_MUL_QGELU_GRAD 8  /* * d/dx quick_gelu(aux[M,N])  (backward of the fc1 activation) */
 #define LIBRA_GEMM_STORE_PREACT 16   /* also store the pre-activation (bf16) to preact[M,N] (saved for backward) */
+#define LIBRA_GEMM_A_T 32            /* A is given reduction-major: A^T [K, M] row-major, lda >= M, M % 8 == 0 (wgrad: dY) */
+#define LIBRA_GEMM_B_T 64            /* B is given reduction-major: [K, N] row-major, ldb >= N, N % 8 == 0 (dgrad: the weight itself; wgrad: X) */
 int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                        int64_t M, int64_t N, int64_t K, const void* bias, const void* resid, int64_t ldr,
                        const void* aux, int64_t ldaux, void* preact, int64_t ldpre, float alpha,
@@ -51,11 +53,11 @@ int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, v
 
 /* split-K variant for wgrad-shaped problems (small M,N, very long K; no epilogue): K slices on the 256^2
  * kernel, fp32 partial slabs in `workspace`, deterministic reduction to bf16 C.  plan() suggests the number
- * of slices for a shape (1 = use libra_gemm_bf16_nt).  N % 8 == 0.                                   */
+ * of slices for a shape (1 = use libra_gemm_bf16_nt).  N % 8 == 0; flags: LIBRA_GEMM_A_T / _B_T only.                                  */
 int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K);
 size_t libra_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t splits);
 int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                              int64_t M, int64_t N, int64_t K, int64_t splits, void* workspace,
+                              int64_t M, int64_t N, int64_t K, int64_t splits, int flags, void* workspace,
                               size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm over the last dim (nn.LayerNorm, eps 1e-5: modeling_clip.py:386-388,:866) ---------

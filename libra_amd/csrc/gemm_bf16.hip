@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdlib>
 #include "hip_common.hpp"
+#include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
 
 namespace libra {
@@ -43,32 +44,13 @@ struct GemmArgs {
     int flags;
 };
 
-// Stage one 128x64 operand tile: wave w copies rows [32w, 32w+32) with four 1-KiB direct-to-LDS
-// instructions.  LDS position p = lane (16-B units within the 1 KiB = 8 rows x 8 chunks) holds the
-// source chunk (p & 7) ^ swz(row).
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int row0, int nrows,
-                                           int k0, char* lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = wave * 32 + j * 8 + (lane >> 3);
-        int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1;                       // clamp the M/N tail (masked at the store)
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const bf16_t* src = g + (long)gr * ld + k0 + c * 8;
-        glds16(src, lds_tile + (wave * 32 + j * 8) * 128);
-    }
-}
-
-__device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
-    return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
     const float s = 1.0f / (1.0f + __expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
+template <bool AT, bool BT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -97,30 +79,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
-    stage_tile(p.A, p.lda, m0, p.M, 0, smem, wave, lane);
-    stage_tile(p.B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
-
-    const int frow = lane & 31;     // fragment row within a 32-row MFMA tile
-    const int fk = lane >> 5;       // which 8-wide k chunk of the 16-deep MFMA step
+    // per-lane source offsets of this wave's four 1-KiB pieces of each operand tile
+    unsigned srcA[4], srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        srcA[j] = stage_src<AT>(wave * 4 + j, lane, m0, p.M, p.lda);
+        srcB[j] = stage_src<BT>(wave * 4 + j, lane, n0, p.N, p.ldb);
+    }
+    const long kstepA = ktile_stride<AT>(p.lda), kstepB = ktile_stride<BT>(p.ldb);
+    auto stage = [&](int buf, int kt) {
+        char* da = smem + buf * 2 * TILE_BYTES + wave * 4096;
+        const bf16_t* ga = p.A + kt * kstepA;
+        const bf16_t* gb = p.B + kt * kstepB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ga + srcA[j], da + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(gb + srcB[j], da + TILE_BYTES + j * 1024);
+    };
+    stage(0, 0);
+    const FragAddr fa = make_frag_addr(lane);
+    const int toA[2] = {frag_toff<AT>(lane, wm * 2), frag_toff<AT>(lane, wm * 2 + 1)};
+    const int toB[2] = {frag_toff<BT>(lane, wn * 2), frag_toff<BT>(lane, wn * 2 + 1)};
 
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();            // tile kt landed everywhere; everyone is done reading the other buffer
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            char* nb = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(p.A, p.lda, m0, p.M, (kt + 1) * BK, nb, wave, lane);
-            stage_tile(p.B, p.ldb, n0, p.N, (kt + 1) * BK, nb + TILE_BYTES, wave, lane);
-        }
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* sa = smem + cur * 2 * TILE_BYTES;
         const char* sb = sa + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 af[2], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = lds_frag(sa, wm * 64 + i * 32 + frow, ks * 2 + fk);
+            for (int i = 0; i < 2; ++i) af[i] = load_frag<AT>(sa, fa, toA[i], ks);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = lds_frag(sb, wn * 64 + j * 32 + frow, ks * 2 + fk);
+            for (int j = 0; j < 2; ++j) bfr[j] = load_frag<BT>(sb, fa, toB[j], ks);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -219,11 +213,10 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
 
 // Tile-structure choice (speed only): the 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of
 // workgroups but runs 1 workgroup / CU (256 slots) against 2 / CU (512 slots) for the 128^2 kernel.
-static int pick_256(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+static int pick_256(int64_t M, int64_t N, int64_t K) {
     static int mode = -1;                          // LIBRA_GEMM_KERNEL = 128 | 256 forces a structure (benchmarks)
     if (mode < 0) { const char* e = getenv("LIBRA_GEMM_KERNEL"); mode = e ? atoi(e) : 0; }
     if (mode == 128) return 0;
-    if (M * lda >= (1LL << 31) || N * ldb >= (1LL << 31)) return 0;       // 32-bit source offsets in that kernel
     if (mode == 256) return 1;
     if (M < 256 || N < 256 || K < 256) return 0;
     const double b256 = (double)((M + 255) / 256) * ((N + 255) / 256);
@@ -249,15 +242,18 @@ extern "C" size_t libra_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 extern "C" int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                         int64_t M, int64_t N, int64_t K, int64_t splits, void* workspace,
+                                         int64_t M, int64_t N, int64_t K, int64_t splits, int flags, void* workspace,
                                          size_t workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0) return LIBRA_OK;
     if (!A || !B || !C || K <= 0 || (K % BK) || splits < 2 || splits > K / BK) return LIBRA_ERR_SHAPE;
-    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (N % 8) || lda < K || ldb < K || ldc < N) return LIBRA_ERR_SHAPE;
-    if (M * lda >= (1LL << 31) || N * ldb >= (1LL << 31)) return LIBRA_ERR_SHAPE;
+    if (flags & ~(LIBRA_GEMM_A_T | LIBRA_GEMM_B_T)) return LIBRA_ERR_SHAPE;
+    const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
+    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (N % 8) || ldc < N) return LIBRA_ERR_SHAPE;
+    if (at ? (lda < M || (M % 8) || K * lda >= (1LL << 31)) : (lda < K || M * lda >= (1LL << 31))) return LIBRA_ERR_SHAPE;
+    if (bt ? (ldb < N || K * ldb >= (1LL << 31)) : (ldb < K || N * ldb >= (1LL << 31))) return LIBRA_ERR_SHAPE;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) return LIBRA_ERR_ALIGN;
     if (!workspace || workspace_bytes < libra_gemm_splitk_workspace_bytes(M, N, splits)) return LIBRA_ERR_ALIGN;
-    return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 1.0f, 0, 0,
+    return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 1.0f, 0, flags,
                                  (float*)workspace, (int)splits, stream);
 }
 
@@ -267,7 +263,10 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
                                   float alpha, int64_t alpha_cols, int flags, void* stream) {
     if (M <= 0 || N <= 0) return LIBRA_OK;                       // empty problem: nothing to do
     if (!A || !B || !C || K <= 0 || (K % BK) != 0) return LIBRA_ERR_SHAPE;
-    if ((lda % 8) || (ldb % 8) || lda < K || ldb < K || ldc < N) return LIBRA_ERR_SHAPE;
+    const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
+    if ((lda % 8) || (ldb % 8) || ldc < N) return LIBRA_ERR_SHAPE;
+    if (at ? (lda < M || (M % 8) || K * lda >= (1LL << 31)) : (lda < K || M * lda >= (1LL << 31))) return LIBRA_ERR_SHAPE;
+    if (bt ? (ldb < N || (N % 8) || K * ldb >= (1LL << 31)) : (ldb < K || N * ldb >= (1LL << 31))) return LIBRA_ERR_SHAPE;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return LIBRA_ERR_ALIGN;
     const bool vec_ok = (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0);
     if (!vec_ok) return LIBRA_ERR_ALIGN;
@@ -277,7 +276,7 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
     if ((flags & LIBRA_GEMM_STORE_PREACT) && (!preact || (ldpre % 8) || ldpre < N || ((uintptr_t)preact & 15))) return LIBRA_ERR_ALIGN;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return LIBRA_ERR_SHAPE;
 
-    if (pick_256(M, N, K, lda, ldb))
+    if (pick_256(M, N, K))
         return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha,
                                      alpha_cols, flags, nullptr, 1, stream);
     GemmArgs p;
@@ -288,14 +287,15 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr_set = true;
-    }
     const long nblk = (long)p.tiles_m * p.tiles_n;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), GEMM_LDS,
-                       (hipStream_t)stream, p);
+    void (*kern)(const GemmArgs) = at ? (bt ? gemm_bf16_nt_kernel<true, true> : gemm_bf16_nt_kernel<true, false>)
+                                      : (bt ? gemm_bf16_nt_kernel<false, true> : gemm_bf16_nt_kernel<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[at * 2 + bt]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_set[at * 2 + bt] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(GEMM_THREADS), GEMM_LDS, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

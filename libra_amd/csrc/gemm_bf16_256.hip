@@ -18,6 +18,7 @@
 //     half-tiles stay in flight across every barrier.  A buffer is re-staged only after the reads of it
 //     were retired before a barrier every wave has passed (B: lgkmcnt(0) before phase 2's barrier).
 #include "hip_common.hpp"
+#include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
 
 namespace libra {
@@ -47,6 +48,7 @@ __device__ __forceinline__ float qgelu_grad(float x) {
 #define LIBRA_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LIBRA_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+template <bool AT, bool BT>
 __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -72,34 +74,30 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = wave * 16 + j * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int ga = m0 + h * 128 + r; ga = ga < p.M ? ga : p.M - 1;
-            int gb = n0 + h * 128 + r; gb = gb < p.N ? gb : p.N - 1;
-            srcA[h][j] = (unsigned)ga * (unsigned)p.lda + c * 8;
-            srcB[h][j] = (unsigned)gb * (unsigned)p.ldb + c * 8;
+            srcA[h][j] = stage_src<AT>(wave * 2 + j, lane, m0 + h * 128, p.M, p.lda);
+            srcB[h][j] = stage_src<BT>(wave * 2 + j, lane, n0 + h * 128, p.N, p.ldb);
         }
-    const int ldst = wave * 16 * 128;      // this wave's byte offset inside any half-tile
+    const int ldst = wave * 2048;          // this wave's byte offset inside any half-tile (2 x 1 KiB pieces)
+    const long kstepA = ktile_stride<AT>(p.lda), kstepB = ktile_stride<BT>(p.ldb);
 
     auto stageA = [&](int h, int kt) {
         char* dst = smem + (kt & 1) * KTB + h * HB + ldst;
-        const bf16_t* base = p.A + (long)kt * 64;
+        const bf16_t* base = p.A + kt * kstepA;
         glds16(base + srcA[h][0], dst);
         glds16(base + srcA[h][1], dst + 1024);
     };
     auto stageB = [&](int h, int kt) {
         char* dst = smem + (kt & 1) * KTB + (2 + h) * HB + ldst;
-        const bf16_t* base = p.B + (long)kt * 64;
+        const bf16_t* base = p.B + kt * kstepB;
         glds16(base + srcB[h][0], dst);
         glds16(base + srcB[h][1], dst + 1024);
     };
 
-    // ---- fragment read addressing: byte offset of (row = l31 (+32k), chunk = 2*ks + fk) inside a half-tile
-    int koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + ((((2 * ks + fk) ^ ((l31 >> 1) & 7))) << 4);
+    const FragAddr fa = make_frag_addr(lane);
     const int aoff = wr * HB;                                  // A half of this wave group
-    const int boff = (2 + (wc >> 1)) * HB + (wc & 1) * 64 * 128;   // B half + 64-row block of this wave
+    const int boff = (2 + (wc >> 1)) * HB;                     // B half of this wave
+    const int toA[4] = {frag_toff<AT>(lane, 0), frag_toff<AT>(lane, 1), frag_toff<AT>(lane, 2), frag_toff<AT>(lane, 3)};
+    const int toB[2] = {frag_toff<BT>(lane, (wc & 1) * 2), frag_toff<BT>(lane, (wc & 1) * 2 + 1)};
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -126,11 +124,11 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         const char* sb = buf + boff;
         // ================= phase 1: read B0, A0; prefetch A_lo(kt+1); quadrant (0,0) =================
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const bf16x8*)(sb + koff[ks]);
+        for (int ks = 0; ks < 4; ++ks) b0[ks] = load_frag<BT>(sb, fa, toB[0], ks);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[i][ks] = *(const bf16x8*)(sa + i * 4096 + koff[ks]);
+            for (int ks = 0; ks < 4; ++ks) a[i][ks] = load_frag<AT>(sa, fa, toA[i], ks);
         if (kt + 1 < nk) stageA(0, kt + 1);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         __builtin_amdgcn_s_barrier();
         // ================= phase 2: read B1; prefetch A_hi(kt+1); quadrant (0,1) =================
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) b1[ks] = *(const bf16x8*)(sb + 4096 + koff[ks]);
+        for (int ks = 0; ks < 4; ++ks) b1[ks] = load_frag<BT>(sb, fa, toB[1], ks);
         if (kt + 1 < nk) stageA(1, kt + 1);
         LIBRA_LGKMCNT0();            // all B reads of this K tile retired before the barrier: B may be re-staged next phase
         __builtin_amdgcn_s_barrier();
@@ -163,7 +161,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[i][ks] = *(const bf16x8*)(sa + (2 + i) * 4096 + koff[ks]);
+            for (int ks = 0; ks < 4; ++ks) a[i][ks] = load_frag<AT>(sa, fa, toA[2 + i], ks);
         if (kt + 2 < nk) stageB(0, kt + 2);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -303,14 +301,17 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (int)((N + 255) / 256);
     p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
     p.slab = slab; p.splitk = splitk < 1 ? 1 : splitk;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-        attr_set = true;
+    const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
+    void (*kern)(const Gemm256Args) =
+        at ? (bt ? gemm_bf16_nt_256_kernel<true, true> : gemm_bf16_nt_256_kernel<true, false>)
+           : (bt ? gemm_bf16_nt_256_kernel<false, true> : gemm_bf16_nt_256_kernel<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[at * 2 + bt]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+        attr_set[at * 2 + bt] = true;
     }
     const long nblk = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3((unsigned)nblk, (unsigned)p.splitk), dim3(G256_THREADS), G256_LDS,
-                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)p.splitk), dim3(G256_THREADS), G256_LDS, (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     if (slab) {
         const long MN = (long)M * N;

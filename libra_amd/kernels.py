@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-GEMM_BIAS, GEMM_QUICK_GELU, GEMM_RESIDUAL, GEMM_MUL_QGELU_GRAD, GEMM_STORE_PREACT = 1, 2, 4, 8, 16
+GEMM_BIAS, GEMM_QUICK_GELU, GEMM_RESIDUAL, GEMM_MUL_QGELU_GRAD, GEMM_STORE_PREACT, GEMM_A_T, GEMM_B_T = 1, 2, 4, 8, 16, 32, 64
 BF16 = torch.bfloat16
 
 
@@ -35,17 +35,31 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def alloc_rows(rows: int, cols: int, device) -> torch.Tensor:
+    """[round_up(rows,64), cols] bf16 with the pad rows zeroed: activations / gradients that later serve as
+    reduction-major (token-major) GEMM operands for wgrad need a reduction length that is a multiple of 64.
+    Use ``buf[:rows]`` as the kernel output."""
+    rp = round_up(rows, 64)
+    buf = torch.empty((rp, cols), dtype=BF16, device=device)
+    if rp != rows:
+        buf[rows:].zero_()
+    return buf
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, quick_gelu: bool = False,
             qgelu_grad_of: Optional[torch.Tensor] = None, preact_out: Optional[torch.Tensor] = None,
-            alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None) -> torch.Tensor:
-    """out[M,N] = epi(a[M,K] @ b[N,K]^T).  `k` limits the contraction to the first k columns."""
+            alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None, a_t: bool = False,
+            b_t: bool = False) -> torch.Tensor:
+    """out[M,N] = epi(A @ B^T) with A = a [M,K] (or a^T when a_t: a is [K,M], reduction-major) and
+    B = b [N,K] (or b^T when b_t: b is [K,N]).  `k` limits the contraction to the first k reduction steps.
+    The reduction length must be a multiple of 64 (reduction-major operands: allocate with alloc_rows)."""
     _chk2d(a, "a"); _chk2d(b, "b")
-    M, Ka = a.shape
-    N, Kb = b.shape
+    (Ka, M) = a.shape if a_t else a.shape[::-1]
+    (Kb, N) = b.shape if b_t else b.shape[::-1]
     K = k if k is not None else Ka
     if K > Ka or K > Kb or (k is None and Ka != Kb):
-        raise ValueError(f"gemm_nt: inner dims differ: a {tuple(a.shape)} b {tuple(b.shape)} k={k}")
+        raise ValueError(f"gemm_nt: inner dims differ: a {tuple(a.shape)} b {tuple(b.shape)} k={k} a_t={a_t} b_t={b_t}")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
     _chk2d(out, "out")
@@ -59,10 +73,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
             nbytes = _lib.lib().libra_gemm_splitk_workspace_bytes(M, N, splits)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
             rc = _lib.lib().libra_gemm_bf16_nt_splitk(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                                      out.stride(0), M, N, K, splits, ws.data_ptr(), nbytes, _stream())
+                                                      out.stride(0), M, N, K, splits,
+                                                      (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0), ws.data_ptr(),
+                                                      nbytes, _stream())
             _lib.check(rc, f"gemm_nt_splitk M={M} N={N} K={K} S={splits}")
             return out
-    flags = 0
+    flags = (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0)
     if bias is not None:
         if bias.numel() != N or bias.dtype != BF16:
             raise ValueError("gemm_nt: bias must be bf16 [N]")
@@ -324,8 +340,9 @@ def _profiled(kind, work_fn):
 
 
 def _gemm_flops(a, b, **kw):
-    k = kw.get("k") or a.shape[1]
-    return 2.0 * a.shape[0] * b.shape[0] * k
+    a_t, b_t = kw.get("a_t", False), kw.get("b_t", False)
+    k = kw.get("k") or (a.shape[0] if a_t else a.shape[1])
+    return 2.0 * (a.shape[1] if a_t else a.shape[0]) * (b.shape[1] if b_t else b.shape[0]) * k
 
 
 gemm_nt = _profiled("gemm", _gemm_flops)(gemm_nt)

@@ -45,6 +45,20 @@ def test_gemm_plain(K, M, N, K_):
     close(out, a.float() @ b.float().t(), what=f"gemm {M}x{N}x{K_}")
 
 
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 264, 192), (1024, 1024, 18496), (3072, 1024, 2048),
+                                    (18464, 1024, 1024), (577, 4096, 1024), (256, 512, 4096)])
+@pytest.mark.parametrize("a_t,b_t", [(False, True), (True, False), (True, True)])
+def test_gemm_transposed_operands(K, M, N, K_, a_t, b_t):
+    """Reduction-major operands read with the LDS transpose loads: no transposed copy is materialised."""
+    if a_t and M % 8:
+        M = M // 8 * 8
+    a, b = rnd(M, K_, seed=11), rnd(N, K_, seed=12)
+    aa = a.t().contiguous() if a_t else a
+    bb = b.t().contiguous() if b_t else b
+    out = K.gemm_nt(aa, bb, a_t=a_t, b_t=b_t)
+    close(out, a.float() @ b.float().t(), what=f"gemm {M}x{N}x{K_} a_t={a_t} b_t={b_t}")
+
+
 def test_gemm_identity_layout(K):
     # A = I (padded), B asymmetric: catches a row/col swap in the C fragment mapping
     n = 128
