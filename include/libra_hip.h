@@ -96,6 +96,11 @@ int libra_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_ou
                          int64_t cols, int64_t rows_pad, float* colsum_f32, int64_t batch,
                          int64_t in_bstride, int64_t out_bstride, void* stream);
 
+/* ---- column sums (bias gradient db[n] = sum_m dY[m,n]); out fp32 [cols] is ADDED to; deterministic two-stage */
+size_t libra_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int libra_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- ViT self-attention, flash style (CLIPAttention.forward, modeling_clip.py:287-363) -------------
  * qkv [B*T, 3*H*64] bf16 (q | k | v, head h at columns h*64 of each third; q UNscaled), vt = V^T
  * [H*64, vt_ld] bf16 with token (b,t) at column b*T_pad + t (T_pad % 8 == 0, keys t >= T ignored).

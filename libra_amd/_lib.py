@@ -23,6 +23,8 @@ SIGNATURES = {
     "libra_gemm_splitk_plan": [_I64, _I64, _I64],
     "libra_gemm_splitk_workspace_bytes": [_I64, _I64, _I64],
     "libra_gemm_bf16_nt_splitk": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, C.c_size_t, _P],
+    "libra_colsum_workspace_bytes": [_I64, _I64],
+    "libra_colsum_bf16": [_P, _I64, _I64, _I64, _P, _P, C.c_size_t, _P],
     "libra_layernorm_bwd_workspace_bytes": [_I64, _I64],
     "libra_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
     "libra_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],

@@ -159,6 +159,18 @@ def transpose(x: torch.Tensor, rows_pad: Optional[int] = None, *, colsum: Option
     return out
 
 
+def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out (fp32 [cols]) += column sums of x (bf16 [rows, cols])."""
+    _chk2d(x, "x")
+    rows, cols = x.shape
+    nbytes = _lib.lib().libra_colsum_workspace_bytes(rows, cols)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().libra_colsum_bf16(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), ws.data_ptr(), nbytes,
+                                      _stream())
+    _lib.check(rc, "colsum")
+    return out
+
+
 def transpose_tokens(x: torch.Tensor, B: int, T: int, T_pad: int, *, out: Optional[torch.Tensor] = None):
     """x [B*T, C] (a column slice is fine) -> out [C, B*T_pad] with token (b,t) at column b*T_pad+t, zero padded."""
     _chk2d(x, "x")
@@ -177,7 +189,8 @@ def patch_im2col(pixel: torch.Tensor, P: int, Kpad: int) -> torch.Tensor:
     if pixel.dim() != 4 or pixel.dtype != BF16 or not pixel.is_contiguous():
         raise ValueError("patch_im2col: pixel must be contiguous bf16 [B,C,H,W]")
     B, Cc, H, W = pixel.shape
-    cols = torch.empty((B * (H // P) * (W // P), Kpad), dtype=BF16, device=pixel.device)
+    n = B * (H // P) * (W // P)
+    cols = alloc_rows(n, Kpad, pixel.device)[:n]
     rc = _lib.lib().libra_patch_im2col(pixel.data_ptr(), cols.data_ptr(), B, Cc, H, W, P, Kpad, _stream())
     _lib.check(rc, "patch_im2col")
     return cols
@@ -207,9 +220,10 @@ def vit_embed_ln(patches, cls, pos, gamma, beta, B: int, T: int, eps: float, *, 
 
 
 def vit_attn_fwd(qkv: torch.Tensor, vt: torch.Tensor, B: int, T: int, H: int, T_pad: int, scale: float, *,
-                 need_lse: bool = True):
+                 need_lse: bool = True, out: Optional[torch.Tensor] = None):
     _chk2d(qkv, "qkv"); _chk2d(vt, "vt")
-    out = torch.empty((B * T, H * 64), dtype=BF16, device=qkv.device)
+    if out is None:
+        out = torch.empty((B * T, H * 64), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device) if need_lse else None
     rc = _lib.lib().libra_vit_attn_fwd(qkv.data_ptr(), qkv.stride(0), vt.data_ptr(), vt.stride(0), T_pad,
                                        out.data_ptr(), out.stride(0), _ptr(lse), B, T, H, float(scale), _stream())
@@ -217,7 +231,8 @@ def vit_attn_fwd(qkv: torch.Tensor, vt: torch.Tensor, B: int, T: int, H: int, T_
     return out, lse
 
 
-def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, T_pad: int, scale: float) -> torch.Tensor:
+def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, T_pad: int, scale: float, *,
+                 out_dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk2d(qkv, "qkv"); _chk2d(out, "out"); _chk2d(dout, "dout")
     dev = qkv.device
     HD = H * 64
@@ -229,7 +244,7 @@ def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, T_pad: int, scale:
         raise ValueError("vit_attn_bwd: out/dout leading dims differ")
     qkt = transpose_tokens(qkv[:, : 2 * HD], B, T, T_pad)
     dot = transpose_tokens(dout, B, T, T_pad)
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty_like(qkv) if out_dqkv is None else out_dqkv
     rc = _lib.lib().libra_vit_attn_bwd(qkv.data_ptr(), qkv.stride(0), qkt.data_ptr(), dot.data_ptr(), qkt.stride(0),
                                        T_pad, dout.data_ptr(), dout.stride(0), lse.data_ptr(), delta.data_ptr(),
                                        dqkv.data_ptr(), dqkv.stride(0), B, T, H, float(scale), _stream())

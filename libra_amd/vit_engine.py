@@ -83,17 +83,9 @@ def pack_forward(params: Dict[str, torch.Tensor], dims: VitDims):
 
 
 def pack_backward(params, dims: VitDims, fwd):
-    out = {"layers": []}
-    out["wpe_t"] = K.transpose(fwd["wpe"])                                   # [kpe, D]
-    for i in range(dims.layers):
-        pre = f"{P}encoder.layers.{i}."
-        out["layers"].append({
-            "wqkv_t": K.transpose(fwd["layers"][i]["wqkv"]),                  # [D, 3D]
-            "wo_t": K.transpose(params[pre + "self_attn.out_proj.weight"].detach()),
-            "w1_t": K.transpose(params[pre + "mlp.fc1.weight"].detach()),     # [D, I]
-            "w2_t": K.transpose(params[pre + "mlp.fc2.weight"].detach()),     # [I, D]
-        })
-    return out
+    """Nothing to build: dgrad reads the weights themselves as reduction-major B operands (LIBRA_GEMM_B_T) and
+    wgrad reads dY / X token-major (LIBRA_GEMM_A_T | _B_T) through the LDS transpose loads."""
+    return {}
 
 
 def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: VitDims, *, save: bool,
@@ -119,18 +111,20 @@ def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: 
     for i in range(L):
         pre = f"{P}encoder.layers.{i}."
         pk = packed["layers"][i]
+        M = B * T
+        rows = (lambda c: K.alloc_rows(M, c, x.device)[:M]) if save else (lambda c: None)
         xn1, m1, r1 = K.layernorm_fwd(x, params[pre + "layer_norm1.weight"], params[pre + "layer_norm1.bias"], dims.eps,
-                                      save_stats=save)
+                                      save_stats=save, out=rows(D))
         qkv = K.gemm_nt(xn1, pk["wqkv"], bias=pk["bqkv"])
         vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, dims.t_pad)
-        o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, dims.t_pad, scale, need_lse=save)
+        o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, dims.t_pad, scale, need_lse=save, out=rows(D))
         x_mid = K.gemm_nt(o, params[pre + "self_attn.out_proj.weight"], bias=params[pre + "self_attn.out_proj.bias"],
                           resid=x)
         xn2, m2, r2 = K.layernorm_fwd(x_mid, params[pre + "layer_norm2.weight"], params[pre + "layer_norm2.bias"],
-                                      dims.eps, save_stats=save)
+                                      dims.eps, save_stats=save, out=rows(D))
         hpre = torch.empty((B * T, dims.inter), dtype=BF16, device=x.device) if save else None
         act = K.gemm_nt(xn2, params[pre + "mlp.fc1.weight"], bias=params[pre + "mlp.fc1.bias"], quick_gelu=True,
-                        preact_out=hpre)
+                        preact_out=hpre, out=rows(dims.inter))
         x_out = K.gemm_nt(act, params[pre + "mlp.fc2.weight"], bias=params[pre + "mlp.fc2.bias"], resid=x_mid)
         if save:
             saved["layers"].append(dict(x=x, xn1=xn1, m1=m1, r1=r1, qkv=qkv, o=o, lse=lse, x_mid=x_mid, xn2=xn2,
@@ -140,10 +134,14 @@ def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: 
     return hs, saved
 
 
-def _wgrad(dy_t: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
-    """dW[N_out, K_in] = dY^T[N_out, M] . X[M, K_in]  as an NT GEMM over the token-contiguous copies."""
-    x_t = K.transpose(x, m_pad)
-    return K.gemm_nt(dy_t, x_t)
+def _full(t: torch.Tensor, m_pad: int) -> torch.Tensor:
+    """The zero-padded [m_pad, C] allocation behind a [M, C] row view made by K.alloc_rows."""
+    return torch.as_strided(t, (m_pad, t.shape[1]), t.stride(), t.storage_offset())
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
+    """dW[N_out, K_in] = sum_m dY[m, N_out] X[m, K_in]: both operands are read token-major as they lie in HBM."""
+    return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True)
 
 
 def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
@@ -163,46 +161,39 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
     top = max((i for i, g in enumerate(dhs) if g is not None), default=-1)
     if top < 0:
         return None, grads
-    dx = dhs[top].reshape(M, D).to(BF16).contiguous().clone()
+    dev_rows = lambda c: K.alloc_rows(M, c, dev)[:M]
+    dx = dev_rows(D)
+    dx.copy_(dhs[top].reshape(M, D))
     f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
     for i in range(min(top, L) - 1, -1, -1):
         pre = f"{P}encoder.layers.{i}."
         s = saved["layers"][i]
-        pb = packed_bwd["layers"][i]
         # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
-        db2 = f32(D)
-        dxo_t = K.transpose(dx, m_pad, colsum=db2)                               # [D, Mp]
-        grads[pre + "mlp.fc2.weight"] = _wgrad(dxo_t, s["act"], m_pad)
-        grads[pre + "mlp.fc2.bias"] = K.f32_to_bf16(db2)
-        dh = K.gemm_nt(dx, pb["w2_t"], qgelu_grad_of=s["hpre"])                  # [M, I] = (dx W2) * gelu'(hpre)
-        db1 = f32(I)
-        dh_t = K.transpose(dh, m_pad, colsum=db1)
-        grads[pre + "mlp.fc1.weight"] = _wgrad(dh_t, s["xn2"], m_pad)
-        grads[pre + "mlp.fc1.bias"] = K.f32_to_bf16(db1)
-        dxn2 = K.gemm_nt(dh, pb["w1_t"])                                         # [M, D]
+        grads[pre + "mlp.fc2.weight"] = _wgrad(dx, s["act"], m_pad)
+        grads[pre + "mlp.fc2.bias"] = K.f32_to_bf16(K.colsum(dx, f32(D)))
+        dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dev_rows(I))
+        grads[pre + "mlp.fc1.weight"] = _wgrad(dh, s["xn2"], m_pad)
+        grads[pre + "mlp.fc1.bias"] = K.f32_to_bf16(K.colsum(dh, f32(I)))
+        dxn2 = K.gemm_nt(dh, params[pre + "mlp.fc1.weight"], b_t=True)                       # [M, D]
         dg2, dbt2 = f32(D), f32(D)
         dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
-                                 dgamma=dg2, dbeta=dbt2)
+                                 dgamma=dg2, dbeta=dbt2, out=dev_rows(D))
         grads[pre + "layer_norm2.weight"] = K.f32_to_bf16(dg2)
         grads[pre + "layer_norm2.bias"] = K.f32_to_bf16(dbt2)
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
-        dbo = f32(D)
-        dxm_t = K.transpose(dx_mid, m_pad, colsum=dbo)
-        grads[pre + "self_attn.out_proj.weight"] = _wgrad(dxm_t, s["o"], m_pad)
-        grads[pre + "self_attn.out_proj.bias"] = K.f32_to_bf16(dbo)
-        do = K.gemm_nt(dx_mid, pb["wo_t"])                                       # [M, D]
-        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, dims.t_pad, scale)
-        dbqkv = f32(3 * D)
-        dqkv_t = K.transpose(dqkv, m_pad, colsum=dbqkv)
-        dwqkv = _wgrad(dqkv_t, s["xn1"], m_pad)                                  # [3D, D]
-        dbq = K.f32_to_bf16(dbqkv)
+        grads[pre + "self_attn.out_proj.weight"] = _wgrad(dx_mid, s["o"], m_pad)
+        grads[pre + "self_attn.out_proj.bias"] = K.f32_to_bf16(K.colsum(dx_mid, f32(D)))
+        do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
+        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, dims.t_pad, scale, out_dqkv=dev_rows(3 * D))
+        dwqkv = _wgrad(dqkv, s["xn1"], m_pad)                                                  # [3D, D]
+        dbq = K.f32_to_bf16(K.colsum(dqkv, f32(3 * D)))
         for j, n in enumerate("qkv"):
             grads[pre + f"self_attn.{n}_proj.weight"] = dwqkv[j * D:(j + 1) * D]
             grads[pre + f"self_attn.{n}_proj.bias"] = dbq[j * D:(j + 1) * D]
-        dxn1 = K.gemm_nt(dqkv, pb["wqkv_t"])
+        dxn1 = K.gemm_nt(dqkv, packed["layers"][i]["wqkv"], b_t=True)
         dg1, dbt1 = f32(D), f32(D)
         dx = K.layernorm_bwd(dxn1, s["x"], params[pre + "layer_norm1.weight"], s["m1"], s["r1"], dres=dx_mid,
-                             dgamma=dg1, dbeta=dbt1)
+                             dgamma=dg1, dbeta=dbt1, out=dev_rows(D))
         grads[pre + "layer_norm1.weight"] = K.f32_to_bf16(dg1)
         grads[pre + "layer_norm1.bias"] = K.f32_to_bf16(dbt1)
         if dhs[i] is not None:
@@ -218,15 +209,20 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
     dpos = demb3.float().sum(0)
     grads[P + "embeddings.position_embedding.weight"] = dpos.to(BF16)
     grads[P + "embeddings.class_embedding"] = demb3[:, 0].float().sum(0).to(BF16)
-    dpatch = demb3[:, 1:].reshape(B * (T - 1), D)                                # contiguous copy
-    np_pad = K.round_up(B * (T - 1), 64)
-    dp_t = K.transpose(dpatch, np_pad)
-    cols_t = K.transpose(saved["cols"], np_pad)                                   # [kpe, Np]
-    dwpe = K.gemm_nt(dp_t, cols_t)                                                # [D, kpe]
+    npatch = B * (T - 1)
+    np_pad = K.round_up(npatch, 64)
+    dpatch = K.alloc_rows(npatch, D, dev)[:npatch]
+    dpatch.view(B, T - 1, D).copy_(demb3[:, 1:])
+    cols = saved["cols"]
+    if cols.shape[0] != np_pad:                     # forward allocates it padded (see patch_im2col); be safe
+        cpad = K.alloc_rows(npatch, cols.shape[1], dev)
+        cpad[:npatch].copy_(cols)
+        cols = cpad[:npatch]
+    dwpe = K.gemm_nt(_full(dpatch, np_pad), _full(cols, np_pad), a_t=True, b_t=True)     # [D, kpe]
     kk = dims.channels * dims.patch * dims.patch
     grads[P + "embeddings.patch_embedding.weight"] = dwpe[:, :kk].reshape(D, dims.channels, dims.patch, dims.patch)
     dpixel = None
     if need_pixel_grad:
-        dcols = K.gemm_nt(dpatch, packed_bwd["wpe_t"])                            # [Np, kpe]
+        dcols = K.gemm_nt(dpatch, packed["wpe"], b_t=True)                               # [Np, kpe]
         dpixel = K.patch_col2im(dcols, B, dims.channels, dims.image, dims.image, dims.patch)
     return dpixel, grads

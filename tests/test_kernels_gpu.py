@@ -136,6 +136,17 @@ def test_transpose(K):
         assert float(out[:, b * Tp + T:(b + 1) * Tp].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows,cols", [(577, 200), (18464, 1024), (100, 4096), (3, 8)])
+def test_colsum(K, rows, cols):
+    x = rnd(rows, cols, seed=rows)
+    out = torch.ones(cols, device="cuda")
+    K.colsum(x, out)
+    close(out, 1.0 + x.float().sum(0), rel=1e-5, what="colsum")
+    out2 = torch.ones(cols, device="cuda")
+    K.colsum(x, out2)
+    assert torch.equal(out, out2)          # deterministic (no atomics)
+
+
 def test_patch_im2col_col2im(K):
     B, C, H, P = 2, 3, 56, 14
     pix = rnd(B, C, H, H, seed=11)
