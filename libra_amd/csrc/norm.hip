@@ -148,24 +148,24 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_bwd_kernel(
     }
 }
 
-// out_gamma[d] += sum_p part[p][0][d];  out_beta[d] += sum_p part[p][1][d].  64 columns x 16 row groups per block.
+// out_gamma[d] += sum_p part[p][0][d];  out_beta[d] += sum_p part[p][1][d].  32 columns x 32 row groups per block.
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int D,
                                                                float* __restrict__ out_gamma,
                                                                float* __restrict__ out_beta) {
-    __shared__ float red[16][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int which = blockIdx.y;
-    const int col = blockIdx.x * 64 + c;
+    const int col = blockIdx.x * 32 + c;
     float s = 0.f;
     if (col < D) {
-        for (int p = rg; p < nparts; p += 16) s += part[((long)p * 2 + which) * D + col];
+        for (int p = rg; p < nparts; p += 32) s += part[((long)p * 2 + which) * D + col];
     }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && col < D) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][c];
+        for (int i = 0; i < 32; ++i) t += red[i][c];
         float* o = which ? out_beta : out_gamma;
         o[col] += t;
     }
@@ -248,7 +248,7 @@ extern "C" int libra_layernorm_fwd(const void* x, const void* gamma, const void*
 
 static long ln_bwd_rows_per_block(long rows) {
     // ~2 workgroups per CU worth of row strips
-    long rpb = (rows + 511) / 512;
+    long rpb = (rows + 255) / 256;
     return ((rpb + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * ROWS_PER_BLOCK;
 }
 
@@ -282,7 +282,7 @@ extern "C" int libra_layernorm_bwd(const void* dy, const void* x, const void* ga
         return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
     });
     if (rc != LIBRA_OK || !dgamma) return rc;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((D + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((D + 31) / 32), 2), dim3(1024), 0, (hipStream_t)stream,
                        part, (int)(grid * ROWS_PER_BLOCK), (int)D, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -34,13 +34,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
     for (int e = 0; e < 8; ++e) if (c8 + e < cols) dst[e] = s[e];
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int strips, int cols,
-                                                           float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+// 32 columns x 32 strip groups per block: every thread adds strips/32 partials, then one LDS reduction
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int strips, int cols,
+                                                            float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int p = 0; p < strips; ++p) s += part[(long)p * cols + c];
-    out[c] += s;
+    if (col < cols)
+        for (int p = g; p < strips; p += 32) s += part[(long)p * cols + col];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && col < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][c];
+        out[col] += t;
+    }
 }
 
 }  // namespace libra
@@ -62,7 +72,7 @@ extern "C" int libra_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_
     hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld,
                        (long)rows, (int)cols, (float*)workspace);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(1024), 0, (hipStream_t)stream,
                        (const float*)workspace, strips, (int)cols, out);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -164,46 +164,56 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
     dev_rows = lambda c: K.alloc_rows(M, c, dev)[:M]
     dx = dev_rows(D)
     dx.copy_(dhs[top].reshape(M, D))
-    f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    # one zeroed fp32 arena for every small (bias / LayerNorm) gradient of this backward; converted to bf16 once
+    n_small = (min(top, L)) * (9 * D + I) + 2 * D
+    arena = torch.zeros(n_small, dtype=torch.float32, device=dev)
+    small: List = []          # (param name, offset, numel)
+    cursor = [0]
+
+    def f32(n, name=None):
+        o = cursor[0]
+        cursor[0] += n
+        if name is not None:
+            small.append((name, o, n))
+        return arena[o:o + n]
     for i in range(min(top, L) - 1, -1, -1):
         pre = f"{P}encoder.layers.{i}."
         s = saved["layers"][i]
         # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
         grads[pre + "mlp.fc2.weight"] = _wgrad(dx, s["act"], m_pad)
-        grads[pre + "mlp.fc2.bias"] = K.f32_to_bf16(K.colsum(dx, f32(D)))
+        K.colsum(dx, f32(D, pre + "mlp.fc2.bias"))
         dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dev_rows(I))
         grads[pre + "mlp.fc1.weight"] = _wgrad(dh, s["xn2"], m_pad)
-        grads[pre + "mlp.fc1.bias"] = K.f32_to_bf16(K.colsum(dh, f32(I)))
+        K.colsum(dh, f32(I, pre + "mlp.fc1.bias"))
         dxn2 = K.gemm_nt(dh, params[pre + "mlp.fc1.weight"], b_t=True)                       # [M, D]
-        dg2, dbt2 = f32(D), f32(D)
+        dg2, dbt2 = f32(D, pre + "layer_norm2.weight"), f32(D, pre + "layer_norm2.bias")
         dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
                                  dgamma=dg2, dbeta=dbt2, out=dev_rows(D))
-        grads[pre + "layer_norm2.weight"] = K.f32_to_bf16(dg2)
-        grads[pre + "layer_norm2.bias"] = K.f32_to_bf16(dbt2)
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
         grads[pre + "self_attn.out_proj.weight"] = _wgrad(dx_mid, s["o"], m_pad)
-        grads[pre + "self_attn.out_proj.bias"] = K.f32_to_bf16(K.colsum(dx_mid, f32(D)))
+        K.colsum(dx_mid, f32(D, pre + "self_attn.out_proj.bias"))
         do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
         dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, dims.t_pad, scale, out_dqkv=dev_rows(3 * D))
         dwqkv = _wgrad(dqkv, s["xn1"], m_pad)                                                  # [3D, D]
-        dbq = K.f32_to_bf16(K.colsum(dqkv, f32(3 * D)))
+        dbq = f32(3 * D)
+        K.colsum(dqkv, dbq)
+        o0 = cursor[0] - 3 * D
         for j, n in enumerate("qkv"):
             grads[pre + f"self_attn.{n}_proj.weight"] = dwqkv[j * D:(j + 1) * D]
-            grads[pre + f"self_attn.{n}_proj.bias"] = dbq[j * D:(j + 1) * D]
+            small.append((pre + f"self_attn.{n}_proj.bias", o0 + j * D, D))
         dxn1 = K.gemm_nt(dqkv, packed["layers"][i]["wqkv"], b_t=True)
-        dg1, dbt1 = f32(D), f32(D)
+        dg1, dbt1 = f32(D, pre + "layer_norm1.weight"), f32(D, pre + "layer_norm1.bias")
         dx = K.layernorm_bwd(dxn1, s["x"], params[pre + "layer_norm1.weight"], s["m1"], s["r1"], dres=dx_mid,
                              dgamma=dg1, dbeta=dbt1, out=dev_rows(D))
-        grads[pre + "layer_norm1.weight"] = K.f32_to_bf16(dg1)
-        grads[pre + "layer_norm1.bias"] = K.f32_to_bf16(dbt1)
         if dhs[i] is not None:
             K.add_(dx, dhs[i].reshape(M, D).to(BF16).contiguous())
     # ---- embeddings: hs0 = LN(emb); emb = [cls ; patches] + pos
-    dg0, db0 = f32(D), f32(D)
+    dg0, db0 = f32(D, P + "pre_layrnorm.weight"), f32(D, P + "pre_layrnorm.bias")
     demb = K.layernorm_bwd(dx, saved["emb"], params[P + "pre_layrnorm.weight"], saved["mean0"], saved["rstd0"],
                            dgamma=dg0, dbeta=db0)
-    grads[P + "pre_layrnorm.weight"] = K.f32_to_bf16(dg0)
-    grads[P + "pre_layrnorm.bias"] = K.f32_to_bf16(db0)
+    small_bf16 = K.f32_to_bf16(arena)
+    for name, o, n in small:
+        grads[name] = small_bf16[o:o + n]
     demb3 = demb.view(B, T, D)
     # tiny batch reductions (B x 577 x 1024 -> 577 x 1024): plumbing, not the hot path
     dpos = demb3.float().sum(0)
