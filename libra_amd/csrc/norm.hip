@@ -248,7 +248,7 @@ extern "C" int libra_layernorm_fwd(const void* x, const void* gamma, const void*
 
 static long ln_bwd_rows_per_block(long rows) {
     // ~2 workgroups per CU worth of row strips
-    long rpb = (rows + 255) / 256;
+    long rpb = (rows + 511) / 512;
     return ((rpb + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * ROWS_PER_BLOCK;
 }
 
