@@ -1,0 +1,247 @@
+"""CPU oracle for the routed ("bridge") LLaMA decoder half of the Libra hot path.
+
+TEST INFRASTRUCTURE ONLY (see vit_oracle.py header for the import rule).
+
+Clean-room functional restatement (plain torch, dtype-agnostic) in *closed form* — the reference routes
+by boolean-mask gather/scatter and duplicates the attention matmuls; here every routed op is written as
+a per-token select, and attention as
+
+    S_ij = q_i . (k_j + [m_i != m_j] kb_j) / sqrt(d)  + mask_ij ,   O_i = sum_j P_ij (v_j + [m_i != m_j] vb_j)
+
+which is algebraically what the reference computes:
+
+  * cal_language_vision            /root/reference/libra/models/libra/modeling_libra.py:111-147
+  * LibraLinear.forward            :192-199   (x A^T B^T; rank-8 bridges have rank != None)
+  * LlamaRMSNorm.forward           /root/reference/libra/models/llama/modeling_llama.py:127-132
+  * rotate_half / apply_rotary_pos_emb   modeling_libra.py:32-61 ; LlamaRotaryEmbedding  modeling_llama.py:135-164
+  * LibraAttention.forward + attn_with_bridge     modeling_libra.py:267-414
+  * LibraMLP.forward               :227-238
+  * LibraDecoderLayer.forward      :437-491
+  * LibraModel.get_inputs_embeds_from_multicodebook :625-661, forward :680-831,
+    _prepare_decoder_attention_mask :602-623, _make_causal_mask/_expand_mask modeling_llama.py:44-73
+  * LibraForCausalLM.cal_vl_logits :1018-1052, loss :1160-1174
+  * LibraTrainWrapper.get_labels   :1397-1411
+  * LibraTokenizer.forward tensor assembly  /root/reference/libra/models/libra/tokenization_libra.py:250-316
+
+Pinned by tests/test_oracle_libra_golden.py against fixtures generated from the reference's own
+LibraForCausalLM (tests/golden/make_golden_libra.py).  State-dict keys are the reference's.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """modeling_llama.py:127-132: variance in fp32, product promoted to fp32, `weight * x.to(input_dtype)`."""
+    dt = x.dtype
+    xf = x.to(torch.float32) if dt != torch.float64 else x
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return w * xf.to(dt)
+
+
+def routed(x: torch.Tensor, flag: torch.Tensor, f_lang, f_vis) -> torch.Tensor:
+    """cal_language_vision (addition_mode off): language fn on ~flag rows, vision fn on flag rows."""
+    yl, yv = f_lang(x), f_vis(x)
+    return torch.where(flag.unsqueeze(-1), yv, yl)
+
+
+def libra_linear(x, sd, pre):
+    return F.linear(F.linear(x, sd[pre + "weight_A"]), sd[pre + "weight_B"])
+
+
+def rope_tables(dim: int, n_pos: int, base: float = 10000.0, dtype=torch.float32):
+    inv = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+    t = torch.arange(n_pos, dtype=inv.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)       # cached in fp32, cast to x.dtype (modeling_llama.py:161-164)
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def apply_rope(x, cos, sin, position_ids):
+    c = cos[position_ids].unsqueeze(1)      # [B,1,S,d]
+    s = sin[position_ids].unsqueeze(1)
+    return x * c + rotate_half(x) * s
+
+
+def additive_mask(attention_mask: torch.Tensor, S: int, dtype) -> torch.Tensor:
+    """[B,1,S,S]: causal (finfo.min above the diagonal) + padding (finfo.min on masked KEYS), summed as the
+    reference does (modeling_libra.py:602-623)."""
+    mn = torch.finfo(dtype).min
+    causal = torch.full((S, S), mn, dtype=dtype)
+    causal = torch.triu(causal, diagonal=1)
+    B = attention_mask.shape[0]
+    exp = attention_mask[:, None, None, :].expand(B, 1, S, S).to(dtype)
+    inv = 1.0 - exp
+    pad = inv.masked_fill(inv.to(torch.bool), mn)
+    return pad + causal[None, None]
+
+
+def attention(sd, pre, x, flag, mask, position_ids, heads: int, cos, sin) -> torch.Tensor:
+    B, S, Hd = x.shape
+    d = Hd // heads
+    q = routed(x, flag, lambda t: F.linear(t, sd[pre + "q_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_q_proj."))
+    k = routed(x, flag, lambda t: F.linear(t, sd[pre + "k_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_k_proj."))
+    v = routed(x, flag, lambda t: F.linear(t, sd[pre + "v_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_v_proj."))
+    kb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_language."),
+                lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_vision."))
+    vb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_v_bridge_on_language."),
+                lambda t: libra_linear(t, sd, pre + "vision_v_bridge_on_vision."))
+    # the reference adds the bridge to K *before* RoPE and rotates both variants (:320-340); RoPE is linear, so
+    # rope(k + kb) = rope(k) + rope(kb) up to rounding — keep the reference's order of operations.
+    k_cross = k + kb
+
+    def heads_(t):
+        return t.view(B, S, heads, d).transpose(1, 2)
+    q, k, k_cross, v, vb = map(heads_, (q, k, k_cross, v, vb))
+    q = apply_rope(q, cos, sin, position_ids)
+    k = apply_rope(k, cos, sin, position_ids)
+    k_cross = apply_rope(k_cross, cos, sin, position_ids)
+    cross = (flag[:, :, None] != flag[:, None, :]).unsqueeze(1)            # [B,1,S,S]: m_i != m_j
+    s_same = q @ k.transpose(-1, -2) / (d ** 0.5)
+    s_cross = q @ k_cross.transpose(-1, -2) / (d ** 0.5)
+    s = torch.where(cross, s_cross, s_same) + mask
+    s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min, dtype=s.dtype))     # :385-388
+    p = torch.softmax(s, dim=-1, dtype=torch.float32 if s.dtype != torch.float64 else torch.float64).to(q.dtype)
+    o = p @ v + (p * cross.to(p.dtype)) @ vb                                    # attn_with_bridge :267-296
+    o = o.transpose(1, 2).reshape(B, S, Hd)
+    return routed(o, flag, lambda t: F.linear(t, sd[pre + "o_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_o_proj."))
+
+
+def mlp(sd, pre, x, flag):
+    def lang(t):
+        return F.linear(F.silu(F.linear(t, sd[pre + "gate_proj.weight"])) * F.linear(t, sd[pre + "up_proj.weight"]),
+                        sd[pre + "down_proj.weight"])
+
+    def vis(t):
+        return libra_linear(F.silu(libra_linear(t, sd, pre + "vision_gate_proj.")) * libra_linear(t, sd, pre + "vision_up_proj."),
+                            sd, pre + "vision_down_proj.")
+    return routed(x, flag, lang, vis)
+
+
+def decoder_layer(sd, i, x, flag, mask, position_ids, heads, eps, cos, sin):
+    pre = f"model.layers.{i}."
+    h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "input_layernorm.weight"], eps),
+               lambda t: rms_norm(t, sd[pre + "vision_input_layernorm.weight"], eps))
+    x = x + attention(sd, pre + "self_attn.", h, flag, mask, position_ids, heads, cos, sin)
+    h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "post_attention_layernorm.weight"], eps),
+               lambda t: rms_norm(t, sd[pre + "vision_post_attention_layernorm.weight"], eps))
+    return x + mlp(sd, pre + "mlp.", h, flag)
+
+
+def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Optional[torch.Tensor], vocab: int, eps: float):
+    """get_inputs_embeds_from_multicodebook (concat_signals & norm_signals on, no vision position embedding)."""
+    Q = input_ids.shape[0]
+    lang_ids = torch.where(flag, torch.zeros_like(input_ids[0]), input_ids[0])
+    lang = F.embedding(lang_ids, sd["model.embed_tokens.weight"])
+    vis = []
+    for q in range(Q):
+        vid = torch.where(flag, input_ids[q] - vocab, torch.zeros_like(input_ids[q]))
+        vis.append(F.embedding(vid, sd[f"model.vision_embed_tokens.{q}.weight"]))
+    vis = torch.cat(vis, dim=-1)
+    if signal is None:
+        signal = vis.new_zeros(vis.shape[:-1] + (sd["model.vision_signal_norm.weight"].shape[0] - vis.shape[-1],))
+    ve = rms_norm(torch.cat([vis, signal.to(vis.dtype)], dim=-1), sd["model.vision_signal_norm.weight"], eps)
+    ve = F.linear(ve, sd["model.vision_contiguous_signal_processor.weight"])
+    return torch.where(flag.unsqueeze(-1), ve, lang)
+
+
+def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, layers: int, heads: int, vocab: int,
+                  max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048):
+    """LibraForCausalLM up to the final routed norm: -> hidden [B,S,H], vision_flag."""
+    flag = vision_indices < max_vision_token_length                      # :1118
+    assert torch.equal(flag, input_ids[0] >= vocab)                        # :707-710
+    B, S = input_ids.shape[1:]
+    x = input_embeds(sd, input_ids, flag, signal, vocab, eps)
+    d = x.shape[-1] // heads
+    cos, sin = rope_tables(d, max(max_pos, S), dtype=x.dtype)
+    pos = torch.arange(S).unsqueeze(0).expand(B, S)
+    mask = additive_mask(attention_mask, S, x.dtype)
+    for i in range(layers):
+        x = decoder_layer(sd, i, x, flag, mask, pos, heads, eps, cos, sin)
+    x = routed(x, flag, lambda t: rms_norm(t, sd["model.norm.weight"], eps),
+               lambda t: rms_norm(t, sd["model.vision_norm.weight"], eps))
+    return x, flag
+
+
+def vl_logits(sd, hidden, flag, Q: int):
+    """cal_vl_logits (unified_head off, 1d): [Q,B,S,V+Vv]; text rows: [lm_head | -inf], vision rows: [-inf | head_q]."""
+    lang = F.linear(hidden, sd["lm_head.weight"])
+    V = lang.shape[-1]
+    outs = []
+    for q in range(Q):
+        vis = F.linear(hidden, sd[f"vision_lm_head.heads.{q}.weight"])
+        Vv = vis.shape[-1]
+        neg_v = torch.full(vis.shape, float("-inf"), dtype=lang.dtype)
+        neg_l = torch.full(lang.shape, float("-inf"), dtype=lang.dtype)
+        row_l = torch.cat([lang, neg_v], -1)
+        row_v = torch.cat([neg_l, vis], -1)
+        outs.append(torch.where(flag.unsqueeze(-1), row_v, row_l))
+    return torch.stack(outs)
+
+
+def causal_lm_loss(logits_q: torch.Tensor, labels_q: torch.Tensor) -> torch.Tensor:
+    """mean over codebooks of shift-by-one CE with ignore_index -100 (:1160-1174)."""
+    Q = logits_q.shape[0]
+    loss = 0.0
+    for q in range(Q):
+        sl = logits_q[q][..., :-1, :].reshape(-1, logits_q.shape[-1])
+        tl = labels_q[q][..., 1:].reshape(-1)
+        loss = loss + F.cross_entropy(sl.float() if sl.dtype not in (torch.float64,) else sl, tl)
+    return loss / Q
+
+
+def get_labels(input_ids, attention_mask, label_mask_position_map, *, boi_token_id: int, bos_token_id: int):
+    """LibraTrainWrapper.get_labels (:1397-1411)."""
+    labels = input_ids.clone()
+    labels[:, attention_mask == 0] = -100
+    labels[labels == boi_token_id] = -100
+    labels[labels == bos_token_id] = -100
+    labels = labels.permute(1, 2, 0)
+    for label, spans in zip(labels, label_mask_position_map):
+        for (start, end) in spans:
+            label[start:end] = -100
+    return labels.permute(2, 0, 1)
+
+
+def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_ids: Optional[torch.Tensor],
+                    encoder_feat: Optional[torch.Tensor], *, img_ph_token_id: int, img_gen_token_id: int,
+                    boi_token_id: int, num_codebook: int, max_vision_token_length: int,
+                    contiguous_ignore_signs: Optional[Sequence[bool]] = None, max_length: Optional[int] = None):
+    """The tensor-assembly half of LibraTokenizer.forward (tokenization_libra.py:250-316), given the text
+    tokenizer's ids (with <img_ph> placeholders already expanded to hw+2 slots per image) and the
+    ImageTokenizer outputs.  -> input_ids [Q,B,S], attention_mask, vision_indices, coninous_signal [sic]."""
+    ids = text_ids.clone()
+    ph = ids == img_ph_token_id
+    gen = ids == img_gen_token_id
+    ids[gen] = boi_token_id
+    ids = ids[None].repeat(num_codebook, 1, 1)
+    has_images = image_ids is not None
+    if has_images:
+        ids[:, ph] = image_ids.flatten(1, 2)
+    vi = torch.full(attention_mask.shape, max_vision_token_length, dtype=torch.long)
+    signal = None
+    if has_images:
+        n_img, L = image_ids.shape[1], image_ids.shape[2]
+        vi[ph] = torch.arange(L).expand(n_img, -1).flatten(0, 1)
+        z = torch.zeros(encoder_feat.shape[0], 1, encoder_feat.shape[2], dtype=encoder_feat.dtype)
+        cont = torch.cat([z, encoder_feat, z], dim=1)
+        if contiguous_ignore_signs is not None:
+            cont[torch.tensor(list(contiguous_ignore_signs), dtype=torch.bool)] = 0
+        signal = torch.zeros(ids.shape[1], ids.shape[2], cont.shape[-1], dtype=cont.dtype)
+        signal[ph] = cont.flatten(0, 1)
+    else:
+        vi[gen] = 0
+    if max_length is not None:
+        ids, attention_mask, vi = ids[:, :, :max_length], attention_mask[:, :max_length], vi[:, :max_length]
+        if signal is not None:
+            signal = signal[:, :max_length]
+    return ids.contiguous(), attention_mask.contiguous(), vi.contiguous(), signal

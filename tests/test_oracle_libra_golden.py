@@ -1,0 +1,84 @@
+"""The decoder oracle (oracle/libra_oracle.py) against fixtures produced by the reference's own
+LibraForCausalLM / LibraTrainWrapper.get_labels / LibraTokenizer.forward.  CPU only."""
+import torch
+
+from helpers import load_golden, rel_err, sub
+from oracle import libra_oracle as LO
+
+
+def _run(t, meta, sd, dtype=torch.float32):
+    c = meta["cfg"]
+    hid, flag = LO.model_forward(sd, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"],
+                                 t["in.signal"].to(dtype), layers=c["num_hidden_layers"], heads=c["num_attention_heads"],
+                                 vocab=c["vocab_size"], max_vision_token_length=c["max_vision_token_length"],
+                                 eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    logits = LO.vl_logits(sd, hid, flag, c["vision_codebook_num"])
+    return hid, flag, logits
+
+
+def test_libra_forward_matches_reference():
+    t, meta = load_golden("libra_tiny.safetensors")
+    sd = sub(t, "w.")
+    hid, flag, logits = _run(t, meta, sd)
+    assert rel_err(hid, t["out.hidden"]) < 5e-6
+    ref = t["out.logits"]
+    assert logits.shape == ref.shape
+    fin = torch.isfinite(ref)
+    assert torch.equal(fin, torch.isfinite(logits))            # the -inf padding pattern is identical
+    assert rel_err(logits[fin], ref[fin]) < 5e-6
+    loss = LO.causal_lm_loss(logits, t["in.labels"])
+    assert abs(float(loss) - float(t["out.loss"])) < 1e-5 * abs(float(t["out.loss"]))
+
+
+def test_libra_embeddings_and_first_layer():
+    t, meta = load_golden("libra_tiny.safetensors")
+    sd = sub(t, "w.")
+    c = meta["cfg"]
+    flag = t["in.vision_indices"] < c["max_vision_token_length"]
+    emb = LO.input_embeds(sd, t["in.input_ids"], flag, t["in.signal"], c["vocab_size"], c["rms_norm_eps"])
+    assert rel_err(emb, t["out.embeds"]) < 2e-6
+    S = emb.shape[1]
+    cos, sin = LO.rope_tables(c["hidden_size"] // c["num_attention_heads"], c["max_position_embeddings"])
+    pos = torch.arange(S).unsqueeze(0).expand(emb.shape[0], S)
+    mask = LO.additive_mask(t["in.attention_mask"], S, emb.dtype)
+    x1 = LO.decoder_layer(sd, 0, emb, flag, mask, pos, c["num_attention_heads"], c["rms_norm_eps"], cos, sin)
+    assert rel_err(x1, t["out.layer0"]) < 5e-6
+
+
+def test_libra_backward_matches_reference_autograd():
+    t, meta = load_golden("libra_tiny.safetensors")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sub(t, "w.").items()}
+    hid, flag, logits = _run(t, meta, sd)
+    LO.causal_lm_loss(logits, t["in.labels"]).backward()
+    n = 0
+    for k, g in sub(t, "grad.").items():
+        if k == "vision_hidden_placeholder":
+            continue
+        assert sd[k].grad is not None, k
+        gmax = float(g.float().abs().max())
+        if gmax < 1e-6:
+            assert float(sd[k].grad.abs().max()) < 1e-5, k
+        else:
+            assert rel_err(sd[k].grad, g.float()) < 2e-3, (k, rel_err(sd[k].grad, g.float()))    # fixture grads are fp16
+        n += 1
+    assert n > 60
+
+
+def test_get_labels_matches_reference():
+    t, meta = load_golden("libra_tiny.safetensors")
+    lab = LO.get_labels(t["in.input_ids"], t["in.attention_mask"], [[tuple(s) for s in sp] for sp in meta["spans"]],
+                        boi_token_id=meta["boi"], bos_token_id=1)
+    assert torch.equal(lab, t["in.labels"])
+
+
+def test_tokenizer_tensor_assembly_matches_reference():
+    t, meta = load_golden("libra_tokenizer_assembly.safetensors")
+    ids, am, vi, sig = LO.assemble_inputs(t["in.text_ids"], t["in.attention_mask"], t["in.image_ids"], t["in.encoder_feat"],
+                                          img_ph_token_id=meta["img_ph"], img_gen_token_id=meta["img_gen"],
+                                          boi_token_id=meta["boi"], num_codebook=meta["Q"],
+                                          max_vision_token_length=meta["L"], contiguous_ignore_signs=meta["ignore"],
+                                          max_length=meta["max_length"])
+    assert torch.equal(ids, t["out.input_ids"])
+    assert torch.equal(am, t["out.attention_mask"])
+    assert torch.equal(vi, t["out.vision_indices"])
+    assert torch.equal(sig, t["out.signal"])
