@@ -51,6 +51,16 @@ int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, v
                        const void* aux, int64_t ldaux, void* preact, int64_t ldpre, float alpha,
                        int64_t alpha_cols, int flags, void* stream);
 
+/* Routed variant (Libra's per-token modality routing, cal_language_vision: modeling_libra.py:111-147, without the
+ * boolean-mask gather/scatter passes): logical row m of A is physical row a_rows[m] (K-contiguous A only;
+ * a_phys_rows = number of physical rows of A), and logical output row m is written to row c_rows[m] of C (and
+ * read from that row of resid / aux, written to that row of preact).  Either map may be NULL.       */
+int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                              int64_t M, int64_t N, int64_t K, const void* bias, const void* resid, int64_t ldr,
+                              const void* aux, int64_t ldaux, void* preact, int64_t ldpre, float alpha,
+                              int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
+                              const int32_t* c_rows, void* stream);
+
 /* split-K variant for wgrad-shaped problems (small M,N, very long K; no epilogue): K slices on the 256^2
  * kernel, fp32 partial slabs in `workspace`, deterministic reduction to bf16 C.  plan() suggests the number
  * of slices for a shape (1 = use libra_gemm_bf16_nt).  N % 8 == 0; flags: LIBRA_GEMM_A_T / _B_T only.                                  */
@@ -140,6 +150,46 @@ int libra_lfq_encode(const void* h, int64_t ld_h, const void* w_in, const void* 
                      const void* b_out, int64_t* indices, int64_t* ids, void* xpre, void* quant,
                      int64_t B, int64_t hw, int64_t E, int64_t Q, int64_t offset, int64_t boi,
                      int64_t eoi, void* stream);
+
+/* ==== routed ("bridge") decoder rows (libra/models/libra/modeling_libra.py) ===========================*/
+/* Routed RMSNorm: y = w_m * bf16(x * rsqrt(mean(x^2)+eps)), w_m = flag[row] ? w_vis : w_lang
+ * (LlamaRMSNorm, models/llama/modeling_llama.py:127-132, routed at modeling_libra.py:463,:481,:817).
+ * flag NULL = unrouted (w_lang for every row: vision_signal_norm, :640).  rstd [rows] fp32 optional.     */
+int libra_rmsnorm_routed_fwd(const void* x, int64_t ldx, const void* w_lang, const void* w_vis,
+                             const uint8_t* flag, void* y, int64_t ldy, float* rstd, int64_t rows, int64_t D,
+                             float eps, void* stream);
+/* RoPE + rank-8 bridge expansion (modeling_libra.py:318-340, apply_rotary_pos_emb :39-61), head_dim 128.
+ * qkv [N, 3*H*128] (q|k|v): q and k are rotated IN PLACE (k -> K_same); tb [N, ldt>=16] holds the bridge
+ * low-rank activations (cols 0..7 key bridge, 8..15 value bridge); bk_x / bv_x are the bridges' weight_B
+ * [H*128, 8] for language / vision tokens; outputs K_cross = rope(bf16(k + kb)), V_cross = bf16(v + vb)
+ * [N, H*128].  Token n has position n % S; cos/sin are bf16 [max_pos, 128] tables.                    */
+int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                      const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                      int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S, int64_t H,
+                      void* stream);
+/* Fused routed-bridge causal flash attention, forward (LibraAttention.forward + attn_with_bridge,
+ * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right-padding via
+ * kv_len[b]), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row
+ * strides ldq/ldk/ldv; flag [B*S] (1 = vision token); out [B*S, H*128]; lse [B,H,S] fp32 optional.      */
+int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, const void* k_cross, int64_t ldk,
+                          const void* v_same, const void* v_cross, int64_t ldv, const uint8_t* flag,
+                          const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
+                          int64_t H, float scale, void* stream);
+/* y = bf16(silu(gate)) * up  (LlamaMLP, models/llama/modeling_llama.py:199-201)                          */
+int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows, int64_t I,
+                 void* stream);
+/* out[r, col0:col0+D] = table[idx[rows_sel ? rows_sel[r] : r] - sub]   (nn.Embedding lookups of
+ * get_inputs_embeds_from_multicodebook, modeling_libra.py:625-636); idx int64                          */
+int libra_gather_rows(const void* table, int64_t D, const int64_t* idx, int64_t sub, const int32_t* rows_sel,
+                      int64_t n, void* out, int64_t ldo, int64_t col0, void* stream);
+/* out[r, col0:col0+D] = in[rows_sel ? rows_sel[r] : r, :D]                                              */
+int libra_copy_rows(const void* in, int64_t ldi, int64_t D, const int32_t* rows_sel, int64_t n, void* out,
+                    int64_t ldo, int64_t col0, void* stream);
+/* per-row cross-entropy terms of CrossEntropyLoss over bf16 logits [rows, V] (modeling_libra.py:1160-1174):
+ * loss_rows[r] = logsumexp(z_r) - z_r[target[r] - target_sub], 0 when target[r] < 0 (ignore_index -100),
+ * +inf when the target lies outside this head's column range (the reference's -inf padded logit).       */
+int libra_ce_rows(const void* logits, int64_t ldz, int64_t V, const int64_t* target, int64_t target_sub,
+                  float* loss_rows, int64_t rows, void* stream);
 
 /* ---- small elementwise helpers -------------------------------------------------------------------*/
 /* out_bf16[i] = bf16(in_f32[i])  (parameter-gradient accumulators -> bf16 .grad) */

@@ -20,6 +20,8 @@ SIGNATURES = {
     "libra_hip_abi_version": [],
     "libra_gemm_bf16_nt": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
                            _F, _I64, _I, _P],
+    "libra_gemm_bf16_nt_routed": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
+                                  _F, _I64, _I, _P, _I64, _P, _P],
     "libra_gemm_splitk_plan": [_I64, _I64, _I64],
     "libra_gemm_splitk_workspace_bytes": [_I64, _I64, _I64],
     "libra_gemm_bf16_nt_splitk": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, C.c_size_t, _P],
@@ -38,6 +40,13 @@ SIGNATURES = {
     "libra_feature_select": [_P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_feature_select_bwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "libra_lfq_encode": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "libra_rmsnorm_routed_fwd": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _F, _P],
+    "libra_rope_bridge": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "libra_bridge_attn_fwd": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
+    "libra_swiglu": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_gather_rows": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _P],
+    "libra_copy_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P],
+    "libra_ce_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
 }

@@ -1,0 +1,310 @@
+// Row kernels of the routed decoder (all HBM-bound): modality-routed RMSNorm, RoPE + rank-8 bridge
+// expansion, SwiGLU, multi-codebook embedding assembly, fused cross-entropy statistics.
+#include "hip_common.hpp"
+#include "../../include/libra_hip.h"
+
+namespace libra {
+
+// ---------------------------------------------------------------------------------------------------
+// Routed RMSNorm (LlamaRMSNorm, modeling_llama.py:127-132, routed by cal_language_vision, modeling_libra.py:463,
+// :481,:817): y = w_m * bf16(x * rsqrt(mean(x^2) + eps)), w_m chosen per row by the modality flag.  The x*rstd
+// product is rounded to bf16 BEFORE the weight multiply, as `self.weight * hidden_states.to(input_dtype)` does.
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_routed_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                             const bf16_t* __restrict__ w_lang,
+                                                             const bf16_t* __restrict__ w_vis,
+                                                             const unsigned char* __restrict__ flag,
+                                                             bf16_t* __restrict__ y, long ldy, float* __restrict__ rstd_o,
+                                                             long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 3;
+    float v[NC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            unpack8(*(const u32x4*)(x + row * ldx + c * 8), v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    if (rstd_o && lane == 0) rstd_o[row] = rstd;
+    const bf16_t* w = (flag && flag[row]) ? w_vis : w_lang;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float g[8], o[8];
+            unpack8(*(const u32x4*)(w + c * 8), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(v[i][e] * rstd));
+            *(u32x4*)(y + row * ldy + c * 8) = pack8(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE + bridge (modeling_libra.py:318-340, :282-286, apply_rotary_pos_emb :39-61).  Per token n (position
+// s = n % S) and head, head_dim 128:
+//   kb = B_k[m] t_k,  vb = B_v[m] t_v          (rank-8 expansion of the bridge low-rank activations, m = modality)
+//   q' = rope(q);  k_same = rope(k);  k_cross = rope(bf16(k + kb));  v_cross = bf16(v + vb)
+// q and k_same overwrite qkv in place; every product / sum is rounded to bf16 where the reference's bf16 ops do.
+// One thread = 8 channels d in [8c, 8c+8) and their RoPE partners d + 64.
+struct RopeArgs {
+    bf16_t* qkv; long ld; int H;                  // [N, 3*H*128]: q | k | v
+    const bf16_t* tb; long ldt;                   // [N, >=16]: cols 0..7 = k-bridge t, 8..15 = v-bridge t
+    const bf16_t* bk_l; const bf16_t* bk_v; const bf16_t* bv_l; const bf16_t* bv_v;   // weight_B [H*128, 8]
+    const unsigned char* flag;
+    const bf16_t* cos; const bf16_t* sin;         // [max_pos, 128] bf16 (the reference casts its fp32 cache to x.dtype)
+    bf16_t* k_cross; bf16_t* v_cross; long ldc;   // [N, H*128]
+    long N; int S;
+};
+
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+
+__global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = p.N * p.H * 8;
+    if (i >= total) return;
+    const int c = (int)(i & 7);
+    const long th = i >> 3;
+    const int h = (int)(th % p.H);
+    const long n = th / p.H;
+    const int s = (int)(n % p.S);
+    const bool vis = p.flag[n] != 0;
+    const int HD = p.H * 128;
+    float tk[8], tv[8];
+    unpack8(*(const u32x4*)(p.tb + n * p.ldt), tk);
+    unpack8(*(const u32x4*)(p.tb + n * p.ldt + 8), tv);
+    const bf16_t* bk = vis ? p.bk_v : p.bk_l;
+    const bf16_t* bv = vis ? p.bv_v : p.bv_l;
+    float cs[2][8], sn[2][8];
+    float q[2][8], k[2][8], v[2][8], kb[2][8], vb[2][8];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int d = hf * 64 + c * 8;
+        const long col = (long)h * 128 + d;
+        unpack8(*(const u32x4*)(p.cos + (long)s * 128 + d), cs[hf]);
+        unpack8(*(const u32x4*)(p.sin + (long)s * 128 + d), sn[hf]);
+        unpack8(*(const u32x4*)(p.qkv + n * p.ld + col), q[hf]);
+        unpack8(*(const u32x4*)(p.qkv + n * p.ld + HD + col), k[hf]);
+        unpack8(*(const u32x4*)(p.qkv + n * p.ld + 2 * HD + col), v[hf]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float wk[8], wv[8];
+            unpack8(*(const u32x4*)(bk + (col + e) * 8), wk);
+            unpack8(*(const u32x4*)(bv + (col + e) * 8), wv);
+            float a = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { a = fmaf(tk[r], wk[r], a); b2 = fmaf(tv[r], wv[r], b2); }
+            kb[hf][e] = rbf(a);
+            vb[hf][e] = rbf(b2);
+        }
+    }
+    float qo[2][8], ko[2][8], kc[2][8], vc[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float kx0 = rbf(k[0][e] + kb[0][e]), kx1 = rbf(k[1][e] + kb[1][e]);
+        // x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
+        qo[0][e] = rbf(rbf(q[0][e] * cs[0][e]) + rbf(-q[1][e] * sn[0][e]));
+        qo[1][e] = rbf(rbf(q[1][e] * cs[1][e]) + rbf(q[0][e] * sn[1][e]));
+        ko[0][e] = rbf(rbf(k[0][e] * cs[0][e]) + rbf(-k[1][e] * sn[0][e]));
+        ko[1][e] = rbf(rbf(k[1][e] * cs[1][e]) + rbf(k[0][e] * sn[1][e]));
+        kc[0][e] = rbf(rbf(kx0 * cs[0][e]) + rbf(-kx1 * sn[0][e]));
+        kc[1][e] = rbf(rbf(kx1 * cs[1][e]) + rbf(kx0 * sn[1][e]));
+        vc[0][e] = v[0][e] + vb[0][e];
+        vc[1][e] = v[1][e] + vb[1][e];
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const long col = (long)h * 128 + hf * 64 + c * 8;
+        *(u32x4*)(p.qkv + n * p.ld + col) = pack8(qo[hf]);
+        *(u32x4*)(p.qkv + n * p.ld + HD + col) = pack8(ko[hf]);
+        *(u32x4*)(p.k_cross + n * p.ldc + col) = pack8(kc[hf]);
+        *(u32x4*)(p.v_cross + n * p.ldc + col) = pack8(vc[hf]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SwiGLU: y = silu(g) * u  with g = gu[:, :I], u = gu[:, I:2I]  (LlamaMLP act_fn(gate) * up, modeling_llama.py:199-201;
+// both bf16 roundings of the reference kept: bf16(silu(g)) * u -> bf16).
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, long ldgu,
+                                                     bf16_t* __restrict__ y, long ldy, long rows, int I) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i8 = I >> 3;
+    if (i >= rows * i8) return;
+    const long r = i / i8;
+    const int c = (int)(i - r * i8) * 8;
+    float a[8], b[8], o[8];
+    unpack8(*(const u32x4*)(g + r * ldgu + c), a);
+    unpack8(*(const u32x4*)(u + r * ldgu + c), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rbf(a[e] / (1.0f + __expf(-a[e]))) * b[e];
+    *(u32x4*)(y + r * ldy + c) = pack8(o);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row gather:  out[r, col0 + :] = table[idx[r] - sub]   (embedding lookups; idx int64)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ table, int D, const long long* __restrict__ idx,
+                                                          long long sub, const int* __restrict__ rows_sel, long n,
+                                                          bf16_t* __restrict__ out, long ldo, int col0) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d8 = D >> 3;
+    if (i >= n * d8) return;
+    const long r = i / d8;
+    const int c = (int)(i - r * d8) * 8;
+    const long src_row = rows_sel ? rows_sel[r] : r;           // which token this output row stands for
+    const long long id = idx[src_row] - sub;
+    *(u32x4*)(out + r * ldo + col0 + c) = *(const u32x4*)(table + id * D + c);
+}
+
+// copy rows: out[r, col0:col0+D] = in[rows_sel[r], :D]
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict__ in, long ldi, int D, const int* __restrict__ rows_sel,
+                                                        long n, bf16_t* __restrict__ out, long ldo, int col0) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d8 = D >> 3;
+    if (i >= n * d8) return;
+    const long r = i / d8;
+    const int c = (int)(i - r * d8) * 8;
+    const long sr = rows_sel ? rows_sel[r] : r;
+    *(u32x4*)(out + r * ldo + col0 + c) = *(const u32x4*)(in + sr * ldi + c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cross-entropy row statistics over logits [rows, V] (bf16): loss_r = logsumexp(z_r) - z_r[target_r], fp32,
+// 0 and not counted when target_r == ignore (-100).  One wave per row (torch's CrossEntropyLoss on the bf16 logits
+// upcasts to fp32 internally the same way).  Accumulates sum(loss) and count with one atomic per block pair —
+// kept deterministic by writing per-row losses and reducing on the host side tensor instead.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const bf16_t* __restrict__ z, long ldz, int V, const long long* __restrict__ target,
+                                                      long long tsub, float* __restrict__ loss_rows, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long t = target[row];
+    if (t < 0) { if (lane == 0) loss_rows[row] = 0.f; return; }
+    const bf16_t* zr = z + row * ldz;
+    float mx = -INFINITY;
+    for (int c = lane * 8; c < V; c += 512) {
+        if (c + 8 <= V) {
+            float v[8];
+            unpack8(*(const u32x4*)(zr + c), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
+        } else {
+            for (int e = 0; c + e < V; ++e) mx = fmaxf(mx, bf2f(zr[c + e]));
+        }
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane * 8; c < V; c += 512) {
+        if (c + 8 <= V) {
+            float v[8];
+            unpack8(*(const u32x4*)(zr + c), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) se += __expf(v[e] - mx);
+        } else {
+            for (int e = 0; c + e < V; ++e) se += __expf(bf2f(zr[c + e]) - mx);
+        }
+    }
+    se = wave_sum(se);
+    if (lane == 0) {
+        const long long tl = t - tsub;
+        const float zt = (tl >= 0 && tl < V) ? bf2f(zr[tl]) : -INFINITY;     // label outside this head's range -> +inf loss, as in the reference
+        loss_rows[row] = (mx + __logf(se)) - zt;
+    }
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH; }
+
+}  // namespace libra
+
+using namespace libra;
+
+extern "C" int libra_rmsnorm_routed_fwd(const void* x, int64_t ldx, const void* w_lang, const void* w_vis,
+                                        const uint8_t* flag, void* y, int64_t ldy, float* rstd, int64_t rows, int64_t D,
+                                        float eps, void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (D <= 0 || (D % 8) || D > 8192 || ldx < D || ldy < D || (ldx % 8) || (ldy % 8)) return LIBRA_ERR_SHAPE;
+    if (!x || !w_lang || !y || (flag && !w_vis) || !al16(x) || !al16(y) || !al16(w_lang) || (w_vis && !al16(w_vis)))
+        return LIBRA_ERR_ALIGN;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const int nc = (int)((D / 8 + 63) / 64);
+#define LAUNCH_RMS(NC)                                                                                              \
+    hipLaunchKernelGGL((rmsnorm_routed_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, \
+                       (long)ldx, (const bf16_t*)w_lang, (const bf16_t*)w_vis, flag, (bf16_t*)y, (long)ldy, rstd,    \
+                       (long)rows, (int)D, eps)
+    if (nc <= 1) LAUNCH_RMS(1); else if (nc <= 2) LAUNCH_RMS(2); else if (nc <= 4) LAUNCH_RMS(4);
+    else if (nc <= 8) LAUNCH_RMS(8); else LAUNCH_RMS(16);
+#undef LAUNCH_RMS
+    return launched();
+}
+
+extern "C" int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                                 const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                                 int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
+                                 int64_t H, void* stream) {
+    if (N <= 0) return LIBRA_OK;
+    if (H <= 0 || S <= 0 || S > max_pos || ld < 3 * H * 128 || ldt < 16 || ldc < H * 128) return LIBRA_ERR_SHAPE;
+    if ((ld % 8) || (ldt % 8) || (ldc % 8)) return LIBRA_ERR_ALIGN;
+    if (!qkv || !tb || !bk_l || !bk_v || !bv_l || !bv_v || !flag || !cos || !sin || !k_cross || !v_cross) return LIBRA_ERR_ALIGN;
+    if (!al16(qkv) || !al16(tb) || !al16(bk_l) || !al16(bk_v) || !al16(bv_l) || !al16(bv_v) || !al16(cos) || !al16(sin) ||
+        !al16(k_cross) || !al16(v_cross)) return LIBRA_ERR_ALIGN;
+    RopeArgs a;
+    a.qkv = (bf16_t*)qkv; a.ld = ld; a.H = (int)H; a.tb = (const bf16_t*)tb; a.ldt = ldt;
+    a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
+    a.flag = flag; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
+    a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
+    const long total = N * H * 8;
+    hipLaunchKernelGGL(rope_bridge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return launched();
+}
+
+extern "C" int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows,
+                            int64_t I, void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (I <= 0 || (I % 8) || ldgu < I || ldy < I || (ldgu % 8) || (ldy % 8)) return LIBRA_ERR_SHAPE;
+    if (!gate || !up || !y || !al16(gate) || !al16(up) || !al16(y)) return LIBRA_ERR_ALIGN;
+    const long total = rows * (I / 8);
+    hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate, (const bf16_t*)up, (long)ldgu, (bf16_t*)y, (long)ldy, (long)rows, (int)I);
+    return launched();
+}
+
+extern "C" int libra_gather_rows(const void* table, int64_t D, const int64_t* idx, int64_t sub, const int32_t* rows_sel,
+                                 int64_t n, void* out, int64_t ldo, int64_t col0, void* stream) {
+    if (n <= 0) return LIBRA_OK;
+    if (D <= 0 || (D % 8) || (ldo % 8) || (col0 % 8) || ldo < col0 + D) return LIBRA_ERR_SHAPE;
+    if (!table || !idx || !out || !al16(table) || !al16(out)) return LIBRA_ERR_ALIGN;
+    const long total = n * (D / 8);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)table, (int)D, (const long long*)idx, (long long)sub, rows_sel, (long)n,
+                       (bf16_t*)out, (long)ldo, (int)col0);
+    return launched();
+}
+
+extern "C" int libra_copy_rows(const void* in, int64_t ldi, int64_t D, const int32_t* rows_sel, int64_t n, void* out,
+                               int64_t ldo, int64_t col0, void* stream) {
+    if (n <= 0) return LIBRA_OK;
+    if (D <= 0 || (D % 8) || (ldi % 8) || (ldo % 8) || (col0 % 8) || ldo < col0 + D || ldi < D) return LIBRA_ERR_SHAPE;
+    if (!in || !out || !al16(in) || !al16(out)) return LIBRA_ERR_ALIGN;
+    const long total = n * (D / 8);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (long)ldi, (int)D, rows_sel, (long)n, (bf16_t*)out, (long)ldo, (int)col0);
+    return launched();
+}
+
+extern "C" int libra_ce_rows(const void* logits, int64_t ldz, int64_t V, const int64_t* target, int64_t target_sub,
+                             float* loss_rows, int64_t rows, void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (V <= 0 || ldz < V || (ldz % 8)) return LIBRA_ERR_SHAPE;
+    if (!logits || !target || !loss_rows || !al16(logits)) return LIBRA_ERR_ALIGN;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)logits, (long)ldz, (int)V, (const long long*)target, (long long)target_sub, loss_rows,
+                       (long)rows);
+    return launched();
+}

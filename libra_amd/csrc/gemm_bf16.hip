@@ -37,6 +37,7 @@ constexpr int GEMM_LDS = 4 * TILE_BYTES;          // A0 B0 A1 B1 = 64 KiB (== 12
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; bf16_t* C;
     const bf16_t* bias; const bf16_t* resid; const bf16_t* aux; bf16_t* preact;
+    const int* a_rows; const int* c_rows;     // optional row gather (A, N-type only) / scatter (C, resid, aux, preact)
     long lda, ldb, ldc, ldr, ldaux, ldpre;
     int M, N, K;
     int tiles_m, tiles_n;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
     unsigned srcA[4], srcB[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        srcA[j] = stage_src<AT>(wave * 4 + j, lane, m0, p.M, p.lda);
+        srcA[j] = stage_src<AT>(wave * 4 + j, lane, m0, p.M, p.lda, p.a_rows);
         srcB[j] = stage_src<BT>(wave * 4 + j, lane, n0, p.N, p.ldb);
     }
     const long kstepA = ktile_stride<AT>(p.lda), kstepB = ktile_stride<BT>(p.ldb);
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
         const int row = pass * 16 + (tid >> 4);
         const int gm = m0 + row;
         if (gm >= p.M) break;
+        const int om = p.c_rows ? p.c_rows[gm] : gm;
         float v[8];
         const f32x4 lo = *(const f32x4*)(ct + row * BN + cgrp * 8);
         const f32x4 hi = *(const f32x4*)(ct + row * BN + cgrp * 8 + 4);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
         if (p.flags & LIBRA_GEMM_STORE_PREACT) {
             // the reference rounds the Linear output to bf16 before the activation sees it
-            bf16_t* pd = p.preact + (long)gm * p.ldpre + gn;
+            bf16_t* pd = p.preact + (long)om * p.ldpre + gn;
             if (full8) *(u32x4*)pd = pack8(v);
             else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
         }
@@ -180,19 +182,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
         }
         if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
             float a[8];
-            if (full8) unpack8(*(const u32x4*)(p.aux + (long)gm * p.ldaux + gn), a);
-            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.aux[(long)gm * p.ldaux + gn + e]) : 0.f;
+            if (full8) unpack8(*(const u32x4*)(p.aux + (long)om * p.ldaux + gn), a);
+            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f(a[e]);
         }
         if (p.flags & LIBRA_GEMM_RESIDUAL) {
             float a[8];
-            if (full8) unpack8(*(const u32x4*)(p.resid + (long)gm * p.ldr + gn), a);
-            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.resid[(long)gm * p.ldr + gn + e]) : 0.f;
+            if (full8) unpack8(*(const u32x4*)(p.resid + (long)om * p.ldr + gn), a);
+            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
         }
-        bf16_t* dst = p.C + (long)gm * p.ldc + gn;
+        bf16_t* dst = p.C + (long)om * p.ldc + gn;
         if (full8) {
             *(u32x4*)dst = pack8(v);
         } else {
@@ -209,7 +211,13 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                      int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
                                      float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
-                                     void* stream);
+                                     const int* a_rows, const int* c_rows, void* stream);
+
+extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                         int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                         int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                         float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
+                                         int64_t a_phys_rows, const int32_t* c_rows, void* stream);
 
 // Tile-structure choice (speed only): the 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of
 // workgroups but runs 1 workgroup / CU (256 slots) against 2 / CU (512 slots) for the 128^2 kernel.
@@ -254,18 +262,29 @@ extern "C" int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void*
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) return LIBRA_ERR_ALIGN;
     if (!workspace || workspace_bytes < libra_gemm_splitk_workspace_bytes(M, N, splits)) return LIBRA_ERR_ALIGN;
     return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 1.0f, 0, flags,
-                                 (float*)workspace, (int)splits, stream);
+                                 (float*)workspace, (int)splits, nullptr, nullptr, stream);
 }
 
 extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                   int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                   int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
                                   float alpha, int64_t alpha_cols, int flags, void* stream) {
+    return libra_gemm_bf16_nt_routed(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha,
+                                     alpha_cols, flags, nullptr, M, nullptr, stream);
+}
+
+extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                         int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                         int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                         float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
+                                         int64_t a_phys_rows, const int32_t* c_rows, void* stream) {
     if (M <= 0 || N <= 0) return LIBRA_OK;                       // empty problem: nothing to do
     if (!A || !B || !C || K <= 0 || (K % BK) != 0) return LIBRA_ERR_SHAPE;
     const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
     if ((lda % 8) || (ldb % 8) || ldc < N) return LIBRA_ERR_SHAPE;
-    if (at ? (lda < M || (M % 8) || K * lda >= (1LL << 31)) : (lda < K || M * lda >= (1LL << 31))) return LIBRA_ERR_SHAPE;
+    if (a_rows && (at || a_phys_rows <= 0)) return LIBRA_ERR_SHAPE;               // row gather: K-contiguous A only
+    const int64_t arows = a_rows ? a_phys_rows : M;
+    if (at ? (lda < M || (M % 8) || K * lda >= (1LL << 31)) : (lda < K || arows * lda >= (1LL << 31))) return LIBRA_ERR_SHAPE;
     if (bt ? (ldb < N || (N % 8) || K * ldb >= (1LL << 31)) : (ldb < K || N * ldb >= (1LL << 31))) return LIBRA_ERR_SHAPE;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return LIBRA_ERR_ALIGN;
     const bool vec_ok = (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0);
@@ -278,7 +297,7 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
 
     if (pick_256(M, N, K))
         return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha,
-                                     alpha_cols, flags, nullptr, 1, stream);
+                                     alpha_cols, flags, nullptr, 1, a_rows, c_rows, stream);
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
@@ -286,6 +305,7 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
+    p.a_rows = a_rows; p.c_rows = c_rows;
 
     const long nblk = (long)p.tiles_m * p.tiles_n;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;

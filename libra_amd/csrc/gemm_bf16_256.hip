@@ -31,6 +31,7 @@ constexpr int G256_THREADS = 512;
 struct Gemm256Args {
     const bf16_t* A; const bf16_t* B; bf16_t* C;
     const bf16_t* bias; const bf16_t* resid; const bf16_t* aux; bf16_t* preact;
+    const int* a_rows; const int* c_rows;     // optional row gather (A, N-type only) / scatter (C, resid, aux, preact)
     long lda, ldb, ldc, ldr, ldaux, ldpre;
     int M, N, K;
     int tiles_m, tiles_n;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            srcA[h][j] = stage_src<AT>(wave * 2 + j, lane, m0 + h * 128, p.M, p.lda);
+            srcA[h][j] = stage_src<AT>(wave * 2 + j, lane, m0 + h * 128, p.M, p.lda, p.a_rows);
             srcB[h][j] = stage_src<BT>(wave * 2 + j, lane, n0 + h * 128, p.N, p.ldb);
         }
     const int ldst = wave * 2048;          // this wave's byte offset inside any half-tile (2 x 1 KiB pieces)
@@ -216,11 +217,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
             const int row = pass * 8 + (lane >> 3);
             const int gm = m0 + wr * 128 + i * 32 + row;
             if (gm < p.M && ncol_ok) {
+                const int om = p.c_rows ? p.c_rows[gm] : gm;
                 float v[8];
                 const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
                 const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
                 if (p.slab) {
-                    float* sd = p.slab + ((long)blockIdx.y * p.M + gm) * p.N + gn;
+                    float* sd = p.slab + ((long)blockIdx.y * p.M + gm) * p.N + gn;   // slabs are never row-mapped
                     if (full8) { *(f32x4*)sd = lo; *(f32x4*)(sd + 4) = hi; }
                     else for (int e = 0; e < 8 && gn + e < p.N; ++e) sd[e] = e < 4 ? lo[e] : hi[e - 4];
                     continue;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
                 if (p.flags & LIBRA_GEMM_STORE_PREACT) {
-                    bf16_t* pd = p.preact + (long)gm * p.ldpre + gn;
+                    bf16_t* pd = p.preact + (long)om * p.ldpre + gn;
                     if (full8) *(u32x4*)pd = pack8(v);
                     else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
                 }
@@ -240,19 +242,19 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
                 }
                 if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
                     float x[8];
-                    if (full8) unpack8(*(const u32x4*)(p.aux + (long)gm * p.ldaux + gn), x);
-                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.aux[(long)gm * p.ldaux + gn + e]) : 0.f;
+                    if (full8) unpack8(*(const u32x4*)(p.aux + (long)om * p.ldaux + gn), x);
+                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad(x[e]);
                 }
                 if (p.flags & LIBRA_GEMM_RESIDUAL) {
                     float x[8];
-                    if (full8) unpack8(*(const u32x4*)(p.resid + (long)gm * p.ldr + gn), x);
-                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.resid[(long)gm * p.ldr + gn + e]) : 0.f;
+                    if (full8) unpack8(*(const u32x4*)(p.resid + (long)om * p.ldr + gn), x);
+                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += x[e];
                 }
-                bf16_t* dst = p.C + (long)gm * p.ldc + gn;
+                bf16_t* dst = p.C + (long)om * p.ldc + gn;
                 if (full8) *(u32x4*)dst = pack8(v);
                 else for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
             }
@@ -292,7 +294,7 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                      int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
                                      float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
-                                     void* stream) {
+                                     const int* a_rows, const int* c_rows, void* stream) {
     Gemm256Args p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
@@ -301,6 +303,7 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (int)((N + 255) / 256);
     p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
     p.slab = slab; p.splitk = splitk < 1 ? 1 : splitk;
+    p.a_rows = a_rows; p.c_rows = c_rows;
     const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
     void (*kern)(const Gemm256Args) =
         at ? (bt ? gemm_bf16_nt_256_kernel<true, true> : gemm_bf16_nt_256_kernel<true, false>)

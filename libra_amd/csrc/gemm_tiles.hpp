@@ -67,12 +67,14 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, const FragAddr& f,
 //   N-type piece = 8 lines x 128 B: line = 8*pc + lane/8, LDS position lane%8
 //   T-type piece = 4 k-rows x 256 B: row = 4*pc + lane/16, LDS position lane%16
 template <bool T>
-__device__ __forceinline__ unsigned stage_src(int pc, int lane, int line0, int nlines, long ld) {
+__device__ __forceinline__ unsigned stage_src(int pc, int lane, int line0, int nlines, long ld,
+                                              const int* __restrict__ rows = nullptr) {
     if constexpr (!T) {
         const int r = pc * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int g = line0 + r;
         g = g < nlines ? g : nlines - 1;                 // clamp the tail (masked at the store)
+        if (rows) g = rows[g];                           // routed gather: logical line -> physical row
         return (unsigned)g * (unsigned)ld + c * 8;
     } else {
         const int r = pc * 4 + (lane >> 4);

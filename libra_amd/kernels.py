@@ -50,23 +50,31 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, quick_gelu: bool = False,
             qgelu_grad_of: Optional[torch.Tensor] = None, preact_out: Optional[torch.Tensor] = None,
             alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None, a_t: bool = False,
-            b_t: bool = False) -> torch.Tensor:
+            b_t: bool = False, a_rows: Optional[torch.Tensor] = None, c_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epi(A @ B^T) with A = a [M,K] (or a^T when a_t: a is [K,M], reduction-major) and
     B = b [N,K] (or b^T when b_t: b is [K,N]).  `k` limits the contraction to the first k reduction steps.
     The reduction length must be a multiple of 64 (reduction-major operands: allocate with alloc_rows)."""
     _chk2d(a, "a"); _chk2d(b, "b")
     (Ka, M) = a.shape if a_t else a.shape[::-1]
+    a_phys = a.shape[0]
+    if a_rows is not None:                       # routed gather: logical rows = len(a_rows)
+        if a_t or a_rows.dtype != torch.int32:
+            raise ValueError("gemm_nt: a_rows needs a K-contiguous A and an int32 index tensor")
+        M = a_rows.numel()
     (Kb, N) = b.shape if b_t else b.shape[::-1]
     K = k if k is not None else Ka
     if K > Ka or K > Kb or (k is None and Ka != Kb):
         raise ValueError(f"gemm_nt: inner dims differ: a {tuple(a.shape)} b {tuple(b.shape)} k={k} a_t={a_t} b_t={b_t}")
+    if c_rows is not None:
+        if out is None or c_rows.dtype != torch.int32 or c_rows.numel() != M or out.shape[1] != N:
+            raise ValueError("gemm_nt: c_rows (int32 [M]) scatters into a caller-provided out [rows, N]")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
     _chk2d(out, "out")
-    if out.shape != (M, N):
+    if c_rows is None and out.shape != (M, N):
         raise ValueError(f"gemm_nt: out is {tuple(out.shape)}, expected {(M, N)}")
     plain = (bias is None and resid is None and not quick_gelu and qgelu_grad_of is None and preact_out is None
-             and alpha_cols == 0)
+             and alpha_cols == 0 and a_rows is None and c_rows is None)
     if plain and M > 0 and N > 0:
         splits = _lib.lib().libra_gemm_splitk_plan(M, N, K)
         if splits > 1:
@@ -86,25 +94,25 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     ldr = ldaux = ldpre = 0
     if resid is not None:
         _chk2d(resid, "resid")
-        if resid.shape != (M, N):
+        if resid.shape != out.shape:
             raise ValueError("gemm_nt: resid shape")
         flags |= GEMM_RESIDUAL; ldr = resid.stride(0)
     if qgelu_grad_of is not None:
         _chk2d(qgelu_grad_of, "qgelu_grad_of")
-        if qgelu_grad_of.shape != (M, N):
+        if qgelu_grad_of.shape != out.shape:
             raise ValueError("gemm_nt: qgelu_grad_of shape")
         flags |= GEMM_MUL_QGELU_GRAD; ldaux = qgelu_grad_of.stride(0)
     if preact_out is not None:
         _chk2d(preact_out, "preact_out")
-        if preact_out.shape != (M, N):
+        if preact_out.shape != out.shape:
             raise ValueError("gemm_nt: preact_out shape")
         flags |= GEMM_STORE_PREACT; ldpre = preact_out.stride(0)
     if quick_gelu:
         flags |= GEMM_QUICK_GELU
-    rc = _lib.lib().libra_gemm_bf16_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                       out.stride(0), M, N, K, _ptr(bias), _ptr(resid), ldr, _ptr(qgelu_grad_of),
-                                       ldaux, _ptr(preact_out), ldpre, float(alpha), int(alpha_cols), flags,
-                                       _stream())
+    rc = _lib.lib().libra_gemm_bf16_nt_routed(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                              out.stride(0), M, N, K, _ptr(bias), _ptr(resid), ldr,
+                                              _ptr(qgelu_grad_of), ldaux, _ptr(preact_out), ldpre, float(alpha),
+                                              int(alpha_cols), flags, _ptr(a_rows), a_phys, _ptr(c_rows), _stream())
     _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
     return out
 
@@ -357,7 +365,83 @@ def _profiled(kind, work_fn):
 def _gemm_flops(a, b, **kw):
     a_t, b_t = kw.get("a_t", False), kw.get("b_t", False)
     k = kw.get("k") or (a.shape[0] if a_t else a.shape[1])
-    return 2.0 * (a.shape[1] if a_t else a.shape[0]) * (b.shape[1] if b_t else b.shape[0]) * k
+    m = kw["a_rows"].numel() if kw.get("a_rows") is not None else (a.shape[1] if a_t else a.shape[0])
+    return 2.0 * m * (b.shape[1] if b_t else b.shape[0]) * k
 
 
 gemm_nt = _profiled("gemm", _gemm_flops)(gemm_nt)
+
+
+# ---- routed decoder rows -------------------------------------------------------------------------------
+def rmsnorm_routed(x, w_lang, w_vis, flag, eps: float, *, out=None):
+    _chk2d(x, "x")
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=BF16, device=x.device) if out is None else out
+    rc = _lib.lib().libra_rmsnorm_routed_fwd(x.data_ptr(), x.stride(0), w_lang.data_ptr(), _ptr(w_vis), _ptr(flag),
+                                             y.data_ptr(), y.stride(0), None, rows, D, float(eps), _stream())
+    _lib.check(rc, "rmsnorm_routed")
+    return y
+
+
+def rope_bridge(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, S: int, H: int):
+    _chk2d(qkv, "qkv"); _chk2d(tb, "tb")
+    N = qkv.shape[0]
+    kc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
+    vc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
+    rc = _lib.lib().libra_rope_bridge(qkv.data_ptr(), qkv.stride(0), tb.data_ptr(), tb.stride(0), bk_l.data_ptr(),
+                                      bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), cos.data_ptr(),
+                                      sin.data_ptr(), cos.shape[0], kc.data_ptr(), vc.data_ptr(), kc.stride(0), N, S, H,
+                                      _stream())
+    _lib.check(rc, "rope_bridge")
+    return kc, vc
+
+
+def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S: int, H: int, scale: float, *,
+                    need_lse: bool = False):
+    for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross")):
+        _chk2d(t, n)
+    if k_same.stride(0) != k_cross.stride(0) or v_same.stride(0) != v_cross.stride(0):
+        raise ValueError("bridge_attn_fwd: same/cross operands must share a row stride")
+    out = torch.empty((B * S, H * 128), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device) if need_lse else None
+    rc = _lib.lib().libra_bridge_attn_fwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_cross.data_ptr(), k_same.stride(0),
+                                          v_same.data_ptr(), v_cross.data_ptr(), v_same.stride(0), flag.data_ptr(),
+                                          _ptr(kv_len), out.data_ptr(), out.stride(0), _ptr(lse), B, S, H, float(scale),
+                                          _stream())
+    _lib.check(rc, "bridge_attn_fwd")
+    return out, lse
+
+
+def swiglu(gate, up, *, out=None):
+    _chk2d(gate, "gate"); _chk2d(up, "up")
+    rows, I = gate.shape
+    if gate.stride(0) != up.stride(0):
+        raise ValueError("swiglu: gate/up must share a row stride")
+    y = torch.empty((rows, I), dtype=BF16, device=gate.device) if out is None else out
+    rc = _lib.lib().libra_swiglu(gate.data_ptr(), up.data_ptr(), gate.stride(0), y.data_ptr(), y.stride(0), rows, I, _stream())
+    _lib.check(rc, "swiglu")
+    return y
+
+
+def gather_rows(table, idx, sub: int, rows_sel, n: int, out, col0: int = 0):
+    rc = _lib.lib().libra_gather_rows(table.data_ptr(), table.shape[1], idx.data_ptr(), sub, _ptr(rows_sel), n,
+                                      out.data_ptr(), out.stride(0), col0, _stream())
+    _lib.check(rc, "gather_rows")
+    return out
+
+
+def copy_rows(src, rows_sel, n: int, out, col0: int = 0):
+    rc = _lib.lib().libra_copy_rows(src.data_ptr(), src.stride(0), src.shape[1], _ptr(rows_sel), n, out.data_ptr(),
+                                    out.stride(0), col0, _stream())
+    _lib.check(rc, "copy_rows")
+    return out
+
+
+def ce_rows(logits, target, target_sub: int = 0):
+    _chk2d(logits, "logits")
+    rows, V = logits.shape
+    loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    rc = _lib.lib().libra_ce_rows(logits.data_ptr(), logits.stride(0), V, target.data_ptr(), target_sub, loss.data_ptr(),
+                                  rows, _stream())
+    _lib.check(rc, "ce_rows")
+    return loss

@@ -1,0 +1,151 @@
+"""Parity of the routed-decoder kernels against fp32 closed-form math on the same bf16 inputs
+(tolerance: see test_kernels_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_kernels_gpu import close, rnd
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def K():
+    from libra_amd import kernels
+    return kernels
+
+
+def _flags(N, seed, mode):
+    g = torch.Generator().manual_seed(seed)
+    if mode == "random":
+        return (torch.rand(N, generator=g) < 0.4).to(torch.uint8)
+    f = torch.zeros(N, dtype=torch.uint8)
+    if mode == "span":
+        a = N // 5
+        f[a:a + max(1, N // 3)] = 1
+    elif mode == "allvis":
+        f[:] = 1
+    return f
+
+
+def test_routed_gemm_gather_scatter(K):
+    Ntok, Kd, N = 300, 128, 200
+    x, w = rnd(Ntok, Kd, seed=1), rnd(N, Kd, seed=2)
+    idx = torch.randperm(Ntok, generator=torch.Generator().manual_seed(3))[:137].sort().values.to(torch.int32).cuda()
+    out = torch.zeros(Ntok, N, dtype=BF, device="cuda")
+    res = rnd(Ntok, N, seed=4)
+    K.gemm_nt(x, w, out=out, a_rows=idx, c_rows=idx, resid=res)
+    ref = torch.zeros(Ntok, N)
+    ii = idx.cpu().long()
+    ref[ii] = (x.float().cpu()[ii] @ w.float().cpu().t()) + res.float().cpu()[ii]
+    close(out, ref, what="routed gemm")
+    untouched = torch.ones(Ntok, dtype=torch.bool); untouched[ii] = False
+    assert float(out.cpu()[untouched].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,D", [(37, 256), (1000, 4096), (5, 6144)])
+def test_rmsnorm_routed(K, rows, D):
+    from oracle import libra_oracle as LO
+    x = rnd(rows, D, seed=1)
+    wl, wv = (rnd(D, seed=2) * 0.1 + 1).to(BF), (rnd(D, seed=3) * 0.1 + 1).to(BF)
+    flag = _flags(rows, 5, "random").cuda()
+    y = K.rmsnorm_routed(x, wl, wv, flag, 1e-6)
+    xf = x.float().cpu()
+    ref = LO.routed(xf, flag.cpu().bool(), lambda t: LO.rms_norm(t, wl.float().cpu(), 1e-6),
+                    lambda t: LO.rms_norm(t, wv.float().cpu(), 1e-6))
+    close(y, ref, what="routed rmsnorm")
+    y2 = K.rmsnorm_routed(x, wl, None, None, 1e-6)
+    close(y2, LO.rms_norm(xf, wl.float().cpu(), 1e-6), what="plain rmsnorm")
+
+
+def _attn_ref(q, ks, kc, vs, vc, flag, lens, B, S, H, scale):
+    d = 128
+    def hd(t):
+        return t.float().view(B, S, H, d).transpose(1, 2)
+    q, ks, kc, vs, vc = map(hd, (q, ks, kc, vs, vc))
+    m = flag.view(B, S).bool()
+    cross = (m[:, :, None] != m[:, None, :]).unsqueeze(1)
+    s = torch.where(cross, q @ kc.transpose(-1, -2), q @ ks.transpose(-1, -2)) * scale
+    i = torch.arange(S)
+    allowed = (i[None, :] <= i[:, None])[None, None] & (i[None, None, None, :] < lens.view(B, 1, 1, 1))
+    s = s.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    o = (p * (~cross)) @ vs + (p * cross) @ vc
+    return o.transpose(1, 2).reshape(B * S, H * d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,S,H,mode", [(1, 16, 1, "span"), (2, 33, 2, "random"), (1, 128, 1, "none"), (2, 200, 2, "span"),
+                                        (1, 640, 2, "random"), (1, 257, 1, "allvis"), (2, 1024, 2, "span")])
+def test_bridge_attention_fwd(K, B, S, H, mode):
+    N, D = B * S, H * 128
+    q, ks, kc, vs, vc = [rnd(N, D, seed=10 + i) for i in range(5)]
+    flag = _flags(N, 7, mode)
+    lens = torch.full((B,), S, dtype=torch.int32)
+    if B > 1:
+        lens[1] = max(1, S - S // 4)
+    o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag.cuda(), lens.cuda(), B, S, H, 128 ** -0.5, need_lse=True)
+    ro, rl = _attn_ref(q.cpu(), ks.cpu(), kc.cpu(), vs.cpu(), vc.cpu(), flag, lens.long(), B, S, H, 128 ** -0.5)
+    # rows beyond a sequence's valid length are don't-care in the reference too (labels -100): compare valid rows
+    valid = (torch.arange(S)[None, :] < lens[:, None].long()).reshape(N)
+    close(o.cpu()[valid], ro[valid], rel=2e-3, what="bridge attn out")
+    vl = valid.view(B, 1, S).expand(B, H, S)
+    close(lse.cpu()[vl], rl[vl], rel=1e-4, what="bridge lse")
+    assert torch.isfinite(o.float()).all()
+
+
+def test_rope_bridge(K):
+    from oracle import libra_oracle as LO
+    B, S, H = 2, 24, 2
+    N, D = B * S, H * 128
+    qkv = rnd(N, 3 * D, seed=1)
+    tb = torch.zeros(N, 64, dtype=BF, device="cuda"); tb[:, :16] = rnd(N, 16, seed=2)
+    bkl, bkv, bvl, bvv = [rnd(D, 8, seed=3 + i, scale=0.3) for i in range(4)]
+    flag = _flags(N, 9, "span")
+    cosf, sinf = LO.rope_tables(128, 64)
+    cos, sin = cosf.to(BF).cuda(), sinf.to(BF).cuda()
+    q0 = qkv.clone()
+    kc, vc = K.rope_bridge(qkv, tb, bkl, bkv, bvl, bvv, flag.cuda(), cos, sin, S, H)
+    # reference in fp32 on the same bf16 inputs (tables in bf16 as the reference casts them)
+    x = q0.float().cpu()
+    q, k, v = x[:, :D], x[:, D:2 * D], x[:, 2 * D:]
+    f = flag.bool()
+    tk, tv = tb[:, :8].float().cpu(), tb[:, 8:16].float().cpu()
+    kb = torch.where(f[:, None], tk @ bkv.float().cpu().t(), tk @ bkl.float().cpu().t())
+    vb = torch.where(f[:, None], tv @ bvv.float().cpu().t(), tv @ bvl.float().cpu().t())
+    pos = torch.arange(S).repeat(B)
+    c, s_ = cos.float().cpu()[pos], sin.float().cpu()[pos]
+
+    def rope(t):
+        t = t.view(N, H, 128)
+        return (t * c[:, None] + LO.rotate_half(t) * s_[:, None]).reshape(N, D)
+    close(qkv[:, :D], rope(q), rel=4e-3, what="q rope")
+    close(qkv[:, D:2 * D], rope(k), rel=4e-3, what="k_same")
+    close(kc, rope(k + kb), rel=4e-3, what="k_cross")
+    close(vc, v + vb, rel=2e-3, what="v_cross")
+    assert torch.equal(qkv[:, 2 * D:], q0[:, 2 * D:])
+
+
+def test_swiglu_gather_ce(K):
+    rows, I = 77, 512
+    gu = rnd(rows, 2 * I, seed=1)
+    y = K.swiglu(gu[:, :I], gu[:, I:])
+    g, u = gu[:, :I].float(), gu[:, I:].float()
+    close(y, F.silu(g) * u, rel=4e-3, what="swiglu")
+    table = rnd(50, 64, seed=2)
+    idx = torch.randint(100, 150, (30,), generator=torch.Generator().manual_seed(3)).cuda()
+    sel = torch.arange(0, 30, 2, dtype=torch.int32).cuda()
+    out = torch.zeros(15, 128, dtype=BF, device="cuda")
+    K.gather_rows(table, idx, 100, sel, 15, out, 64)
+    assert torch.equal(out[:, 64:], table[(idx[sel.long()] - 100)])
+    K.copy_rows(table, sel, 15, out, 0)
+    assert torch.equal(out[:, :64], table[sel.long()])
+    V = 515
+    z = torch.zeros(40, 520, dtype=BF, device="cuda"); z[:, :V] = rnd(40, V, seed=5) * 3
+    tgt = torch.randint(0, V, (40,), generator=torch.Generator().manual_seed(6)) + 1000
+    tgt[::7] = -100
+    loss = K.ce_rows(z[:, :V], tgt.cuda(), 1000)
+    ref = F.cross_entropy(z[:, :V].float().cpu(), (tgt - 1000).clamp_min(0), reduction="none")
+    ref[tgt < 0] = 0
+    close(loss, ref, rel=1e-4, what="ce rows")
