@@ -170,9 +170,10 @@ int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const 
 /* Fused routed-bridge causal flash attention, forward (LibraAttention.forward + attn_with_bridge,
  * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right-padding via
  * kv_len[b]), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row
- * strides ldq/ldk/ldv; flag [B*S] (1 = vision token); out [B*S, H*128]; lse [B,H,S] fp32 optional.      */
-int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, const void* k_cross, int64_t ldk,
-                          const void* v_same, const void* v_cross, int64_t ldv, const uint8_t* flag,
+ * strides ldq/ldk/ldkc/ldv/ldvc; flag [B*S] (1 = vision token); out [B*S, H*128]; lse [B,H,S] fp32 optional.      */
+int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
+                          int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
+                          const uint8_t* flag,
                           const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
                           int64_t H, float scale, void* stream);
 /* y = bf16(silu(gate)) * up  (LlamaMLP, models/llama/modeling_llama.py:199-201)                          */

@@ -29,8 +29,8 @@ constexpr int BR_LDS = 2 * STAGE_BYTES + 1024;  // double buffered + key-modalit
 
 struct BridgeArgs {
     const bf16_t* q; long ldq;
-    const bf16_t* k_same; const bf16_t* k_cross; long ldk;
-    const bf16_t* v_same; const bf16_t* v_cross; long ldv;
+    const bf16_t* k_same; const bf16_t* k_cross; long ldk, ldkc;
+    const bf16_t* v_same; const bf16_t* v_cross; long ldv, ldvc;
     const unsigned char* flag;     // [B*S] 1 = vision token
     const int* kv_len;             // [B] valid (non-padded) length, right padding
     bf16_t* out; long ldo;
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
     const bf16_t* ks_base = p.k_same + tok0 * p.ldk + h * BD;
-    const bf16_t* kc_base = p.k_cross + tok0 * p.ldk + h * BD;
+    const bf16_t* kc_base = p.k_cross + tok0 * p.ldkc + h * BD;
     const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * BD;
-    const bf16_t* vc_base = p.v_cross + tok0 * p.ldv + h * BD;
+    const bf16_t* vc_base = p.v_cross + tok0 * p.ldvc + h * BD;
 
     f32x16 o[4];
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
         needs(t, same, cross);
         char* dst = smem + buf * STAGE_BYTES;
         if (same) stage_kv(ks_base, p.ldk, vs_base, p.ldv, t * BKV, S, dst, wave, lane);
-        if (cross) stage_kv(kc_base, p.ldk, vc_base, p.ldv, t * BKV, S, dst + VAR_BYTES, wave, lane);
+        if (cross) stage_kv(kc_base, p.ldkc, vc_base, p.ldvc, t * BKV, S, dst + VAR_BYTES, wave, lane);
     };
     stage(0, 0);
 
@@ -304,19 +304,21 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
 
 using namespace libra;
 
-extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, const void* k_cross, int64_t ldk,
-                                     const void* v_same, const void* v_cross, int64_t ldv, const uint8_t* flag,
+extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
+                                     int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
+                                     const uint8_t* flag,
                                      const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
                                      int64_t H, float scale, void* stream) {
     if (B <= 0 || S <= 0) return LIBRA_OK;
-    if (H <= 0 || ldq < H * BD || ldk < H * BD || ldv < H * BD || ldo < H * BD || S > 4096) return LIBRA_ERR_SHAPE;
-    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8)) return LIBRA_ERR_ALIGN;
+    if (H <= 0 || ldq < H * BD || ldk < H * BD || ldv < H * BD || ldkc < H * BD || ldvc < H * BD || ldo < H * BD || S > 4096)
+        return LIBRA_ERR_SHAPE;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldkc % 8) || (ldvc % 8) || (ldo % 8)) return LIBRA_ERR_ALIGN;
     if (!q || !k_same || !k_cross || !v_same || !v_cross || !flag || !out) return LIBRA_ERR_ALIGN;
     if (((uintptr_t)q | (uintptr_t)k_same | (uintptr_t)k_cross | (uintptr_t)v_same | (uintptr_t)v_cross | (uintptr_t)out) & 15)
         return LIBRA_ERR_ALIGN;
     BridgeArgs a;
-    a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.k_cross = (const bf16_t*)k_cross; a.ldk = ldk;
-    a.v_same = (const bf16_t*)v_same; a.v_cross = (const bf16_t*)v_cross; a.ldv = ldv;
+    a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.k_cross = (const bf16_t*)k_cross; a.ldk = ldk; a.ldkc = ldkc;
+    a.v_same = (const bf16_t*)v_same; a.v_cross = (const bf16_t*)v_cross; a.ldv = ldv; a.ldvc = ldvc;
     a.flag = flag; a.kv_len = kv_len; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.n_qt = (int)((S + BQ - 1) / BQ);
     a.sl2 = scale * 1.4426950408889634f;

@@ -400,12 +400,11 @@ def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S
                     need_lse: bool = False):
     for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross")):
         _chk2d(t, n)
-    if k_same.stride(0) != k_cross.stride(0) or v_same.stride(0) != v_cross.stride(0):
-        raise ValueError("bridge_attn_fwd: same/cross operands must share a row stride")
     out = torch.empty((B * S, H * 128), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device) if need_lse else None
-    rc = _lib.lib().libra_bridge_attn_fwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_cross.data_ptr(), k_same.stride(0),
-                                          v_same.data_ptr(), v_cross.data_ptr(), v_same.stride(0), flag.data_ptr(),
+    rc = _lib.lib().libra_bridge_attn_fwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_same.stride(0), k_cross.data_ptr(),
+                                          k_cross.stride(0), v_same.data_ptr(), v_same.stride(0), v_cross.data_ptr(),
+                                          v_cross.stride(0), flag.data_ptr(),
                                           _ptr(kv_len), out.data_ptr(), out.stride(0), _ptr(lse), B, S, H, float(scale),
                                           _stream())
     _lib.check(rc, "bridge_attn_fwd")

@@ -2,5 +2,7 @@ from .clip_encoder import CLIPVisionTower
 from .image_tokenizer import ImageTokenizer
 from .lookup_free_quantization import LFQ
 from .vqgan import VQModel
+from .configuration_libra import LibraConfig
+from .modeling_libra import LibraForCausalLM, LlamaRMSNorm
 
-__all__ = ["CLIPVisionTower", "ImageTokenizer", "LFQ", "VQModel"]
+__all__ = ["CLIPVisionTower", "ImageTokenizer", "LFQ", "VQModel", "LibraConfig", "LibraForCausalLM", "LlamaRMSNorm"]

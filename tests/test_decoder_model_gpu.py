@@ -1,0 +1,101 @@
+"""The routed decoder (forward) on MI355X against the reference fixture / the CPU oracle."""
+import pytest
+import torch
+
+from helpers import load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def test_libra_tiny_forward_vs_reference_fixture():
+    from libra_amd.libra import LibraConfig, LibraForCausalLM
+    from oracle import libra_oracle as LO
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    m = LibraForCausalLM(LibraConfig(**c))
+    missing, unexpected = m.load_state_dict(sub(t, "w."), strict=True)
+    m = m.to(BF).cuda().eval()
+    ids, am, vi = t["in.input_ids"].cuda(), t["in.attention_mask"].cuda(), t["in.vision_indices"].cuda()
+    sig, lab = t["in.signal"].to(BF).cuda(), t["in.labels"].cuda()
+    with torch.no_grad():
+        out = m(input_ids=ids, attention_mask=am, vision_indices=vi, contiguous_signal=sig, labels=lab,
+                output_hidden_states=True)
+    # fp32 oracle on the bf16-rounded weights / signal: only the arithmetic differs
+    sdf = {k: v.to(BF).float() for k, v in sub(t, "w.").items()}
+    sdb = {k: v.to(BF) for k, v in sub(t, "w.").items()}
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+              max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    hid, flag = LO.model_forward(sdf, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"],
+                                 t["in.signal"].to(BF).float(), **kw)
+    hidb, _ = LO.model_forward(sdb, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"], t["in.signal"].to(BF), **kw)
+    valid = t["in.attention_mask"].bool()
+    ours = rel_err(out.hidden_states[-1].float().cpu()[valid], hid[valid])
+    theirs = rel_err(hidb.float()[valid], hid[valid])
+    assert ours < max(1.5 * theirs, 3e-3), (ours, theirs)
+    # logits: identical -inf pattern; finite part close; loss within bf16-logit noise of the fp32 loss
+    logits = LibraForCausalLM.materialize_logits(out).float().cpu()
+    ref_logits = LO.vl_logits(sdf, hid, flag, c["vision_codebook_num"])
+    assert logits.shape == t["out.logits"].shape
+    assert torch.equal(torch.isfinite(logits), torch.isfinite(ref_logits))
+    fin = torch.isfinite(ref_logits) & valid[None, :, :, None]
+    assert rel_err(logits[fin], ref_logits[fin]) < max(2.0 * theirs, 6e-3)
+    ref_loss = float(LO.causal_lm_loss(ref_logits, t["in.labels"]))
+    assert abs(float(out.loss) - ref_loss) < 2e-2 * abs(ref_loss), (float(out.loss), ref_loss)
+    assert abs(float(out.loss) - float(t["out.loss"])) < 5e-2 * abs(float(t["out.loss"]))
+    with pytest.raises(NotImplementedError):
+        m.requires_grad_(True)
+        o2 = m(input_ids=ids, attention_mask=am, vision_indices=vi, contiguous_signal=sig, labels=lab)
+        o2.loss.backward()
+
+
+def test_libra_full_width_single_layer_vs_oracle():
+    """One full-width Libra-11B decoder layer (H=4096, I=11008, 32 heads x 128, rank-8 bridges) at S=256:
+    the hot-loop body of BASELINE config 3, against the fp32 oracle on the host."""
+    from libra_amd import decoder_engine as DE
+    from oracle import libra_oracle as LO
+    g = torch.Generator().manual_seed(5)
+    H, I, heads, r, rg = 4096, 11008, 32, 1024, 2752
+    B, S, L = 2, 256, 70
+    sd = {}
+
+    def rn(*shape, std):
+        return (torch.randn(*shape, generator=g) * std).to(BF)
+    p = "model.layers.0."
+    for n in ("q", "k", "v", "o"):
+        sd[p + f"self_attn.{n}_proj.weight"] = rn(H, H, std=H ** -0.5)
+        sd[p + f"self_attn.vision_{n}_proj.weight_A"] = rn(r, H, std=H ** -0.5)
+        sd[p + f"self_attn.vision_{n}_proj.weight_B"] = rn(H, r, std=r ** -0.5)
+    for kv in ("k", "v"):
+        for w in ("language", "vision"):
+            sd[p + f"self_attn.vision_{kv}_bridge_on_{w}.weight_A"] = rn(8, H, std=H ** -0.5)
+            sd[p + f"self_attn.vision_{kv}_bridge_on_{w}.weight_B"] = rn(H, 8, std=0.3)
+    sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = rn(I, H, std=H ** -0.5), rn(I, H, std=H ** -0.5)
+    sd[p + "mlp.down_proj.weight"] = rn(H, I, std=I ** -0.5)
+    for n in ("gate", "up"):
+        sd[p + f"mlp.vision_{n}_proj.weight_A"], sd[p + f"mlp.vision_{n}_proj.weight_B"] = rn(rg, H, std=H ** -0.5), rn(I, rg, std=rg ** -0.5)
+    sd[p + "mlp.vision_down_proj.weight_A"], sd[p + "mlp.vision_down_proj.weight_B"] = rn(r, I, std=I ** -0.5), rn(H, r, std=r ** -0.5)
+    for n in ("input_layernorm", "post_attention_layernorm", "vision_input_layernorm", "vision_post_attention_layernorm"):
+        sd[p + n + ".weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(BF)
+    sd["model.embed_tokens.weight"] = rn(8, H, std=1.0)
+    x = rn(B, S, H, std=1.0)
+    vi = torch.full((B, S), L, dtype=torch.long)
+    vi[0, 3:3 + L] = torch.arange(L); vi[1, 100:100 + L] = torch.arange(L)
+    am = torch.ones(B, S, dtype=torch.long); am[1, 200:] = 0
+    d = DE.DecDims(hidden=H, inter=I, layers=1, heads=heads, vocab=32000, vision_vocab=514, codebooks=2, max_vision_len=L,
+                   signal=2048)
+    dsd = {k: v.cuda() for k, v in sd.items()}
+    pk = DE.pack(dsd, d)
+    flag, li, vidx, lens = DE.route(vi.cuda(), am.cuda(), d)
+    cos, sin = DE.rope_tables(128, 2048, "cuda")
+    y = DE.layer_forward(dsd, pk[0], 0, d, x.view(B * S, H).cuda(), flag, li, vidx, lens, cos, sin, B, S).view(B, S, H)
+    f = vi < L
+    cosr, sinr = LO.rope_tables(128, 2048)
+    pos = torch.arange(S).unsqueeze(0).expand(B, S)
+    sdf = {k: v.float() for k, v in sd.items()}
+    ref = LO.decoder_layer(sdf, 0, x.float(), f, LO.additive_mask(am, S, torch.float32), pos, heads, 1e-6, cosr, sinr)
+    refb = LO.decoder_layer(sd, 0, x, f, LO.additive_mask(am, S, BF), pos, heads, 1e-6, cosr.to(BF), sinr.to(BF))
+    valid = am.bool()
+    ours, theirs = rel_err(y.float().cpu()[valid], ref[valid]), rel_err(refb.float()[valid], ref[valid])
+    print(f"full-width layer: ours {ours:.3e}, reference-style bf16 {theirs:.3e}")
+    assert ours < max(1.5 * theirs, 3e-3), (ours, theirs)
