@@ -144,6 +144,34 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
     return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True)
 
 
+class _SideStream:
+    """Weight / bias gradients are off the critical path (nothing in the backward consumes them), so they are
+    enqueued on a second HIP stream: their workgroups fill the CUs that the tail wave of the dgrad GEMMs, the
+    attention kernels and the row kernels leave idle.  Ordering is by events; operands are pinned against the
+    caching allocator with record_stream."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = torch.cuda.Stream(device=device)
+        self.enabled = True
+
+    def run(self, fn, *operands):
+        if not self.enabled:
+            return fn()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in operands:
+            t.record_stream(self.side)
+        return out
+
+    def join(self, *outs):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t in outs:
+                t.record_stream(self.main)
+
+
 def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
              *, need_pixel_grad: bool = True):
     """Given d(loss)/d(hidden_states[i]) (None = zero) return (d_pixel or None, {param name: bf16 grad}).
@@ -176,27 +204,34 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
         if name is not None:
             small.append((name, o, n))
         return arena[o:o + n]
+    side = _SideStream(dev)
+
+    def param_grads(wname, bname, dy, x, nb):
+        bslice = f32(nb, bname)
+
+        def work():
+            g = _wgrad(dy, x, m_pad)
+            K.colsum(dy, bslice)
+            return g
+        grads[wname] = side.run(work, dy, x)
+
     for i in range(min(top, L) - 1, -1, -1):
         pre = f"{P}encoder.layers.{i}."
         s = saved["layers"][i]
         # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
-        grads[pre + "mlp.fc2.weight"] = _wgrad(dx, s["act"], m_pad)
-        K.colsum(dx, f32(D, pre + "mlp.fc2.bias"))
+        param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dx, s["act"], D)
         dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dev_rows(I))
-        grads[pre + "mlp.fc1.weight"] = _wgrad(dh, s["xn2"], m_pad)
-        K.colsum(dh, f32(I, pre + "mlp.fc1.bias"))
+        param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dh, s["xn2"], I)
         dxn2 = K.gemm_nt(dh, params[pre + "mlp.fc1.weight"], b_t=True)                       # [M, D]
         dg2, dbt2 = f32(D, pre + "layer_norm2.weight"), f32(D, pre + "layer_norm2.bias")
         dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
                                  dgamma=dg2, dbeta=dbt2, out=dev_rows(D))
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
-        grads[pre + "self_attn.out_proj.weight"] = _wgrad(dx_mid, s["o"], m_pad)
-        K.colsum(dx_mid, f32(D, pre + "self_attn.out_proj.bias"))
+        param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D)
         do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
         dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, dims.t_pad, scale, out_dqkv=dev_rows(3 * D))
-        dwqkv = _wgrad(dqkv, s["xn1"], m_pad)                                                  # [3D, D]
-        dbq = f32(3 * D)
-        K.colsum(dqkv, dbq)
+        param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D)                   # [3D, D]
+        dwqkv = grads.pop(pre + "self_attn.qkv_packed")
         o0 = cursor[0] - 3 * D
         for j, n in enumerate("qkv"):
             grads[pre + f"self_attn.{n}_proj.weight"] = dwqkv[j * D:(j + 1) * D]
@@ -211,6 +246,7 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
     dg0, db0 = f32(D, P + "pre_layrnorm.weight"), f32(D, P + "pre_layrnorm.bias")
     demb = K.layernorm_bwd(dx, saved["emb"], params[P + "pre_layrnorm.weight"], saved["mean0"], saved["rstd0"],
                            dgamma=dg0, dbeta=db0)
+    side.join(*[g for g in grads.values() if g.ndim == 2])
     small_bf16 = K.f32_to_bf16(arena)
     for name, o, n in small:
         grads[name] = small_bf16[o:o + n]
