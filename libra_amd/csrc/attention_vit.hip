@@ -27,8 +27,7 @@ constexpr int HD = 64;            // head dim
 constexpr int QB = 128;           // query rows per workgroup
 constexpr int KB = 64;            // keys per tile
 constexpr int KV_TILE_BYTES = KB * HD * 2;   // 8 KiB
-constexpr int ATT_STAGES = 4;                 // LDS ring: up to 3 K/V tiles in flight, counted vmcnt (never drains)
-constexpr int ATT_LDS = ATT_STAGES * 2 * KV_TILE_BYTES;   // 64 KiB
+constexpr int ATT_LDS = 4 * KV_TILE_BYTES;   // K0 V0 K1 V1 = 32 KiB
 
 struct AttnFwdArgs {
     const bf16_t* qkv; long ld_qkv;
@@ -95,24 +94,18 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (T + KB - 1) / KB;
-    auto stage = [&](int t) {
-        char* nb = smem + (t % ATT_STAGES) * 2 * KV_TILE_BYTES;
-        stage_rows64(kbase, p.ld_qkv, t * KB, T, nb, wave, lane);
-        stage_rows64(vbase + t * KB, p.ld_vt, 0, HD, nb + KV_TILE_BYTES, wave, lane);
-    };
-    // prologue: tiles 0..2 in flight (4 direct-to-LDS ops per wave per tile)
-    stage(0);
-    if (nkt > 1) stage(1);
-    if (nkt > 2) stage(2);
+    stage_rows64(kbase, p.ld_qkv, 0, T, smem, wave, lane);
+    stage_rows64(vbase, p.ld_vt, 0, HD, smem + KV_TILE_BYTES, wave, lane);
 
     for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt must have landed; tiles kt+1, kt+2 stay in flight across the barrier (counted wait)
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // everyone has tile kt and is done with tile kt-1 (ring slot of tile kt+3)
-        if (kt + 3 < nkt) stage(kt + 3);
-        const int cur = kt % ATT_STAGES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) {
+            char* nb = smem + (cur ^ 1) * 2 * KV_TILE_BYTES;
+            stage_rows64(kbase, p.ld_qkv, (kt + 1) * KB, T, nb, wave, lane);
+            stage_rows64(vbase + (kt + 1) * KB, p.ld_vt, 0, HD, nb + KV_TILE_BYTES, wave, lane);
+        }
         if (!active) continue;
         const char* sk = smem + cur * 2 * KV_TILE_BYTES;
         const char* sv = sk + KV_TILE_BYTES;
@@ -243,11 +236,6 @@ extern "C" int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, const void* v
     a.sl2 = scale * 1.4426950408889634f;
     const long nblk = (long)B * H * a.n_qt;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)vit_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3((unsigned)nblk), dim3(256), ATT_LDS, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
