@@ -176,6 +176,15 @@ int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_
                           const uint8_t* flag,
                           const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
                           int64_t H, float scale, void* stream);
+/* Backward of libra_bridge_attn_fwd (deterministic, two passes): from dO and the forward's operands / lse produce
+ * dq [B*S,H*128] (w.r.t. the rotated q) and the four operand gradients dK_same, dK_cross, dV_same, dV_cross
+ * ([B*S, H*128], row stride ldg).  `out` is the forward output (for D = rowsum(dO*O)); delta [B,H,S] is scratch.  */
+int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
+                          int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
+                          const void* out, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
+                          const int32_t* kv_len, const float* lse, float* delta, void* dq, int64_t lddq,
+                          void* dk_same, void* dk_cross, void* dv_same, void* dv_cross, int64_t ldg, int64_t B,
+                          int64_t S, int64_t H, float scale, void* stream);
 /* y = bf16(silu(gate)) * up  (LlamaMLP, models/llama/modeling_llama.py:199-201)                          */
 int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows, int64_t I,
                  void* stream);

@@ -444,3 +444,22 @@ def ce_rows(logits, target, target_sub: int = 0):
                                   rows, _stream())
     _lib.check(rc, "ce_rows")
     return loss
+
+
+def bridge_attn_bwd(q, k_same, k_cross, v_same, v_cross, out, dout, flag, kv_len, lse, B: int, S: int, H: int, scale: float):
+    """-> dq, dk_same, dk_cross, dv_same, dv_cross  (each [B*S, H*128] bf16)."""
+    for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross"), (out, "out"),
+                 (dout, "dout")):
+        _chk2d(t, n)
+    dev = q.device
+    N, HD = B * S, H * 128
+    g = [torch.empty((N, HD), dtype=BF16, device=dev) for _ in range(5)]
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    rc = _lib.lib().libra_bridge_attn_bwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_same.stride(0), k_cross.data_ptr(),
+                                          k_cross.stride(0), v_same.data_ptr(), v_same.stride(0), v_cross.data_ptr(),
+                                          v_cross.stride(0), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0),
+                                          flag.data_ptr(), _ptr(kv_len), lse.data_ptr(), delta.data_ptr(), g[0].data_ptr(),
+                                          g[0].stride(0), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(),
+                                          HD, B, S, H, float(scale), _stream())
+    _lib.check(rc, "bridge_attn_bwd")
+    return tuple(g)

@@ -101,6 +101,36 @@ def test_bridge_attention_fwd(K, B, S, H, mode):
     assert torch.isfinite(o.float()).all()
 
 
+@pytest.mark.parametrize("B,S,H,mode", [(1, 16, 1, "span"), (2, 33, 2, "random"), (1, 128, 1, "none"), (2, 200, 2, "span"),
+                                        (1, 320, 1, "random"), (2, 512, 2, "span")])
+def test_bridge_attention_bwd(K, B, S, H, mode):
+    N, D = B * S, H * 128
+    q, ks, kc, vs, vc = [rnd(N, D, seed=20 + i) for i in range(5)]
+    do = rnd(N, D, seed=30)
+    flag = _flags(N, 8, mode)
+    lens = torch.full((B,), S, dtype=torch.int32)
+    if B > 1:
+        lens[1] = max(1, S - S // 4)
+    sc = 128 ** -0.5
+    o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag.cuda(), lens.cuda(), B, S, H, sc, need_lse=True)
+    grads = K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag.cuda(), lens.cuda(), lse, B, S, H, sc)
+    ins = [t.float().cpu().requires_grad_(True) for t in (q, ks, kc, vs, vc)]
+    ro, _ = _attn_ref(*ins, flag, lens.long(), B, S, H, sc)
+    valid = (torch.arange(S)[None, :] < lens[:, None].long()).reshape(N)
+    # gradients only flow from valid query rows (the reference's padded rows carry label -100)
+    (ro * (do.float().cpu() * valid[:, None])).sum().backward()
+    # NOTE: our kernel also propagates dO of padded QUERY rows; zero them for an apples-to-apples comparison
+    do2 = (do.float() * valid.cuda()[:, None]).to(BF)
+    grads = K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do2, flag.cuda(), lens.cuda(), lse, B, S, H, sc)
+    for g, r, n in zip(grads, ins, ("dq", "dk_same", "dk_cross", "dv_same", "dv_cross")):
+        ref = r.grad
+        if n == "dq":
+            close(g.cpu()[valid], ref[valid], rel=6e-3, what=n)
+        else:
+            close(g, ref, rel=6e-3, what=n)
+        assert torch.isfinite(g.float()).all(), n
+
+
 def test_rope_bridge(K):
     from oracle import libra_oracle as LO
     B, S, H = 2, 24, 2
