@@ -201,6 +201,30 @@ int libra_copy_rows(const void* in, int64_t ldi, int64_t D, const int32_t* rows_
 int libra_ce_rows(const void* logits, int64_t ldz, int64_t V, const int64_t* target, int64_t target_sub,
                   float* loss_rows, int64_t rows, void* stream);
 
+/* ---- decoder backward row kernels ------------------------------------------------------------------*/
+/* dlogits[r,v] = sum_q [t_q[r]>=0] coef_q (softmax(z_r)[v] - [v == t_q[r]-target_sub]); target1 may be NULL.   */
+int libra_ce_rows_bwd(const void* logits, int64_t ldz, int64_t V, const int64_t* target0, const int64_t* target1,
+                      int64_t target_sub, float coef0, float coef1, void* dlogits, int64_t lddz, int64_t rows,
+                      void* stream);
+/* routed RMSNorm backward: dx = rstd (g - xh mean(g xh)) [+ dres], g = dy w_m, xh = x rstd (rstd from the forward) */
+int libra_rmsnorm_routed_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* w_lang,
+                             const void* w_vis, const uint8_t* flag, const float* rstd, const void* dres, int64_t lddr,
+                             void* dx, int64_t lddx, int64_t rows, int64_t D, void* stream);
+/* dw_m[c] += sum_{rows of modality m} dy x rstd  (fp32 [D], deterministic two-stage; dw_vis NULL when unrouted) */
+size_t libra_rmsnorm_wgrad_workspace_bytes(int64_t rows, int64_t D);
+int libra_rmsnorm_routed_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* rstd,
+                               const uint8_t* flag, float* dw_lang, float* dw_vis, void* workspace,
+                               size_t workspace_bytes, int64_t rows, int64_t D, void* stream);
+/* SwiGLU backward: dgate = dy up s (1 + gate (1 - s)), dup = dy silu(gate)                                   */
+int libra_swiglu_bwd(const void* dy, int64_t lddy, const void* gate, const void* up, int64_t ldgu, void* dgate,
+                     void* dup, int64_t ldd, int64_t rows, int64_t I, void* stream);
+/* backward of libra_rope_bridge: dqkv [N,3*H*128] = (R^T dq', R^T (dK_same + dK_cross), dV_same + dV_cross),
+ * dkb [N,H*128] = R^T dK_cross  (dvb = dV_cross itself)                                                      */
+int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const void* dk_cross, const void* dv_same,
+                          const void* dv_cross, int64_t ld, const void* cos, const void* sin, int64_t max_pos,
+                          void* dqkv, int64_t ldo, void* dkb, int64_t ldb, int64_t N, int64_t S, int64_t H,
+                          void* stream);
+
 /* ---- small elementwise helpers -------------------------------------------------------------------*/
 /* out_bf16[i] = bf16(in_f32[i])  (parameter-gradient accumulators -> bf16 .grad) */
 int libra_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);

@@ -49,6 +49,12 @@ SIGNATURES = {
     "libra_gather_rows": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _P],
     "libra_copy_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P],
     "libra_ce_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _P],
+    "libra_ce_rows_bwd": [_P, _I64, _I64, _P, _P, _I64, _F, _F, _P, _I64, _I64, _P],
+    "libra_rmsnorm_routed_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_rmsnorm_wgrad_workspace_bytes": [_I64, _I64],
+    "libra_rmsnorm_routed_wgrad": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
+    "libra_swiglu_bwd": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P],
+    "libra_rope_bridge_bwd": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
 }

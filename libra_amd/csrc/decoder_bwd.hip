@@ -1,0 +1,310 @@
+// Backward row kernels of the routed decoder (HBM-bound): CE gradient, routed RMSNorm backward (dx and the
+// per-modality weight gradients), SwiGLU backward, RoPE/bridge backward.
+#include "hip_common.hpp"
+#include "../../include/libra_hip.h"
+
+namespace libra {
+
+// ---------------------------------------------------------------------------------------------------
+// dz[r, v] = sum_q [t_q[r] >= 0] * coef_q * (softmax(z_r)[v] - [v == t_q[r] - sub])     (CrossEntropyLoss, mean reduction,
+// averaged over the codebooks: coef_q = 1 / (count_q * Q)); one wave per row, three passes over the row.
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const bf16_t* __restrict__ z, long ldz, int V,
+                                                          const long long* __restrict__ t0, const long long* __restrict__ t1,
+                                                          long long sub, float c0, float c1, bf16_t* __restrict__ dz, long lddz,
+                                                          long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long a0 = t0 ? t0[row] : -1, a1 = t1 ? t1[row] : -1;
+    const float w0 = a0 >= 0 ? c0 : 0.f, w1 = a1 >= 0 ? c1 : 0.f;
+    const float wsum = w0 + w1;
+    const bf16_t* zr = z + row * ldz;
+    bf16_t* dr = dz + row * lddz;
+    float mx = -INFINITY, se = 0.f;
+    if (wsum != 0.f) {
+        for (int c = lane; c < V; c += 64) mx = fmaxf(mx, bf2f(zr[c]));
+        mx = wave_max(mx);
+        for (int c = lane; c < V; c += 64) se += __expf(bf2f(zr[c]) - mx);
+        se = wave_sum(se);
+    }
+    const float inv = wsum != 0.f ? 1.0f / se : 0.f;
+    const long long i0 = a0 - sub, i1 = a1 - sub;
+    for (int c = lane; c < V; c += 64) {
+        float g = 0.f;
+        if (wsum != 0.f) {
+            g = wsum * __expf(bf2f(zr[c]) - mx) * inv;
+            if (a0 >= 0 && c == i0) g -= w0;
+            if (a1 >= 0 && c == i1) g -= w1;
+        }
+        dr[c] = f2bf(g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Routed RMSNorm backward, dx part:  y = w_m * (x * rstd)  =>  dx = rstd * (g - xh * mean(g * xh)),  g = dy * w_m, xh = x * rstd
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_routed_bwd_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+                                                                 long ldx, const bf16_t* __restrict__ w_lang,
+                                                                 const bf16_t* __restrict__ w_vis,
+                                                                 const unsigned char* __restrict__ flag,
+                                                                 const float* __restrict__ rstd_i, const bf16_t* __restrict__ dres,
+                                                                 long lddr, bf16_t* __restrict__ dx, long lddx, long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 3;
+    const bf16_t* w = (flag && flag[row]) ? w_vis : w_lang;
+    const float rstd = rstd_i[row];
+    float g[NC][8], xh[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float a[8], b[8], ww[8];
+            unpack8(*(const u32x4*)(dy + row * lddy + c * 8), a);
+            unpack8(*(const u32x4*)(x + row * ldx + c * 8), b);
+            unpack8(*(const u32x4*)(w + c * 8), ww);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g[i][e] = a[e] * ww[e]; xh[i][e] = b[e] * rstd; s += g[i][e] * xh[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
+        }
+    }
+    s = wave_sum(s) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - xh[i][e] * s);
+            if (dres) {
+                float r[8];
+                unpack8(*(const u32x4*)(dres + row * lddr + c * 8), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += r[e];
+            }
+            *(u32x4*)(dx + row * lddx + c * 8) = pack8(o);
+        }
+    }
+}
+
+// weight-gradient part: dw_m[c] = sum_{rows of modality m} dy[r,c] * x[r,c] * rstd[r]; thread = 8 columns, strips of rows,
+// partial [strip][2][D] fp32 then a deterministic second stage.
+constexpr int RW_STRIPS = 256;
+__global__ __launch_bounds__(256) void rmsnorm_wgrad_partial_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+                                                                    long ldx, const float* __restrict__ rstd,
+                                                                    const unsigned char* __restrict__ flag, long rows, int D,
+                                                                    float* __restrict__ part) {
+    const int c8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c8 >= D) return;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+    float sl[8], sv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sl[e] = 0.f; sv[e] = 0.f; }
+    for (long r = r0; r < r1; ++r) {
+        float a[8], b[8];
+        unpack8(*(const u32x4*)(dy + r * lddy + c8), a);
+        unpack8(*(const u32x4*)(x + r * ldx + c8), b);
+        const float rs = rstd[r];
+        const bool vis = flag && flag[r];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = a[e] * b[e] * rs;
+            sl[e] += vis ? 0.f : t;
+            sv[e] += vis ? t : 0.f;
+        }
+    }
+    float* d0 = part + ((long)blockIdx.y * 2) * D + c8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { d0[e] = sl[e]; d0[D + e] = sv[e]; }
+}
+__global__ __launch_bounds__(1024) void rmsnorm_wgrad_final_kernel(const float* __restrict__ part, int strips, int D,
+                                                                   float* __restrict__ out_l, float* __restrict__ out_v) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int which = blockIdx.y;
+    const int col = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (col < D)
+        for (int p = g; p < strips; p += 32) s += part[((long)p * 2 + which) * D + col];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && col < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][c];
+        float* o = which ? out_v : out_l;
+        if (o) o[col] += t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SwiGLU backward: y = silu(g) * u  =>  dg = dy * u * s * (1 + g (1 - s)),  du = dy * silu(g),  s = sigmoid(g)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ g,
+                                                         const bf16_t* __restrict__ u, long ldgu, bf16_t* __restrict__ dg,
+                                                         bf16_t* __restrict__ du, long ldd, long rows, int I) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i8 = I >> 3;
+    if (i >= rows * i8) return;
+    const long r = i / i8;
+    const int c = (int)(i - r * i8) * 8;
+    float a[8], b[8], d[8], og[8], ou[8];
+    unpack8(*(const u32x4*)(g + r * ldgu + c), a);
+    unpack8(*(const u32x4*)(u + r * ldgu + c), b);
+    unpack8(*(const u32x4*)(dy + r * lddy + c), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float s = 1.0f / (1.0f + __expf(-a[e]));
+        og[e] = d[e] * b[e] * s * (1.0f + a[e] * (1.0f - s));
+        ou[e] = d[e] * a[e] * s;
+    }
+    *(u32x4*)(dg + r * ldd + c) = pack8(og);
+    *(u32x4*)(du + r * ldd + c) = pack8(ou);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE / bridge backward.  Forward:  q' = R q,  K_same = R k,  K_cross = R (k + kb),  V_cross = v + vb  (R = rotation by
+// position).  So  dq = R^T dq',  dk = R^T (dK_same + dK_cross),  dkb = R^T dK_cross,  dv = dV_same + dV_cross,  dvb = dV_cross.
+// R^T: (y1, y2) at (d, d+64) with c, s:  x1 = y1 c + y2 s,  x2 = y2 c - y1 s.
+struct RopeBwdArgs {
+    const bf16_t* dq; const bf16_t* dks; const bf16_t* dkc; const bf16_t* dvs; const bf16_t* dvc; long ld;   // [N, H*128]
+    const bf16_t* cos; const bf16_t* sin;
+    bf16_t* dqkv; long ldo;      // [N, 3*H*128]
+    bf16_t* dkb; long ldb;       // [N, H*128]
+    long N; int S, H;
+};
+__global__ __launch_bounds__(256) void rope_bridge_bwd_kernel(const RopeBwdArgs p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = p.N * p.H * 8;
+    if (i >= total) return;
+    const int c = (int)(i & 7);
+    const long th = i >> 3;
+    const int h = (int)(th % p.H);
+    const long n = th / p.H;
+    const int s = (int)(n % p.S);
+    const int HD = p.H * 128;
+    const long col0 = (long)h * 128 + c * 8, col1 = col0 + 64;
+    float cs[8], sn[8];
+    unpack8(*(const u32x4*)(p.cos + (long)s * 128 + c * 8), cs);
+    unpack8(*(const u32x4*)(p.sin + (long)s * 128 + c * 8), sn);
+    auto ld2 = [&](const bf16_t* t, float* a, float* b) {
+        unpack8(*(const u32x4*)(t + n * p.ld + col0), a);
+        unpack8(*(const u32x4*)(t + n * p.ld + col1), b);
+    };
+    float q1[8], q2[8], ks1[8], ks2[8], kc1[8], kc2[8], vs1[8], vs2[8], vc1[8], vc2[8];
+    ld2(p.dq, q1, q2); ld2(p.dks, ks1, ks2); ld2(p.dkc, kc1, kc2); ld2(p.dvs, vs1, vs2); ld2(p.dvc, vc1, vc2);
+    float oq1[8], oq2[8], ok1[8], ok2[8], ob1[8], ob2[8], ov1[8], ov2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        oq1[e] = q1[e] * cs[e] + q2[e] * sn[e];
+        oq2[e] = q2[e] * cs[e] - q1[e] * sn[e];
+        ob1[e] = kc1[e] * cs[e] + kc2[e] * sn[e];
+        ob2[e] = kc2[e] * cs[e] - kc1[e] * sn[e];
+        const float t1 = ks1[e] + kc1[e], t2 = ks2[e] + kc2[e];
+        ok1[e] = t1 * cs[e] + t2 * sn[e];
+        ok2[e] = t2 * cs[e] - t1 * sn[e];
+        ov1[e] = vs1[e] + vc1[e];
+        ov2[e] = vs2[e] + vc2[e];
+    }
+    *(u32x4*)(p.dqkv + n * p.ldo + col0) = pack8(oq1);
+    *(u32x4*)(p.dqkv + n * p.ldo + col1) = pack8(oq2);
+    *(u32x4*)(p.dqkv + n * p.ldo + HD + col0) = pack8(ok1);
+    *(u32x4*)(p.dqkv + n * p.ldo + HD + col1) = pack8(ok2);
+    *(u32x4*)(p.dqkv + n * p.ldo + 2 * HD + col0) = pack8(ov1);
+    *(u32x4*)(p.dqkv + n * p.ldo + 2 * HD + col1) = pack8(ov2);
+    *(u32x4*)(p.dkb + n * p.ldb + col0) = pack8(ob1);
+    *(u32x4*)(p.dkb + n * p.ldb + col1) = pack8(ob2);
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH; }
+
+}  // namespace libra
+
+using namespace libra;
+
+extern "C" int libra_ce_rows_bwd(const void* logits, int64_t ldz, int64_t V, const int64_t* target0, const int64_t* target1,
+                                 int64_t target_sub, float coef0, float coef1, void* dlogits, int64_t lddz, int64_t rows,
+                                 void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (V <= 0 || ldz < V || lddz < V) return LIBRA_ERR_SHAPE;
+    if (!logits || !dlogits || (!target0 && !target1)) return LIBRA_ERR_ALIGN;
+    hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)logits, (long)ldz, (int)V, (const long long*)target0, (const long long*)target1,
+                       (long long)target_sub, coef0, coef1, (bf16_t*)dlogits, (long)lddz, (long)rows);
+    return launched();
+}
+
+extern "C" int libra_rmsnorm_routed_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* w_lang,
+                                        const void* w_vis, const uint8_t* flag, const float* rstd, const void* dres,
+                                        int64_t lddr, void* dx, int64_t lddx, int64_t rows, int64_t D, void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (D <= 0 || (D % 8) || D > 8192 || lddy < D || ldx < D || lddx < D || (lddy % 8) || (ldx % 8) || (lddx % 8)) return LIBRA_ERR_SHAPE;
+    if (!dy || !x || !w_lang || !rstd || !dx || (flag && !w_vis) || (dres && (lddr % 8))) return LIBRA_ERR_ALIGN;
+    if (!al16(dy) || !al16(x) || !al16(w_lang) || !al16(dx) || (w_vis && !al16(w_vis)) || (dres && !al16(dres))) return LIBRA_ERR_ALIGN;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const int nc = (int)((D / 8 + 63) / 64);
+#define LAUNCH_RB(NC)                                                                                                \
+    hipLaunchKernelGGL((rmsnorm_routed_bwd_kernel<NC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, \
+                       (long)lddy, (const bf16_t*)x, (long)ldx, (const bf16_t*)w_lang, (const bf16_t*)w_vis, flag, rstd,  \
+                       (const bf16_t*)dres, (long)lddr, (bf16_t*)dx, (long)lddx, (long)rows, (int)D)
+    if (nc <= 1) LAUNCH_RB(1); else if (nc <= 2) LAUNCH_RB(2); else if (nc <= 4) LAUNCH_RB(4);
+    else if (nc <= 8) LAUNCH_RB(8); else LAUNCH_RB(16);
+#undef LAUNCH_RB
+    return launched();
+}
+
+extern "C" size_t libra_rmsnorm_wgrad_workspace_bytes(int64_t rows, int64_t D) {
+    return (rows > 0 && D > 0) ? (size_t)RW_STRIPS * 2 * D * sizeof(float) : 0;
+}
+
+extern "C" int libra_rmsnorm_routed_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* rstd,
+                                          const uint8_t* flag, float* dw_lang, float* dw_vis, void* workspace,
+                                          size_t workspace_bytes, int64_t rows, int64_t D, void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (D <= 0 || (D % 8) || lddy < D || ldx < D || (lddy % 8) || (ldx % 8)) return LIBRA_ERR_SHAPE;
+    if (!dy || !x || !rstd || !workspace || !al16(dy) || !al16(x) || !al16(workspace)) return LIBRA_ERR_ALIGN;
+    if (workspace_bytes < libra_rmsnorm_wgrad_workspace_bytes(rows, D)) return LIBRA_ERR_ALIGN;
+    const int strips = (int)(rows < RW_STRIPS ? rows : RW_STRIPS);
+    dim3 grid((unsigned)((D + 2047) / 2048), (unsigned)strips);
+    hipLaunchKernelGGL(rmsnorm_wgrad_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)lddy,
+                       (const bf16_t*)x, (long)ldx, rstd, flag, (long)rows, (int)D, (float*)workspace);
+    if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
+    hipLaunchKernelGGL(rmsnorm_wgrad_final_kernel, dim3((unsigned)((D + 31) / 32), 2), dim3(1024), 0, (hipStream_t)stream,
+                       (const float*)workspace, strips, (int)D, dw_lang, dw_vis);
+    return launched();
+}
+
+extern "C" int libra_swiglu_bwd(const void* dy, int64_t lddy, const void* gate, const void* up, int64_t ldgu, void* dgate,
+                                void* dup, int64_t ldd, int64_t rows, int64_t I, void* stream) {
+    if (rows <= 0) return LIBRA_OK;
+    if (I <= 0 || (I % 8) || lddy < I || ldgu < I || ldd < I || (lddy % 8) || (ldgu % 8) || (ldd % 8)) return LIBRA_ERR_SHAPE;
+    if (!dy || !gate || !up || !dgate || !dup || !al16(dy) || !al16(gate) || !al16(up) || !al16(dgate) || !al16(dup)) return LIBRA_ERR_ALIGN;
+    const long total = rows * (I / 8);
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, (long)lddy, (const bf16_t*)gate, (const bf16_t*)up, (long)ldgu, (bf16_t*)dgate,
+                       (bf16_t*)dup, (long)ldd, (long)rows, (int)I);
+    return launched();
+}
+
+extern "C" int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const void* dk_cross, const void* dv_same,
+                                     const void* dv_cross, int64_t ld, const void* cos, const void* sin, int64_t max_pos,
+                                     void* dqkv, int64_t ldo, void* dkb, int64_t ldb, int64_t N, int64_t S, int64_t H,
+                                     void* stream) {
+    if (N <= 0) return LIBRA_OK;
+    if (H <= 0 || S <= 0 || S > max_pos || ld < H * 128 || ldo < 3 * H * 128 || ldb < H * 128) return LIBRA_ERR_SHAPE;
+    if ((ld % 8) || (ldo % 8) || (ldb % 8)) return LIBRA_ERR_ALIGN;
+    if (!dq || !dk_same || !dk_cross || !dv_same || !dv_cross || !cos || !sin || !dqkv || !dkb) return LIBRA_ERR_ALIGN;
+    if (!al16(dq) || !al16(dk_same) || !al16(dk_cross) || !al16(dv_same) || !al16(dv_cross) || !al16(dqkv) || !al16(dkb)) return LIBRA_ERR_ALIGN;
+    RopeBwdArgs a;
+    a.dq = (const bf16_t*)dq; a.dks = (const bf16_t*)dk_same; a.dkc = (const bf16_t*)dk_cross; a.dvs = (const bf16_t*)dv_same;
+    a.dvc = (const bf16_t*)dv_cross; a.ld = ld; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
+    a.dqkv = (bf16_t*)dqkv; a.ldo = ldo; a.dkb = (bf16_t*)dkb; a.ldb = ldb; a.N = N; a.S = (int)S; a.H = (int)H;
+    const long total = N * H * 8;
+    hipLaunchKernelGGL(rope_bridge_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return launched();
+}

@@ -6,7 +6,7 @@ are index lists (``lang_idx``, ``vis_idx``) that the GEMM uses to gather its A r
 host sync in the reference: modeling_libra.py:111-147) costs ONE nonzero() per batch.
 
 Rounding points follow the reference's bf16 execution (every Linear output, norm, RoPE term is bf16);
-accumulation is fp32 in the MFMA.  Reference lines: see oracle/libra_oracle.py (same structure).
+accumulation is fp32 in the MFMA.  Reference file:line citations: include/libra_hip.h and DESIGN.md.
 """
 from __future__ import annotations
 
@@ -102,7 +102,7 @@ def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims
     return flag.to(torch.uint8).contiguous(), lang_idx.contiguous(), vis_idx.contiguous(), lens.contiguous()
 
 
-def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal):
+def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None):
     """get_inputs_embeds_from_multicodebook (modeling_libra.py:625-661) -> x [N, H]."""
     Q, B, S = input_ids.shape
     N, H = B * S, d.hidden
@@ -124,75 +124,96 @@ def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal):
             K.copy_rows(signal.reshape(N, Cs).to(BF16), vis_idx, n_v, ve, H)
         else:
             ve[:, H:].zero_()
-        ven = K.rmsnorm_routed(ve, sd["model.vision_signal_norm.weight"], None, None, d.eps)
+        ven = _rows(n_v, H + Cs, dev, sv is not None)
+        _, rstd_e = K.rmsnorm_routed(ve, sd["model.vision_signal_norm.weight"], None, None, d.eps, out=ven, save_rstd=True)
         K.gemm_nt(ven, sd["model.vision_contiguous_signal_processor.weight"], out=x, c_rows=vis_idx)
+        if sv is not None:
+            sv.update(ve=ve, ven=ven, rstd_e=rstd_e)
     return x
 
 
-def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int):
+def _rows(n: int, c: int, dev, save: bool):
+    """Compact per-modality buffer; when it will later be a reduction-major wgrad operand it needs zeroed pad rows."""
+    return K.alloc_rows(n, c, dev)[:n] if save else torch.empty((n, c), dtype=BF16, device=dev)
+
+
+def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None):
+    """One LibraDecoderLayer (modeling_libra.py:437-491).  `sv` (dict) collects what the backward needs."""
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S
     dev = x.device
+    save = sv is not None
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     pre = f"model.layers.{i}."
     a, m = pre + "self_attn.", pre + "mlp."
     # ---- attention block
-    h = K.rmsnorm_routed(x, sd[pre + "input_layernorm.weight"], sd[pre + "vision_input_layernorm.weight"], flag, d.eps)
+    h, rstd1 = K.rmsnorm_routed(x, sd[pre + "input_layernorm.weight"], sd[pre + "vision_input_layernorm.weight"], flag, d.eps,
+                                save_rstd=True)
     qkv = torch.empty((N, 3 * H), dtype=BF16, device=dev)
     tb = torch.empty((N, 64), dtype=BF16, device=dev)
+    t = None
     if n_l:
         K.gemm_nt(h, pk["wqkv"], out=qkv, a_rows=lang_idx, c_rows=lang_idx)
         K.gemm_nt(h, pk["ab_l"], out=tb, a_rows=lang_idx, c_rows=lang_idx)
     if n_v:
-        t = K.gemm_nt(h, pk["aqkv"], a_rows=vis_idx)                                   # [n_v, 3r]
+        t = K.gemm_nt(h, pk["aqkv"], a_rows=vis_idx, out=_rows(n_v, 3 * r, dev, save))                  # [n_v, 3r]
         for j, nm in enumerate(("q", "k", "v")):
             K.gemm_nt(t[:, j * r:(j + 1) * r], sd[a + f"vision_{nm}_proj.weight_B"], out=qkv[:, j * H:(j + 1) * H],
                       c_rows=vis_idx)
         K.gemm_nt(h, pk["ab_v"], out=tb, a_rows=vis_idx, c_rows=vis_idx)
     kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
-    o, _ = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
-                             (H // d.heads) ** -0.5)
+    o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
+                               (H // d.heads) ** -0.5, need_lse=save)
     x_mid = torch.empty_like(x)
+    to = None
     if n_l:
         K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x)
     if n_v:
-        t = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx)
-        K.gemm_nt(t, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x)
+        to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save))
+        K.gemm_nt(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x)
     # ---- MLP block
-    h2 = K.rmsnorm_routed(x_mid, sd[pre + "post_attention_layernorm.weight"],
-                          sd[pre + "vision_post_attention_layernorm.weight"], flag, d.eps)
+    h2, rstd2 = K.rmsnorm_routed(x_mid, sd[pre + "post_attention_layernorm.weight"],
+                                 sd[pre + "vision_post_attention_layernorm.weight"], flag, d.eps, save_rstd=True)
     x_out = torch.empty_like(x)
+    gu = act = tg = guv = actv = td = None
     if n_l:
         gu = K.gemm_nt(h2, pk["wgu"], a_rows=lang_idx)                                 # [n_l, 2I]
-        act = K.swiglu(gu[:, :I], gu[:, I:])
+        act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save))
         K.gemm_nt(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid)
     if n_v:
-        tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx)                                  # [n_v, 2 rg]
+        tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save))               # [n_v, 2 rg]
         guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
         K.gemm_nt(tg[:, :rg], sd[m + "vision_gate_proj.weight_B"], out=guv[:, :I])
         K.gemm_nt(tg[:, rg:], sd[m + "vision_up_proj.weight_B"], out=guv[:, I:])
-        actv = K.swiglu(guv[:, :I], guv[:, I:])
-        td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"])
+        actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save))
+        td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save))
         K.gemm_nt(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)
+    if save:
+        sv.update(x=x, rstd1=rstd1, h=h, qkv=qkv, tb=tb, kc=kc, vc=vc, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu,
+                  act=act, t=t, to=to, tg=tg, guv=guv, actv=actv, td=td)
     return x_out
 
 
 def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, signal, labels=None, *,
-            want_hidden_states: bool = False):
-    """-> dict(hidden [B,S,H], flag, lang_idx, vis_idx, z_lang [n_l,V], z_vis list of [n_v,Vv], loss or None)."""
+            want_hidden_states: bool = False, save: bool = False):
+    """-> dict(hidden [B,S,H], flag, lang_idx, vis_idx, z_lang [n_l,V], z_vis list of [n_v,Vv], loss or None, saved)."""
     Q, B, S = input_ids.shape
     dev = input_ids.device
     flag, lang_idx, vis_idx, lens = route(vision_indices, attention_mask, d)
     if not torch.equal(flag.view(B, S).bool(), input_ids[0] >= d.vocab):
         raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
     cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, S), dev)
-    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal)
+    saved = dict(layers=[], emb={}) if save else None
+    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None)
     hs = [x] if want_hidden_states else None
     for i in range(d.layers):
-        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S)
+        sv = {} if save else None
+        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv)
+        if save:
+            saved["layers"].append(sv)
         if want_hidden_states:
             hs.append(x)
-    hidden = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps)
+    hidden, rstd_f = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
     z_vis = []
@@ -204,6 +225,7 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         else:
             z_vis.append(None)
     loss = None
+    tgts, counts = [], []
     if labels is not None:
         N = B * S
         loss = torch.zeros((), dtype=torch.float32, device=dev)
@@ -211,15 +233,22 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
             tgt = torch.full((B, S), -100, dtype=torch.int64, device=dev)
             tgt[:, :-1] = labels[q][:, 1:]                                             # shift so that tokens < n predict n
             tgt = tgt.reshape(N)
+            tl = tgt.index_select(0, lang_idx.long()).contiguous() if n_l else None
+            tv = tgt.index_select(0, vis_idx.long()).contiguous() if n_v else None
             tot = torch.zeros((), dtype=torch.float32, device=dev)
             if n_l:
-                tot = tot + K.ce_rows(z_lang, tgt.index_select(0, lang_idx.long()).contiguous(), 0).sum()
+                tot = tot + K.ce_rows(z_lang, tl, 0).sum()
             if n_v:
-                tot = tot + K.ce_rows(z_vis[q], tgt.index_select(0, vis_idx.long()).contiguous(), d.vocab).sum()
-            loss = loss + tot / (tgt >= 0).sum().clamp_min(1)
+                tot = tot + K.ce_rows(z_vis[q], tv, d.vocab).sum()
+            cnt = (tgt >= 0).sum().clamp_min(1)
+            loss = loss + tot / cnt
+            tgts.append((tl, tv)); counts.append(cnt)
         loss = loss / Q
+    if save:
+        saved.update(x_last=x, rstd_f=rstd_f, hidden=hidden, tgts=tgts, counts=counts, cos=cos, sin=sin, lens=lens, B=B, S=S,
+                     Q=Q, input_ids=input_ids)
     return dict(hidden=hidden.view(B, S, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang,
-                z_vis=z_vis, loss=loss, hidden_states=hs)
+                z_vis=z_vis, loss=loss, hidden_states=hs, saved=saved)
 
 
 def dense_logits(out, d: DecDims, B: int, S: int):
@@ -235,3 +264,248 @@ def dense_logits(out, d: DecDims, B: int, S: int):
         if out["z_vis"][q] is not None:
             res[q, out["vis_idx"].long(), V:] = out["z_vis"][q]
     return res.view(Q, B, S, V + Vv)
+
+
+# ======================================================================================================
+# Backward schedule (hand-written; replaces autograd through modeling_libra.py:437-491, :625-661, :1018-1174)
+# ======================================================================================================
+def _full(t: torch.Tensor) -> torch.Tensor:
+    """The zero-padded [round_up(rows,64), C] allocation behind a K.alloc_rows row view (column slices allowed)."""
+    return torch.as_strided(t, (K.round_up(t.shape[0], 64), t.shape[1]), t.stride(), t.storage_offset())
+
+
+def _compact(t2d: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """Rows `idx` of a sequence-order tensor, gathered into a 64-row-padded compact buffer (reduction-major wgrad operand)."""
+    n = idx.numel()
+    buf = K.alloc_rows(n, t2d.shape[1], t2d.device)
+    K.copy_rows(t2d, idx, n, buf, 0)
+    return buf[:n]
+
+
+def _wg(dy_c: torch.Tensor, x_c: torch.Tensor) -> torch.Tensor:
+    """dW[out, in] = sum_tokens dy[t, out] x[t, in]; both operands token-major, padded (LIBRA_GEMM_A_T | _B_T)."""
+    return K.gemm_nt(_full(dy_c), _full(x_c), a_t=True, b_t=True)
+
+
+def backward(sd, packed, d: DecDims, out, want):
+    """Gradients of out["loss"] w.r.t. every parameter name in `want` (a set) -> {name: bf16 grad}."""
+    sv = out["saved"]
+    flag, lang_idx, vis_idx = out["flag"], out["lang_idx"], out["vis_idx"]
+    B, S, Q = sv["B"], sv["S"], sv["Q"]
+    N, H, I, r, rg = B * S, d.hidden, d.inter, d.r, d.rg
+    dev = flag.device
+    n_l, n_v = lang_idx.numel(), vis_idx.numel()
+    cos, sin, lens = sv["cos"], sv["sin"], sv["lens"]
+    g: Dict[str, torch.Tensor] = {}
+    f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    w = lambda name: name in want
+
+    # ---- loss -> logits -> final hidden
+    hidden = sv["hidden"]
+    dhid = torch.zeros((N, H), dtype=BF16, device=dev)
+    coef = [float(1.0 / (sv["counts"][q].item() * Q)) for q in range(Q)]
+    def head_pad(name):
+        """Head weight with its vocab (the dgrad reduction length) zero-padded to the GEMM's 64 granule."""
+        W = sd[name]
+        V = W.shape[0]
+        Vp = K.round_up(V, 64)
+        if Vp == V:
+            return W, V, Vp
+        wp = torch.zeros((Vp, H), dtype=BF16, device=dev)
+        wp[:V] = W
+        return wp, V, Vp
+
+    def dlogits(z, t0, t1, sub, c0, c1, Vp):
+        n, V = z.shape
+        full = torch.zeros((K.round_up(n, 64), Vp), dtype=BF16, device=dev)      # zero pad rows AND pad columns
+        K.ce_rows_bwd(z, t0, t1, sub, c0, c1, full[:n, :V])
+        return full
+
+    if Q > 2:
+        raise NotImplementedError("more than two codebooks")
+    if n_l:
+        tl = [sv["tgts"][q][0] for q in range(Q)]
+        wl, V, Vp = head_pad("lm_head.weight")
+        dzf = dlogits(out["z_lang"], tl[0], tl[1] if Q > 1 else None, 0, coef[0], coef[1] if Q > 1 else 0.0, Vp)
+        K.gemm_nt(dzf[:n_l], wl, b_t=True, out=dhid, c_rows=lang_idx)
+        if w("lm_head.weight"):
+            g["lm_head.weight"] = K.gemm_nt(dzf, _full(_compact(hidden, lang_idx)), a_t=True, b_t=True)[:V]
+    if n_v:
+        hv = None
+        for q in range(Q):
+            name = f"vision_lm_head.heads.{q}.weight"
+            wq, V, Vp = head_pad(name)
+            dzf = dlogits(out["z_vis"][q], sv["tgts"][q][1], None, d.vocab, coef[q], 0.0, Vp)
+            K.gemm_nt(dzf[:n_v], wq, b_t=True, out=dhid, c_rows=vis_idx, resid=dhid if q > 0 else None)
+            if w(name):
+                hv = _compact(hidden, vis_idx) if hv is None else hv
+                g[name] = K.gemm_nt(dzf, _full(hv), a_t=True, b_t=True)[:V]
+    dx = K.rmsnorm_routed_bwd(dhid, sv["x_last"], sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, sv["rstd_f"])
+    if w("model.norm.weight") or w("model.vision_norm.weight"):
+        dl, dv = f32(H), f32(H)
+        K.rmsnorm_routed_wgrad(dhid, sv["x_last"], sv["rstd_f"], flag, dl, dv)
+        g["model.norm.weight"], g["model.vision_norm.weight"] = K.f32_to_bf16(dl), K.f32_to_bf16(dv)
+
+    for i in range(d.layers - 1, -1, -1):
+        dx = layer_backward(sd, packed[i], i, d, sv["layers"][i], dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w)
+
+    # ---- embeddings (modeling_libra.py:625-661)
+    e = sv["emb"]
+    if n_v:
+        proc = "model.vision_contiguous_signal_processor.weight"
+        dven = K.gemm_nt(dx, sd[proc], b_t=True, a_rows=vis_idx)                                   # [n_v, H+Cs]
+        if w(proc):
+            g[proc] = _wg(_compact(dx, vis_idx), e["ven"])
+        dve = K.rmsnorm_routed_bwd(dven, e["ve"], sd["model.vision_signal_norm.weight"], None, None, e["rstd_e"])
+        if w("model.vision_signal_norm.weight"):
+            dn = f32(H + d.signal)
+            K.rmsnorm_routed_wgrad(dven, e["ve"], e["rstd_e"], None, dn, None)
+            g["model.vision_signal_norm.weight"] = K.f32_to_bf16(dn)
+        ids = sv["input_ids"]
+        for q in range(Q):
+            name = f"model.vision_embed_tokens.{q}.weight"
+            if w(name):
+                # embedding gradient = scatter-add of rows by token id: tiny (n_v x H/Q), done with torch index_add_ (plumbing)
+                acc = torch.zeros(sd[name].shape, dtype=torch.float32, device=dev)
+                tok = (ids[q].reshape(-1).index_select(0, vis_idx.long()) - d.vocab)
+                acc.index_add_(0, tok, dve[:, q * (H // Q):(q + 1) * (H // Q)].float())
+                g[name] = acc.to(BF16)
+    if n_l and w("model.embed_tokens.weight"):
+        acc = torch.zeros(sd["model.embed_tokens.weight"].shape, dtype=torch.float32, device=dev)
+        tok = sv["input_ids"][0].reshape(-1).index_select(0, lang_idx.long())
+        acc.index_add_(0, tok, dx.index_select(0, lang_idx.long()).float())
+        g["model.embed_tokens.weight"] = acc.to(BF16)
+    return g
+
+
+def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w):
+    H, I, r, rg = d.hidden, d.inter, d.r, d.rg
+    N = B * S
+    dev = dx_out.device
+    n_l, n_v = lang_idx.numel(), vis_idx.numel()
+    pre = f"model.layers.{i}."
+    a, m = pre + "self_attn.", pre + "mlp."
+    f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    any_l = lambda names: any(w(n) for n in names)
+
+    # ================= MLP: x_out = x_mid + down(silu(gate(h2)) * up(h2)), routed =================
+    dh2 = torch.empty((N, H), dtype=BF16, device=dev)
+    h2 = sv["h2"]
+    if n_l:
+        gu = sv["gu"]
+        dact = K.gemm_nt(dx_out, sd[m + "down_proj.weight"], b_t=True, a_rows=lang_idx)                 # [n_l, I]
+        if w(m + "down_proj.weight"):
+            g[m + "down_proj.weight"] = _wg(_compact(dx_out, lang_idx), sv["act"])
+        dgu = K.alloc_rows(n_l, 2 * I, dev)[:n_l]
+        K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
+        K.gemm_nt(dgu, pk["wgu"], b_t=True, out=dh2, c_rows=lang_idx)
+        if any_l([m + "gate_proj.weight", m + "up_proj.weight"]):
+            dwgu = _wg(dgu, _compact(h2, lang_idx))
+            g[m + "gate_proj.weight"], g[m + "up_proj.weight"] = dwgu[:I], dwgu[I:]
+    if n_v:
+        tg, guv, actv, td = sv["tg"], sv["guv"], sv["actv"], sv["td"]
+        dxo_v = _compact(dx_out, vis_idx)
+        dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=K.alloc_rows(n_v, r, dev)[:n_v])
+        if w(m + "vision_down_proj.weight_B"):
+            g[m + "vision_down_proj.weight_B"] = _wg(dxo_v, td)
+        dactv = K.gemm_nt(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True)                            # [n_v, I]
+        if w(m + "vision_down_proj.weight_A"):
+            g[m + "vision_down_proj.weight_A"] = _wg(dtd, actv)
+        dguv = K.alloc_rows(n_v, 2 * I, dev)[:n_v]
+        K.swiglu_bwd(dactv, guv[:, :I], guv[:, I:], dguv[:, :I], dguv[:, I:])
+        dtg = K.alloc_rows(n_v, 2 * rg, dev)[:n_v]
+        K.gemm_nt(dguv[:, :I], sd[m + "vision_gate_proj.weight_B"], b_t=True, out=dtg[:, :rg])
+        K.gemm_nt(dguv[:, I:], sd[m + "vision_up_proj.weight_B"], b_t=True, out=dtg[:, rg:])
+        if w(m + "vision_gate_proj.weight_B"):
+            g[m + "vision_gate_proj.weight_B"] = _wg(dguv[:, :I], tg[:, :rg])
+        if w(m + "vision_up_proj.weight_B"):
+            g[m + "vision_up_proj.weight_B"] = _wg(dguv[:, I:], tg[:, rg:])
+        K.gemm_nt(dtg, pk["agu"], b_t=True, out=dh2, c_rows=vis_idx)
+        if any_l([m + "vision_gate_proj.weight_A", m + "vision_up_proj.weight_A"]):
+            dagu = _wg(dtg, _compact(h2, vis_idx))
+            g[m + "vision_gate_proj.weight_A"], g[m + "vision_up_proj.weight_A"] = dagu[:rg], dagu[rg:]
+    ln_l, ln_v = pre + "post_attention_layernorm.weight", pre + "vision_post_attention_layernorm.weight"
+    dx_mid = K.rmsnorm_routed_bwd(dh2, sv["x_mid"], sd[ln_l], sd[ln_v], flag, sv["rstd2"], dres=dx_out)
+    if w(ln_l) or w(ln_v):
+        dl, dv = f32(H), f32(H)
+        K.rmsnorm_routed_wgrad(dh2, sv["x_mid"], sv["rstd2"], flag, dl, dv)
+        g[ln_l], g[ln_v] = K.f32_to_bf16(dl), K.f32_to_bf16(dv)
+
+    # ================= attention: x_mid = x + o_proj(attn(rope(q), K_same/K_cross, V_same/V_cross)) =================
+    o = sv["o"]
+    do = torch.empty((N, H), dtype=BF16, device=dev)
+    if n_l:
+        K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do)
+        if w(a + "o_proj.weight"):
+            g[a + "o_proj.weight"] = _wg(_compact(dx_mid, lang_idx), _compact(o, lang_idx))
+    if n_v:
+        dxm_v = _compact(dx_mid, vis_idx)
+        dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=K.alloc_rows(n_v, r, dev)[:n_v])
+        if w(a + "vision_o_proj.weight_B"):
+            g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"])
+        K.gemm_nt(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx)
+        if w(a + "vision_o_proj.weight_A"):
+            g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx))
+    qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
+    dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
+                                               sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5)
+    dqkv = torch.empty((N, 3 * H), dtype=BF16, device=dev)
+    dkb = torch.empty((N, H), dtype=BF16, device=dev)
+    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb)
+    dvb = dvc
+    # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
+    dtb = torch.zeros((N, 64), dtype=BF16, device=dev)
+    h = sv["h"]
+    for idx, which, bk, bv in ((lang_idx, "language", pk["bk_l"], pk["bv_l"]), (vis_idx, "vision", pk["bk_v"], pk["bv_v"])):
+        if idx.numel() == 0:
+            continue
+        K.gemm_nt(dkb, bk, b_t=True, a_rows=idx, c_rows=idx, out=dtb[:, 0:8])
+        K.gemm_nt(dvb, bv, b_t=True, a_rows=idx, c_rows=idx, out=dtb[:, 8:16])
+        nk, nv = a + f"vision_k_bridge_on_{which}.weight_B", a + f"vision_v_bridge_on_{which}.weight_B"
+        if w(nk) or w(nv):
+            tbc = _compact(tb, idx)
+            if w(nk):
+                g[nk] = _wg(_compact(dkb, idx), tbc[:, 0:8])[:, :d.rank].contiguous()
+            if w(nv):
+                g[nv] = _wg(_compact(dvb, idx), tbc[:, 8:16])[:, :d.rank].contiguous()
+    dh = torch.empty((N, H), dtype=BF16, device=dev)
+    if n_l:
+        K.gemm_nt(dqkv, pk["wqkv"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)
+        K.gemm_nt(dtb, pk["ab_l"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh, resid=dh)
+        hl = None
+        if any_l([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]):
+            hl = _compact(h, lang_idx)
+            dw = _wg(_compact(dqkv, lang_idx), hl)
+            for j, nm in enumerate(("q", "k", "v")):
+                g[a + f"{nm}_proj.weight"] = dw[j * H:(j + 1) * H]
+        nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
+        if w(nk) or w(nv):
+            hl = _compact(h, lang_idx) if hl is None else hl
+            dab = _wg(_compact(dtb, lang_idx), hl)                                          # [64, H]
+            g[nk], g[nv] = dab[0:d.rank].contiguous(), dab[8:8 + d.rank].contiguous()
+    if n_v:
+        t = sv["t"]
+        dqkv_v = _compact(dqkv, vis_idx)                                                    # [n_v, 3H]
+        dt = K.alloc_rows(n_v, 3 * r, dev)[:n_v]
+        for j, nm in enumerate(("q", "k", "v")):
+            K.gemm_nt(dqkv_v[:, j * H:(j + 1) * H], sd[a + f"vision_{nm}_proj.weight_B"], b_t=True, out=dt[:, j * r:(j + 1) * r])
+            if w(a + f"vision_{nm}_proj.weight_B"):
+                g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r])
+        K.gemm_nt(dt, pk["aqkv"], b_t=True, out=dh, c_rows=vis_idx)
+        K.gemm_nt(dtb, pk["ab_v"], b_t=True, a_rows=vis_idx, c_rows=vis_idx, out=dh, resid=dh)
+        hv = _compact(h, vis_idx)
+        if any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"]):
+            da = _wg(dt, hv)
+            for j, nm in enumerate(("q", "k", "v")):
+                g[a + f"vision_{nm}_proj.weight_A"] = da[j * r:(j + 1) * r]
+        nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
+        if w(nk) or w(nv):
+            dab = _wg(_compact(dtb, vis_idx), hv)
+            g[nk], g[nv] = dab[0:d.rank].contiguous(), dab[8:8 + d.rank].contiguous()
+    ln_l, ln_v = pre + "input_layernorm.weight", pre + "vision_input_layernorm.weight"
+    dx = K.rmsnorm_routed_bwd(dh, sv["x"], sd[ln_l], sd[ln_v], flag, sv["rstd1"], dres=dx_mid)
+    if w(ln_l) or w(ln_v):
+        dl, dv = f32(H), f32(H)
+        K.rmsnorm_routed_wgrad(dh, sv["x"], sv["rstd1"], flag, dl, dv)
+        g[ln_l], g[ln_v] = K.f32_to_bf16(dl), K.f32_to_bf16(dv)
+    return dx

@@ -373,14 +373,15 @@ gemm_nt = _profiled("gemm", _gemm_flops)(gemm_nt)
 
 
 # ---- routed decoder rows -------------------------------------------------------------------------------
-def rmsnorm_routed(x, w_lang, w_vis, flag, eps: float, *, out=None):
+def rmsnorm_routed(x, w_lang, w_vis, flag, eps: float, *, out=None, save_rstd: bool = False):
     _chk2d(x, "x")
     rows, D = x.shape
     y = torch.empty((rows, D), dtype=BF16, device=x.device) if out is None else out
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_rstd else None
     rc = _lib.lib().libra_rmsnorm_routed_fwd(x.data_ptr(), x.stride(0), w_lang.data_ptr(), _ptr(w_vis), _ptr(flag),
-                                             y.data_ptr(), y.stride(0), None, rows, D, float(eps), _stream())
+                                             y.data_ptr(), y.stride(0), _ptr(rstd), rows, D, float(eps), _stream())
     _lib.check(rc, "rmsnorm_routed")
-    return y
+    return (y, rstd) if save_rstd else y
 
 
 def rope_bridge(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, S: int, H: int):
@@ -463,3 +464,51 @@ def bridge_attn_bwd(q, k_same, k_cross, v_same, v_cross, out, dout, flag, kv_len
                                           HD, B, S, H, float(scale), _stream())
     _lib.check(rc, "bridge_attn_bwd")
     return tuple(g)
+
+
+# ---- routed decoder, backward rows -----------------------------------------------------------------------
+def ce_rows_bwd(logits, t0, t1, sub: int, c0: float, c1: float, out):
+    _chk2d(logits, "logits"); _chk2d(out, "out")
+    rows, V = logits.shape
+    rc = _lib.lib().libra_ce_rows_bwd(logits.data_ptr(), logits.stride(0), V, _ptr(t0), _ptr(t1), sub, float(c0), float(c1),
+                                      out.data_ptr(), out.stride(0), rows, _stream())
+    _lib.check(rc, "ce_rows_bwd")
+    return out
+
+
+def rmsnorm_routed_bwd(dy, x, w_lang, w_vis, flag, rstd, *, dres=None, out=None):
+    _chk2d(dy, "dy"); _chk2d(x, "x")
+    rows, D = x.shape
+    dx = torch.empty((rows, D), dtype=BF16, device=x.device) if out is None else out
+    rc = _lib.lib().libra_rmsnorm_routed_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), w_lang.data_ptr(),
+                                             _ptr(w_vis), _ptr(flag), rstd.data_ptr(), _ptr(dres),
+                                             dres.stride(0) if dres is not None else 0, dx.data_ptr(), dx.stride(0), rows, D,
+                                             _stream())
+    _lib.check(rc, "rmsnorm_routed_bwd")
+    return dx
+
+
+def rmsnorm_routed_wgrad(dy, x, rstd, flag, dw_lang, dw_vis):
+    """dw_lang / dw_vis (fp32 [D], either may be None) += per-modality sums of dy * x * rstd."""
+    rows, D = x.shape
+    nbytes = _lib.lib().libra_rmsnorm_wgrad_workspace_bytes(rows, D)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().libra_rmsnorm_routed_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), rstd.data_ptr(),
+                                               _ptr(flag), _ptr(dw_lang), _ptr(dw_vis), ws.data_ptr(), nbytes, rows, D,
+                                               _stream())
+    _lib.check(rc, "rmsnorm_routed_wgrad")
+
+
+def swiglu_bwd(dy, gate, up, dgate, dup):
+    rows, I = gate.shape
+    rc = _lib.lib().libra_swiglu_bwd(dy.data_ptr(), dy.stride(0), gate.data_ptr(), up.data_ptr(), gate.stride(0),
+                                     dgate.data_ptr(), dup.data_ptr(), dgate.stride(0), rows, I, _stream())
+    _lib.check(rc, "swiglu_bwd")
+
+
+def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb):
+    N = dq.shape[0]
+    rc = _lib.lib().libra_rope_bridge_bwd(dq.data_ptr(), dks.data_ptr(), dkc.data_ptr(), dvs.data_ptr(), dvc.data_ptr(),
+                                          dq.stride(0), cos.data_ptr(), sin.data_ptr(), cos.shape[0], dqkv.data_ptr(),
+                                          dqkv.stride(0), dkb.data_ptr(), dkb.stride(0), N, S, H, _stream())
+    _lib.check(rc, "rope_bridge_bwd")

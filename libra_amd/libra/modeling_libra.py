@@ -3,9 +3,8 @@
 LibraDecoderLayer :416-435, LibraModel :524-600, MultiLMHead :834-843, LibraForCausalLM :845-940, forward :1069-1188).
 
 The sub-modules only own the parameters (same names and shapes as the reference checkpoints: SURVEY §8b); the
-compute is the kernel schedule in ``libra_amd/decoder_engine.py``.  Status: FORWARD (loss / logits / hidden states,
-i.e. evaluation and the forward half of a training step) is implemented and parity-tested against the reference
-fixtures; the decoder's hand-written backward is the next row — calling ``loss.backward()`` raises.
+compute is the kernel schedule in ``libra_amd/decoder_engine.py`` (forward and hand-written backward, exposed to
+autograd through one ``torch.autograd.Function``), parity-tested against the reference fixtures.
 Only the configuration both recipes use is supported (use_bridge, concat+norm signals, 1d prediction, no 2d RoPE,
 no unified head, dropout 0); anything else raises NotImplementedError rather than silently diverging.
 """
@@ -201,17 +200,14 @@ class LibraForCausalLM(PreTrainedModel):
         Q, B, S = input_ids.shape
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.bool, device=input_ids.device)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            grad_note = True
-        else:
-            grad_note = False
-        with torch.no_grad():
-            sd, packed = self._state()
-            out = DE.forward(sd, packed, self._dims, input_ids, attention_mask, vision_indices, contiguous_signal, labels,
-                             want_hidden_states=bool(output_hidden_states))
-        loss = out["loss"]
-        if loss is not None and grad_note:
-            loss = _NoBackward.apply(loss, next(p for p in self.parameters() if p.requires_grad))
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        holder = {}
+        loss = _LibraFunction.apply(self, holder, names, input_ids, attention_mask, vision_indices, contiguous_signal, labels,
+                                    bool(output_hidden_states), *params)
+        out = holder["out"]
+        if labels is None:
+            loss = None
         hs = None
         if output_hidden_states:
             hs = tuple(h.view(B, S, -1) for h in out["hidden_states"]) + (out["hidden"],)
@@ -227,12 +223,38 @@ class LibraForCausalLM(PreTrainedModel):
         return output._lazy_logits.get()
 
 
-class _NoBackward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, loss, anchor):
-        return loss.clone()
+class _LibraFunction(torch.autograd.Function):
+    """Autograd bridge: forward = DE.forward (saving activations when any parameter needs a gradient), backward =
+    DE.backward (hand-written kernel schedule).  Only the parameters that require gradients get one (the reference's
+    freeze policy, modeling_libra.py:1342-1369, is expressed through requires_grad exactly as upstream)."""
 
     @staticmethod
-    def backward(ctx, g):
-        raise NotImplementedError("the routed decoder's hand-written backward is not built yet (DESIGN.md §7); "
-                                  "forward / evaluation only in this round")
+    def forward(ctx, model, holder, names, input_ids, attention_mask, vision_indices, signal, labels, want_hs, *params):
+        sd = dict(zip(names, params))
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != model._pack_key:
+            model._pack_key, model._packed = key, DE.pack(sd, model._dims)
+        need = labels is not None and any(ctx.needs_input_grad[9:])
+        out = DE.forward(sd, model._packed, model._dims, input_ids, attention_mask, vision_indices, signal, labels,
+                         want_hidden_states=want_hs, save=need)
+        holder["out"] = out
+        ctx.model, ctx.sd, ctx.out, ctx.names = model, sd, out, names
+        ctx.want = {n for n, ng in zip(names, ctx.needs_input_grad[9:]) if ng}
+        loss = out["loss"]
+        return loss if loss is not None else torch.zeros((), device=input_ids.device)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        if ctx.out.get("saved") is None:
+            raise RuntimeError("backward through LibraForCausalLM requested but no activations were saved")
+        grads = DE.backward(ctx.sd, ctx.model._packed, ctx.model._dims, ctx.out, ctx.want)
+        res = []
+        for n in ctx.names:
+            gr = grads.get(n) if n in ctx.want else None
+            if gr is not None:
+                p = ctx.sd[n]
+                gr = gr.reshape(p.shape)
+                gr = gr * gloss.to(gr.dtype)
+            res.append(gr)
+        ctx.out["saved"] = None
+        return (None,) * 9 + tuple(res)
