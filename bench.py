@@ -81,6 +81,48 @@ def make_step(clip, tok, pixel, cot, world):
     return step
 
 
+def build_libra(device, batch, seq=2048):
+    """BASELINE configs[2]/[3] shape: the reference's real pretraining step — frozen CLIP ViT + VQ encode under no_grad
+    (clip_encoder.py:53, image_tokenizer.py:70) -> tensor assembly -> Libra-11B routed decoder fwd+bwd with the language
+    stream frozen (modeling_libra.py:1342-1346: 4.27 B trainable "vision" parameters)."""
+    from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy, assemble_inputs, get_labels
+    clip, tok, pixel, _ = build(device, batch)
+    clip.requires_grad_(False)
+    tok.model.encoder.allow_grad = False
+    with torch.device(device):
+        dec = LibraForCausalLM(LibraConfig())
+    dec = dec.to(torch.bfloat16)
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            if "bridge" in n and n.endswith("weight_B"):
+                p.normal_(0, 0.02)             # zero-initialised upstream; make the bridge path numerically live
+    apply_freeze_policy(dec, frozen_language=True)
+    V, L = 32000, 578
+    PH = V - 1
+    g = torch.Generator().manual_seed(42)
+    text = torch.randint(3, V - 2, (batch, seq), generator=g)
+    text[:, 0] = 1
+    text[:, 1:1 + L] = PH
+    text = text.to(device)
+    am = torch.ones(batch, seq, dtype=torch.long, device=device)
+    spans = [[(1 + L, 2 + L)] for _ in range(batch)]
+    params = [p for p in dec.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        with torch.no_grad():
+            img = tok.encode(pixel)
+        inp = assemble_inputs(text, am, img, img_ph_token_id=PH, img_gen_token_id=V - 2, boi_token_id=tok.boi_token_id,
+                              num_codebook=2, max_vision_token_length=L)
+        labels = get_labels(inp, spans, boi_token_id=tok.boi_token_id, bos_token_id=1)
+        out = dec(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], vision_indices=inp["vision_indices"],
+                  contiguous_signal=inp["coninous_signal"], labels=labels)
+        out.loss.backward()
+        return out.loss.detach()
+    return step, params
+
+
 def cpu_baseline(sample_iters=3):
     """The CPU oracle (oracle/vit_oracle.py, proven equal to the reference's modules on the golden fixtures) timed on
     this box's host cores: ViT-L/14@336 fwd+bwd, B=1, fp32."""
@@ -122,7 +164,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--workload", choices=["vit", "libra"], default="vit",
+                    help="vit = BASELINE configs[1] (headline line); libra = full pretraining step, ViT+VQ (no grad) -> "
+                         "Libra-11B routed decoder fwd+bwd, bs 8, seq 2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -137,8 +182,25 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
-    clip, tok, pixel, cot = build(device, args.batch)
-    step = make_step(clip, tok, pixel, cot, world)
+    if args.batch is None:
+        args.batch = 32 if args.workload == "vit" else 8
+    if args.workload == "vit":
+        clip, tok, pixel, cot = build(device, args.batch)
+        step = make_step(clip, tok, pixel, cot, world)
+    else:
+        from libra_amd.dp import BucketedGradReducer
+        inner, dparams = build_libra(device, args.batch)
+
+        def step():
+            loss = inner()
+            if world > 1:
+                red = BucketedGradReducer(bucket_bytes=256 << 20)
+                red.add({str(i): p.grad for i, p in enumerate(dparams) if p.grad is not None})
+                outg = red.finish()
+                for i, p in enumerate(dparams):
+                    if p.grad is not None:
+                        p.grad = outg[str(i)]
+            return loss
 
     def note(msg):
         if rank == 0:
@@ -175,7 +237,12 @@ def main():
     gflop = sum(w for w, _ in gem) / 1e9
     gms = sum(t for _, t in gem)
     achieved = gflop / gms if gms > 0 else 0.0        # GFLOP/ms == TFLOP/s
-    gflop_step_img = GFLOP_FWD_PER_IMG + 2 * (GFLOP_FWD_PER_IMG - GFLOP_LAYER)   # bwd skips the unused last layer
+    if args.workload == "vit":
+        gflop_step_img = GFLOP_FWD_PER_IMG + 2 * (GFLOP_FWD_PER_IMG - GFLOP_LAYER)   # bwd skips the unused last layer
+    else:
+        # ViT fwd + decoder fwd (25.44 T) + decoder bwd: dgrad everywhere, wgrad for the vision weights, attention bwd 2.5x
+        dec_bwd = 32 * (595.0 + 153.34 + 2.5 * 34.4 + 153.34) + 385.0 + 2 * 4.8
+        gflop_step_img = GFLOP_FWD_PER_IMG + 25440.0 + dec_bwd
     roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1),
@@ -186,12 +253,15 @@ def main():
            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs=32/GPU (LLM frozen)",
+           "config": {"workload": ("configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs=32/GPU (LLM frozen)"
+                                   if args.workload == "vit" else
+                                   "configs[2]/[3]: ViT+VQ encode (no grad) -> Libra-11B routed decoder fwd+bwd, frozen language, "
+                                   "bs=8/GPU, seq 2048, one 336px image per sequence"),
                       "global_batch": args.batch * world, "image": "3x336x336", "vit_tokens": 577,
                       "parallelism": f"dp{world}", "algorithmic_gflop_per_image": round(gflop_step_img, 1),
                       "value_per_gpu": round(ips / world, 2)},
            "roofline": roof}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.workload == "vit":
         note("timing the CPU oracle on the host cores ...")
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
