@@ -9,10 +9,12 @@
 //   dq pass  : forward-like (lane <-> query, 128 queries / workgroup, 32-key tiles, same variant skipping);
 //              K and V tiles are staged once in the reduction-major image and read BOTH ways: 16-byte row reads
 //              for S^T = K Q^T and dP^T = V dO^T, LDS transpose reads for dQ^T += K^T dS^T.
-//   dkv pass : lane <-> key.  Workgroup = 64 keys, 4 waves = 2 key halves x 2 head-dim halves (each wave owns a
-//              [64 d x 32 keys] block of all four gradient accumulators = 128 VGPRs); the workgroup's K/V
-//              operand tiles stay resident in LDS (64 KiB), Q / dO tiles of 32 queries stream through a double
-//              buffer and are likewise read both ways.
+//   dkv pass : lane <-> key.  Workgroup = 64 keys, 4 waves = 2 key halves x 2 ROLES: a "dV wave" recomputes P
+//              (S = Q K^T) and accumulates dV_same / dV_cross, a "dK wave" recomputes P and dP = dO V^T and
+//              accumulates dK_same / dK_cross (two [128 d x 32 keys] accumulators = 128 VGPRs per wave, no
+//              first-stage work duplicated for the same output).  The workgroup's K/V operand tiles stay
+//              resident in LDS (64 KiB); Q / dO tiles of 32 queries stream through a double buffer in BOTH
+//              images (row image for the first-stage A operand, reduction-major image for the transpose reads).
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
 // ================================================================================================
 // dK / dV pass
 constexpr int KV_RES = 4 * 16384;             // resident K_same, K_cross, V_same, V_cross: [64 keys][128 d] each
-constexpr int QD_STAGE = 2 * 8192 + 256;      // Q tile, dO tile (32 queries, reduction-major image), L[32], D[32]
+constexpr int QD_STAGE = 4 * 8192 + 256;      // Q row image, Q reduction-major image, dO row image, dO r-m image, L[32], D[32]
 constexpr int DKV_LDS_B = KV_RES + 2 * QD_STAGE + 1024;
 
 // resident operand tile: two N-type [64 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 16 KiB
@@ -256,9 +258,21 @@ __device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, lon
         glds16(base + (long)key * ld + sub * 64 + c * 8, dst + pc * 1024);
     }
 }
-__device__ __forceinline__ bf16x8 res_frag(const char* tile, int row, int ks, int fk) {
+// row image of a [32 rows][128 d] tile: two N-type [32][64] sub-tiles (4 KiB each); 8 pieces of 1 KiB over 4 waves
+__device__ __forceinline__ void stage_n32(const bf16_t* __restrict__ base, long ld, int row0, int nrows, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pc = wave * 2 + j;
+        const int sub = pc >> 2, r = (pc & 3) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int row = row0 + r; row = row < nrows ? row : nrows - 1;
+        glds16(base + (long)row * ld + sub * 64 + c * 8, dst + pc * 1024);
+    }
+}
+// fragment (row, 8 consecutive d of k-step ks) of a row image whose sub-tiles are `sub_bytes` apart
+__device__ __forceinline__ bf16x8 nfrag(const char* tile, int row, int ks, int fk, int sub_bytes) {
     const int sub = ks >> 2, c = (2 * (ks & 3) + fk) ^ ((row >> 1) & 7);
-    return *(const bf16x8*)(tile + sub * 8192 + row * 128 + (c << 4));
+    return *(const bf16x8*)(tile + sub * sub_bytes + row * 128 + (c << 4));
 }
 
 __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
@@ -268,7 +282,8 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     unsigned* qmask = (unsigned*)(smem + KV_RES + 2 * QD_STAGE); // per 32-query tile: bit i = query i is a vision token
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kw = wave & 1, dw = wave >> 1;
+    const int kw = wave & 1;
+    const bool role_dk = (wave >> 1) != 0;                       // waves 0,1: dV; waves 2,3: dK
     const int fk = lane >> 5, l31 = lane & 31;
     const int nblk = p.B * p.H * p.n_t;
     const int L = xcd_remap(blockIdx.x, nblk);
@@ -304,24 +319,26 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     const float* dbase = p.delta + ((long)b * p.H + h) * S;
     auto stage_q = [&](int buf, int t) {
         char* dst = qd + buf * QD_STAGE;
-        stage_t32(qbase, p.ldq, t * 32, S, dst, wave, lane, 4);
-        stage_t32(dobase, p.ldo, t * 32, S, dst + 8192, wave, lane, 4);
+        stage_n32(qbase, p.ldq, t * 32, S, dst, wave, lane);                    // Q rows      (first-stage A operand)
+        stage_t32(qbase, p.ldq, t * 32, S, dst + 8192, wave, lane, 4);          // Q, r-m image (Q^T fragments for dK)
+        stage_n32(dobase, p.ldo, t * 32, S, dst + 16384, wave, lane);           // dO rows
+        stage_t32(dobase, p.ldo, t * 32, S, dst + 24576, wave, lane, 4);        // dO, r-m image (dO^T fragments for dV)
         if (wave < 2 && lane < 32) {
             int qi = t * 32 + lane; qi = qi < S ? qi : S - 1;
             const float* src = (wave == 0 ? lbase : dbase) + qi;
-            __builtin_amdgcn_global_load_lds((const LIBRA_GLB void*)src, (LIBRA_LDS void*)(dst + 16384 + wave * 128), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const LIBRA_GLB void*)src, (LIBRA_LDS void*)(dst + 32768 + wave * 128), 4, 0, 0);
         }
     };
     const int qt0 = key0 / 32;                                   // first query tile that can see this key block
     const int nqt = ntile_all;
-    f32x16 dk_s[2], dk_c[2], dv_s[2], dv_c[2];
+    f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk_s[i][r] = 0.f; dk_c[i][r] = 0.f; dv_s[i][r] = 0.f; dv_c[i][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc_s[i][r] = 0.f; acc_c[i][r] = 0.f; }
     if (qt0 < nqt) stage_q(0, qt0);
 
-    const char* rKs = res + kw * 32 * 128;                        // this wave's 32 key rows inside each 64-row sub-tile
+    const char* rK = res + kw * 32 * 128;                         // this wave's 32 key rows inside each 64-row sub-tile
     for (int it = qt0; it < nqt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -329,9 +346,11 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         if (it + 1 < nqt) stage_q(cur ^ 1, it + 1);
         const int q0 = it * 32;
         if (kbase_w >= S || q0 + 31 < kbase_w) continue;          // no (query >= key) pair for this wave in the tile
-        const char* sq = qd + cur * QD_STAGE;
-        const char* sdo = sq + 8192;
-        const float* sL = (const float*)(sq + 16384);
+        const char* sqn = qd + cur * QD_STAGE;
+        const char* sqt = sqn + 8192;
+        const char* sdn = sqn + 16384;
+        const char* sdt = sqn + 24576;
+        const float* sL = (const float*)(sqn + 32768);
         const float* sD = sL + 32;
         const unsigned qm = qmask[it];
         int nvalid = S - q0; nvalid = nvalid > 32 ? 32 : nvalid;
@@ -342,19 +361,25 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         f32x16 s_s, s_c, p_s, p_c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s_s[r] = 0.f; s_c[r] = 0.f; p_s[r] = 0.f; p_c[r] = 0.f; }
-        // S = Q K^T, dP = dO V^T : A = Q / dO rows (16-byte row reads of the streamed image), B = resident K / V fragments
+        // S = Q K^T (both roles), dP = dO V^T (dK waves only): A = row image of the streamed tile, B = resident fragments
         if (wsame) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                s_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sq, l31, 2 * ks + fk), res_frag(rKs, l31, ks, fk), s_s, 0, 0, 0);
-                p_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sdo, l31, 2 * ks + fk), res_frag(rKs + 32768, l31, ks, fk), p_s, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks)
+                s_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sqn, l31, ks, fk, 4096), nfrag(rK, l31, ks, fk, 8192), s_s, 0, 0, 0);
+            if (role_dk) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    p_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sdn, l31, ks, fk, 4096), nfrag(rK + 32768, l31, ks, fk, 8192), p_s, 0, 0, 0);
             }
         }
         if (wcross) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                s_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sq, l31, 2 * ks + fk), res_frag(rKs + 16384, l31, ks, fk), s_c, 0, 0, 0);
-                p_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sdo, l31, 2 * ks + fk), res_frag(rKs + 49152, l31, ks, fk), p_c, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks)
+                s_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sqn, l31, ks, fk, 4096), nfrag(rK + 16384, l31, ks, fk, 8192), s_c, 0, 0, 0);
+            if (role_dk) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    p_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sdn, l31, ks, fk, 4096), nfrag(rK + 49152, l31, ks, fk, 8192), p_c, 0, 0, 0);
             }
         }
         // accumulator row r <-> query q0 + (r&3) + 8(r>>2) + 4fk ; column <-> this lane's key
@@ -374,38 +399,30 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                 const float dpv = cr ? p_c[r] : p_s[r];
                 const float pr = (qa >= kabs && qa < S && kabs < len && kin)
                                      ? __builtin_amdgcn_exp2f(sv * p.sl2 - Lv[e] * LOG2E) : 0.f;
-                s_s[r] = pr;                                      // P
-                p_s[r] = pr * (dpv - Dv[e]);                      // dS
+                s_s[r] = role_dk ? pr * (dpv - Dv[e]) : pr;       // dS for the dK waves, P for the dV waves
                 crossbits |= (cr ? 1u : 0u) << r;
             }
         }
+        const char* st = role_dk ? sqt : sdt;                     // Q^T fragments (dK) or dO^T fragments (dV)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
-            bf16x8 pS, pC, dS, dC;
-            split_pack(s_s, crossbits, sx, pS, pC);
-            split_pack(p_s, crossbits, sx, dS, dC);
+            bf16x8 bS, bC;
+            split_pack(s_s, crossbits, sx, bS, bC);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 dot = tread_t(sdo, lane, dw * 2 + dt, sx);   // dO^T[d][queries]
-                const bf16x8 qtf = tread_t(sq, lane, dw * 2 + dt, sx);    // Q^T[d][queries]
-                if (wsame) {
-                    dv_s[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pS, dv_s[dt], 0, 0, 0);
-                    dk_s[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dS, dk_s[dt], 0, 0, 0);
-                }
-                if (wcross) {
-                    dv_c[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pC, dv_c[dt], 0, 0, 0);
-                    dk_c[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dC, dk_c[dt], 0, 0, 0);
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 af = tread_t(st, lane, dt, sx);
+                if (wsame) acc_s[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bS, acc_s[dt], 0, 0, 0);
+                if (wcross) acc_c[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bC, acc_c[dt], 0, 0, 0);
             }
         }
     }
-    // ---- store: each wave's [64 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 136 B)
+    // ---- store: each wave's two [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
     __syncthreads();
-    constexpr int OROW = 136;
+    constexpr int OROW = 264;
     char* so = smem + wave * (32 * OROW);
     auto store = [&](const f32x16* acc, float mul, bf16_t* dst) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = dt * 32 + 8 * g + 4 * fk;
@@ -415,23 +432,21 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                 *(u32x2*)(so + l31 * OROW + d * 2) = w;
             }
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int r = pass * 8 + (lane >> 3);
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 4 + (lane >> 4);
             const int kk = kbase_w + r;
             if (kk < S) {
-                const char* src = so + r * OROW + (lane & 7) * 16;
+                const char* src = so + r * OROW + (lane & 15) * 16;
                 const u32x2 a = *(const u32x2*)src;
                 const u32x2 c2 = *(const u32x2*)(src + 8);
                 u32x4 v;
                 v[0] = a[0]; v[1] = a[1]; v[2] = c2[0]; v[3] = c2[1];
-                *(u32x4*)(dst + (tok0 + kk) * p.ldg + h * D128 + dw * 64 + (lane & 7) * 8) = v;
+                *(u32x4*)(dst + (tok0 + kk) * p.ldg + h * D128 + (lane & 15) * 8) = v;
             }
         }
     };
-    store(dk_s, p.scale, p.dk_same);
-    store(dk_c, p.scale, p.dk_cross);
-    store(dv_s, 1.0f, p.dv_same);
-    store(dv_c, 1.0f, p.dv_cross);
+    if (role_dk) { store(acc_s, p.scale, p.dk_same); store(acc_c, p.scale, p.dk_cross); }
+    else { store(acc_s, 1.0f, p.dv_same); store(acc_c, 1.0f, p.dv_cross); }
 }
 
 // delta[b,h,s] = sum_d dO * O   (16 lanes per (token, head), head_dim 128)

@@ -287,7 +287,7 @@ def _wg(dy_c: torch.Tensor, x_c: torch.Tensor) -> torch.Tensor:
     return K.gemm_nt(_full(dy_c), _full(x_c), a_t=True, b_t=True)
 
 
-def backward(sd, packed, d: DecDims, out, want):
+def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     """Gradients of out["loss"] w.r.t. every parameter name in `want` (a set) -> {name: bf16 grad}."""
     sv = out["saved"]
     flag, lang_idx, vis_idx = out["flag"], out["lang_idx"], out["vis_idx"]
@@ -303,7 +303,7 @@ def backward(sd, packed, d: DecDims, out, want):
     # ---- loss -> logits -> final hidden
     hidden = sv["hidden"]
     dhid = torch.zeros((N, H), dtype=BF16, device=dev)
-    coef = [float(1.0 / (sv["counts"][q].item() * Q)) for q in range(Q)]
+    coef = [float(gscale / (sv["counts"][q].item() * Q)) for q in range(Q)]       # upstream gradient folded into dlogits
     def head_pad(name):
         """Head weight with its vocab (the dgrad reduction length) zero-padded to the GEMM's 64 granule."""
         W = sd[name]

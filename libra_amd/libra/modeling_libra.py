@@ -247,14 +247,14 @@ class _LibraFunction(torch.autograd.Function):
     def backward(ctx, gloss):
         if ctx.out.get("saved") is None:
             raise RuntimeError("backward through LibraForCausalLM requested but no activations were saved")
-        grads = DE.backward(ctx.sd, ctx.model._packed, ctx.model._dims, ctx.out, ctx.want)
+        # the incoming scalar (1.0, or a loss scale / 1/accum factor) is folded into the logits gradient: one host read
+        # per step instead of one elementwise kernel per parameter
+        grads = DE.backward(ctx.sd, ctx.model._packed, ctx.model._dims, ctx.out, ctx.want, gscale=float(gloss))
         res = []
         for n in ctx.names:
             gr = grads.get(n) if n in ctx.want else None
             if gr is not None:
-                p = ctx.sd[n]
-                gr = gr.reshape(p.shape)
-                gr = gr * gloss.to(gr.dtype)
+                gr = gr.reshape(ctx.sd[n].shape)
             res.append(gr)
         ctx.out["saved"] = None
         return (None,) * 9 + tuple(res)
