@@ -21,9 +21,9 @@
 namespace libra {
 
 constexpr int BD = 128;            // head dim
-constexpr int BQ = 128;            // query rows per workgroup (4 waves x 32)
-constexpr int BKV = 32;            // keys per tile
-constexpr int VAR_BYTES = 2 * BKV * BD * 2;     // one variant: K tile (8 KiB) + V tile (8 KiB)
+constexpr int BQ = 256;            // query rows per workgroup (8 waves x 32)
+constexpr int BKV = 64;            // keys per tile (two 32-key halves)
+constexpr int VAR_BYTES = 2 * BKV * BD * 2;     // one variant: K tile (16 KiB) + V tile (16 KiB)
 constexpr int STAGE_BYTES = 2 * VAR_BYTES;      // same + cross
 constexpr int BR_LDS = 2 * STAGE_BYTES + 1024;  // double buffered + key-modality masks
 
@@ -39,33 +39,34 @@ struct BridgeArgs {
     float sl2;
 };
 
-// K tile image: two N-type [32 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 4 KiB each.
-// V tile image: T-type [32 keys][128 d] (256-byte rows, chunk ^ ((row&3)<<2)), 8 KiB.
-__device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ kp, long ldk, const bf16_t* __restrict__ vp, long ldv,
-                                         int key0, int S, char* dst, int wave, int lane) {
-    // K: 8 pieces of 1 KiB (8 rows x 128 B); piece pc -> sub-tile pc>>2, rows 8*(pc&3)..; wave w takes pieces 2w, 2w+1
+// K tile image: four N-type [32 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 4 KiB each, ordered
+//               (key half, d half).  V tile image: T-type [64 keys][128 d] (256-byte rows, chunk ^ ((row&3)<<2)), 16 KiB.
+__device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ kp, unsigned ldk_b, const bf16_t* __restrict__ vp,
+                                         unsigned ldv_b, int key0, int S, char* dst, int wave, int lane) {
+    // (kp, vp: wave-uniform sequence/head bases; ld*_b: row strides in bytes; per-lane part is a 32-bit byte offset)
+    // K: 16 pieces of 1 KiB (8 rows x 128 B); piece pc -> sub-tile pc>>2, rows 8*(pc&3)..; wave w takes pieces 2w, 2w+1
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pc = wave * 2 + j;
-        const int sub = pc >> 2, r = (pc & 3) * 8 + (lane >> 3);
+        const int st = pc >> 2, r = (pc & 3) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int key = key0 + r; key = key < S ? key : S - 1;
-        glds16(kp + (long)key * ldk + sub * 64 + c * 8, dst + pc * 1024);
+        int key = key0 + (st >> 1) * 32 + r; key = key < S ? key : S - 1;
+        glds16_off(kp, (unsigned)key * ldk_b + (unsigned)((st & 1) * 128 + c * 16), dst + pc * 1024);
     }
-    // V: 8 pieces of 1 KiB (4 rows x 256 B); wave w takes pieces 2w, 2w+1
+    // V: 16 pieces of 1 KiB (4 rows x 256 B); wave w takes pieces 2w, 2w+1
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pc = wave * 2 + j;
         const int r = pc * 4 + (lane >> 4);
         const int c = (lane & 15) ^ ((r & 3) << 2);
         int key = key0 + r; key = key < S ? key : S - 1;
-        glds16(vp + (long)key * ldv + c * 8, dst + 8192 + pc * 1024);
+        glds16_off(vp, (unsigned)key * ldv_b + (unsigned)(c * 16), dst + 16384 + pc * 1024);
     }
 }
 
-__global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArgs p) {
+__global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* kmask = (unsigned*)(smem + 2 * STAGE_BYTES);        // per 32-key tile: bit j = key j is a vision token
+    unsigned* kmask = (unsigned*)(smem + 2 * STAGE_BYTES);        // per 32 keys: bit j = key j is a vision token
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fk = lane >> 5, l31 = lane & 31;
@@ -83,10 +84,10 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
     int q = q0w + l31;
     q = q < S ? q : S - 1;
 
-    // ---- key-modality masks of this sequence into LDS (ballot over 32 flags per tile) ----
-    const int ntile_all = (S + BKV - 1) / BKV;
-    for (int t = wave; t < ntile_all; t += 4) {
-        const int key = t * BKV + l31;
+    // ---- key-modality masks of this sequence into LDS (ballot over 32 flags) ----
+    const int n32 = (S + 31) / 32;
+    for (int t = wave; t < n32 + 1; t += 8) {                       // one spare word so a ragged 64-key tile reads zeros
+        const int key = t * 32 + l31;
         const bool vis = (key < S) && (fk == 0) && p.flag[tok0 + key] != 0;
         const unsigned long long bal = __ballot(vis);
         if (lane == 0) kmask[t] = (unsigned)bal;
@@ -102,10 +103,9 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
         if (__ballot(valid && !q_vis)) if (lane == 0) atomicOr(&qpres[0], 1);
     }
     __syncthreads();
-    const bool blkL = qpres[0] != 0, blkV = qpres[1] != 0;
-    const unsigned long long wbal_v = __ballot(q_vis && (q0w + l31) < S);
-    const unsigned long long wbal_l = __ballot(!q_vis && (q0w + l31) < S);
-    const bool wV = wbal_v != 0, wL = wbal_l != 0;                  // this wave's query modalities
+    const bool blkL = __builtin_amdgcn_readfirstlane(qpres[0]) != 0, blkV = __builtin_amdgcn_readfirstlane(qpres[1]) != 0;
+    const bool wV = __ballot(q_vis && (q0w + l31) < S) != 0;        // this wave's query modalities
+    const bool wL = __ballot(!q_vis && (q0w + l31) < S) != 0;
 
     // ---- Q fragments: lane (q = l31, half fk) holds Q[q][16*ks + 8*fk .. +8], ks = 0..7 ----
     bf16x8 qf[8];
@@ -130,26 +130,67 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
     int kend = (qt + 1) * BQ; kend = kend < S ? kend : S;
     const int nkt = (kend + BKV - 1) / BKV;
 
-    auto needs = [&](int t, bool& same, bool& cross) {
-        const unsigned km = kmask[t];
-        int nvalid = S - t * BKV; nvalid = nvalid > BKV ? BKV : nvalid;
-        const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
-        const bool kV = (km & full) != 0, kL = ((~km) & full) != 0;
-        same = (blkL && kL) || (blkV && kV);
-        cross = (blkL && kV) || (blkV && kL);
+    // modality content of `n` keys starting at 32-key word w0 (n = 32 or 64), valid keys only
+    auto key_mods = [&](int w0, int n, bool& kV, bool& kL) {
+        // (readfirstlane: LDS data is wave-uniform here, and MFMAs under a branch the compiler believes divergent cost a
+        //  full copy of every accumulator they touch)
+        unsigned long long m = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0]);
+        if (n == 64) m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0 + 1]) << 32;
+        int nvalid = S - w0 * 32; nvalid = nvalid > n ? n : nvalid;
+        const unsigned long long full = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        kV = (m & full) != 0; kL = ((~m) & full) != 0;
     };
     auto stage = [&](int buf, int t) {
-        bool same, cross;
-        needs(t, same, cross);
+        bool kV, kL;
+        key_mods(2 * t, 64, kV, kL);
         char* dst = smem + buf * STAGE_BYTES;
-        if (same) stage_kv(ks_base, p.ldk, vs_base, p.ldv, t * BKV, S, dst, wave, lane);
-        if (cross) stage_kv(kc_base, p.ldkc, vc_base, p.ldvc, t * BKV, S, dst + VAR_BYTES, wave, lane);
+        if ((blkL && kL) || (blkV && kV))
+            stage_kv(ks_base, (unsigned)p.ldk * 2u, vs_base, (unsigned)p.ldv * 2u, t * BKV, S, dst, wave, lane);
+        if ((blkL && kV) || (blkV && kL))
+            stage_kv(kc_base, (unsigned)p.ldkc * 2u, vc_base, (unsigned)p.ldvc * 2u, t * BKV, S, dst + VAR_BYTES, wave, lane);
     };
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) pin(qf[ks]);                     // Q has landed before any LDS-DMA is in flight
     stage(0, 0);
 
-    // fragment addressing
-    const int pp = lane & 15, g16 = (lane >> 4) & 1;
-    const int vrow = (4 * fk + (pp >> 2)) * 256;                    // T-type V: keys 4*fk + (p>>2) (+8 for the 2nd read)
+    // fragment addressing.  The lane-derived LDS offsets are recomputed per tile from an opaque copy of the lane id:
+    // hoisted to kernel entry they are ten long-lived registers that hipcc spills around the tile loop, and a scratch
+    // reload inside the loop is a vmcnt(0) drain of the LDS-DMA queue.
+    int lane_o = lane;
+    // S^T (32 keys x 32 queries) of one key half from the K image at `kimg`
+    auto qk_half = [&](const char* kimg, f32x16& s) {
+        const int l31o = lane_o & 31, fko = lane_o >> 5;
+        const int kswz = (l31o >> 1) & 7;
+        const char* krow = kimg + l31o * 128;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int c = (2 * (ks & 3) + fko) ^ kswz;
+            const bf16x8 kf = *(const bf16x8*)(krow + (ks >> 2) * 4096 + (c << 4));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+    };
+    // O^T += V^T P^T for one 16-key step: `vstep` = V image + 4096 * step
+    auto pv_step = [&](const char* vstep, const bf16x8 pk) {
+        const int pp = lane_o & 15, g16 = (lane_o >> 4) & 1;
+        const char* vrow = vstep + (4 * (lane_o >> 5) + (pp >> 2)) * 256 + ((pp & 1) << 3);   // keys 4fk + (p>>2), 2nd read +8
+        const int tlo = (2 * g16 + ((pp & 3) >> 1)) << 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            // 32-line block dt of the 128-line (d) T-type tile
+            const char* a = vrow + ((((dt ^ (pp >> 2)) & 3) << 6) | tlo);
+            union { bf16x8 v; s16x4 h2[2]; } va;
+            va.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
+            va.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pk, o[dt], 0, 0, 0);
+        }
+    };
+    auto rescale = [&](float alpha) {
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    };
 
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -159,104 +200,94 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_fwd_kernel(const BridgeArg
         if (!active) continue;
         const int kv0 = kt * BKV;
         if (kv0 > q0w + 31) continue;                               // tile entirely above this wave's diagonal
-        bool bsame, bcross;
-        needs(kt, bsame, bcross);
-        const unsigned km = kmask[kt];
-        // wave-level needs (subset of the block-level ones)
-        int nvalid = S - kv0; nvalid = nvalid > BKV ? BKV : nvalid;
-        const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
-        const bool kV = (km & full) != 0, kL = ((~km) & full) != 0;
+        asm volatile("" : "+v"(lane_o));
+        const char* sks = smem + cur * STAGE_BYTES;                 // same variant: K (4 x 4 KiB), V at +16384
+        const char* skc = sks + VAR_BYTES;
+        bool kV, kL;
+        key_mods(2 * kt, 64, kV, kL);
         const bool wsame = (wL && kL) || (wV && kV);
         const bool wcross = (wL && kV) || (wV && kL);
-        const char* sks = smem + cur * STAGE_BYTES;                 // K same (2 x 4 KiB), V same at +8192
-        const char* skc = sks + VAR_BYTES;
 
-        // ---- S^T = K Q^T (32 keys x 32 queries), per needed variant ----
-        f32x16 s_s, s_c;
+        const bool mixed = wsame && wcross;                         // both variants present: select per element
+        const char* img1 = wsame ? sks : skc;                       // primary variant (same unless only cross is needed)
+
+        // ---- S^T = K Q^T, 64 keys x 32 queries ----
+        f32x16 sA, sB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s_s[r] = 0.f; s_c[r] = 0.f; }
-        if (wsame) {
+        for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; }
+        qk_half(img1, sA);
+        qk_half(img1 + 8192, sB);
+        unsigned crA = 0, crB = 0;                                  // bit r: element r takes the cross variant (mixed tiles)
+        if (mixed) {
+            f32x16 tA, tB;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int sub = ks >> 2, c = (2 * (ks & 3) + fk) ^ ((l31 >> 1) & 7);
-                const bf16x8 kf = *(const bf16x8*)(sks + sub * 4096 + l31 * 128 + (c << 4));
-                s_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_s, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) { tA[r] = 0.f; tB[r] = 0.f; }
+            qk_half(skc, tA);
+            qk_half(skc + 8192, tB);
+            const unsigned km0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt]);
+            const unsigned km1 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + 1]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = (r & 3) + 8 * (r >> 2) + 4 * fk;     // local key of accumulator row r
+                const bool ca = (((km0 >> kl) & 1u) != 0) != q_vis, cb = (((km1 >> kl) & 1u) != 0) != q_vis;
+                sA[r] = ca ? tA[r] : sA[r];
+                sB[r] = cb ? tB[r] : sB[r];
+                crA |= (ca ? 1u : 0u) << r;
+                crB |= (cb ? 1u : 0u) << r;
             }
         }
-        if (wcross) {
+        if (kv0 + BKV - 1 > q0w || kv0 + BKV > len) {               // causal diagonal / padded keys inside this tile
+            const int qabs = q0w + l31;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int sub = ks >> 2, c = (2 * (ks & 3) + fk) ^ ((l31 >> 1) & 7);
-                const bf16x8 kf = *(const bf16x8*)(skc + sub * 4096 + l31 * 128 + (c << 4));
-                s_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_c, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                sA[r] = (key <= qabs && key < len) ? sA[r] : -INFINITY;
+                sB[r] = (key + 32 <= qabs && key + 32 < len) ? sB[r] : -INFINITY;
             }
         }
-        // ---- select per element, scale, mask, online softmax ----
-        const int qabs = q0w + l31;
-        float tmax = -INFINITY;
-        unsigned crossbits = 0;                                     // bit r: element r uses the cross variant
+        // ---- online softmax; the running max only advances when a tile exceeds it by 2^DEFER_THR ----
+        float tmax = max3f(sA[0], sA[1], sB[0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * fk;         // local key of accumulator row r
-            const int key = kv0 + kl;
-            const bool kvis = (km >> kl) & 1u;
-            const bool cr = kvis != q_vis;
-            float v = (cr ? s_c[r] : s_s[r]) * p.sl2;
-            v = (key <= qabs && key < len) ? v : -INFINITY;
-            s_s[r] = v;
-            crossbits |= (cr ? 1u : 0u) << r;
-            tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        for (int r = 2; r < 16; r += 2) tmax = max3f(tmax, sA[r], sA[r + 1]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) tmax = max3f(tmax, sB[r], sB[r + 1]);
+        tmax = fmaxf(tmax, sB[15]);
+        tmax = half_swap_max(tmax * p.sl2);
         const float m_new = fmaxf(m_run, tmax);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;       // fully masked so far: keep everything at 0
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
+        if (__any(m_new > m_run + DEFER_THR)) {                     // wave-uniform; the first tile always lands here
+            rescale(__builtin_amdgcn_exp2f(m_run - m_new));
+            m_run = m_new;
+        }
+        const float nm = m_run == -INFINITY ? 0.f : -m_run;         // (a row with no visible key yet stays at exactly 0)
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(s_s[r] - m_use);
-            s_s[r] = e;
-            psum += e;
+            sA[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sA[r], p.sl2, nm));
+            sB[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sB[r], p.sl2, nm));
+            psum += sA[r] + sB[r];
         }
-        l_run = l_run * alpha + psum;
+        l_run += psum;
+        // ---- O^T += V^T P^T; k-step st consumes accumulator regs 8(st&1)..+7 of half st>>1 = local keys
+        //      32(st>>1) + 16(st&1) + 4fk + {0..3, 8..11}
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-
-        // ---- O^T += V^T P^T per variant; k-step sx consumes accumulator regs 8sx..8sx+7 = local keys
-        //      16sx + 4fk + {0..3, 8..11}
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            union { bf16x8 v; unsigned u[4]; } ps, pc;
+        for (int st = 0; st < 4; ++st) {
+            union { bf16x8 v; unsigned u[4]; } pk, pk2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int r0 = 8 * sx + 2 * j, r1 = r0 + 1;
-                const float a0 = s_s[r0], a1 = s_s[r1];
-                const bool c0 = (crossbits >> r0) & 1u, c1 = (crossbits >> r1) & 1u;
-                ps.u[j] = pack2bf(c0 ? 0.f : a0, c1 ? 0.f : a1);
-                pc.u[j] = pack2bf(c0 ? a0 : 0.f, c1 ? a1 : 0.f);
+                const int r0 = 8 * (st & 1) + 2 * j;
+                pk.u[j] = st < 2 ? pack2bf(sA[r0], sA[r0 + 1]) : pack2bf(sB[r0], sB[r0 + 1]);
             }
+            if (mixed) {                                            // split P by variant (bf16 pair masks)
+                const unsigned cr = (st < 2 ? crA : crB) >> (8 * (st & 1));
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                // 32-line block dt of the 128-line (d) T-type tile; key rows 16sx + 4fk + (p>>2), second read +8
-                const int toff = (((((dt ^ (pp >> 2)) & 3) << 2) | (2 * g16 + ((pp & 3) >> 1))) << 4) + ((pp & 1) << 3);
-                if (wsame) {
-                    const char* a = sks + 8192 + sx * 4096 + vrow + toff;
-                    union { bf16x8 v; s16x4 h2[2]; } va;
-                    va.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
-                    va.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, ps.v, o[dt], 0, 0, 0);
-                }
-                if (wcross) {
-                    const char* a = skc + 8192 + sx * 4096 + vrow + toff;
-                    union { bf16x8 v; s16x4 h2[2]; } va;
-                    va.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
-                    va.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pc.v, o[dt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned keep2 = (((cr >> (2 * j)) & 1u) ? 0xffffu : 0u) | (((cr >> (2 * j + 1)) & 1u) ? 0xffff0000u : 0u);
+                    pk2.u[j] = pk.u[j] & keep2;
+                    pk.u[j] &= ~keep2;
                 }
             }
+            pv_step(img1 + 16384 + st * 4096, pk.v);
+            if (mixed) pv_step(skc + 16384 + st * 4096, pk2.v);
         }
     }
 
@@ -310,7 +341,8 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
                                      const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
                                      int64_t H, float scale, void* stream) {
     if (B <= 0 || S <= 0) return LIBRA_OK;
-    if (H <= 0 || ldq < H * BD || ldk < H * BD || ldv < H * BD || ldkc < H * BD || ldvc < H * BD || ldo < H * BD || S > 4096)
+    if (H <= 0 || ldq < H * BD || ldk < H * BD || ldv < H * BD || ldkc < H * BD || ldvc < H * BD || ldo < H * BD || S > 4096 ||
+        ldk >= (1 << 18) || ldkc >= (1 << 18) || ldv >= (1 << 18) || ldvc >= (1 << 18))
         return LIBRA_ERR_SHAPE;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldkc % 8) || (ldvc % 8) || (ldo % 8)) return LIBRA_ERR_ALIGN;
     if (!q || !k_same || !k_cross || !v_same || !v_cross || !flag || !out) return LIBRA_ERR_ALIGN;
@@ -329,6 +361,6 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
         (void)hipFuncSetAttribute((const void*)bridge_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(bridge_attn_fwd_kernel, dim3((unsigned)nblk), dim3(256), BR_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_fwd_kernel, dim3((unsigned)nblk), dim3(512), BR_LDS, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -37,28 +37,48 @@ struct BridgeBwdArgs {
     float sl2, scale;
 };
 
-// reduction-major image of a [32 rows][128 d] tile (256-byte rows, chunk ^ ((row&3)<<2)); 8 pieces of 1 KiB.
+// Reduction-major image of a [rows][128 d] tile: 256-byte rows, 16-byte chunk c of row r stored at position
+// c ^ tswz(r).  tswz mixes (r&3) into the chunk's high bits (what the transpose read ds_read_b64_tr_b16 needs to be
+// conflict free) and (r>>2)&3 into its low bits, which also spreads the 16 rows of a ds_read_b128 lane group over
+// all 64 banks: one image serves BOTH the row-fragment reads (A/B operand with k = d) and the transposed reads
+// (A operand with k = rows).  [With only the (r&3) term, row reads were 4-way conflicted: 65 % of the dQ pass's LDS
+// cycles in the round-1 PMC profile.]
+__device__ __forceinline__ int tswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
 __device__ __forceinline__ void stage_t32(const bf16_t* __restrict__ base, long ld, int row0, int nrows, char* dst,
                                           int wave, int lane, int nwaves) {
     for (int pc = wave; pc < 8; pc += nwaves) {
         const int r = pc * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ ((r & 3) << 2);
+        const int c = (lane & 15) ^ tswz(r);
         int row = row0 + r; row = row < nrows ? row : nrows - 1;
         glds16(base + (long)row * ld + c * 8, dst + pc * 1024);
     }
 }
+// [64 rows][128 d] image, 16 pieces of 1 KiB over 8 waves; base is wave-uniform, ld_b = row stride in bytes
+__device__ __forceinline__ void stage_t64(const bf16_t* __restrict__ base, unsigned ld_b, int row0, int nrows, char* dst,
+                                          int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pc = wave * 2 + j;
+        const int r = pc * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ tswz(r);
+        int row = row0 + r; row = row < nrows ? row : nrows - 1;
+        glds16_off(base, (unsigned)row * ld_b + (unsigned)(c * 16), dst + pc * 1024);
+    }
+}
 // 16-byte row read (8 consecutive d of one row) from the reduction-major image
 __device__ __forceinline__ bf16x8 nread_t(const char* tile, int row, int chunk) {
-    return *(const bf16x8*)(tile + row * 256 + ((chunk ^ ((row & 3) << 2)) << 4));
+    return *(const bf16x8*)(tile + row * 256 + ((chunk ^ tswz(row)) << 4));
 }
 // transpose read: A-operand fragment X^T[d = 32*dt + l31][rows 16*sx + 4*fk + {0..3, 8..11}]
 __device__ __forceinline__ bf16x8 tread_t(const char* tile, int lane, int dt, int sx) {
     const int pp = lane & 15, g16 = (lane >> 4) & 1, fk = lane >> 5;
-    const int toff = (((((dt ^ (pp >> 2)) & 3) << 2) | (2 * g16 + ((pp & 3) >> 1))) << 4) + ((pp & 1) << 3);
-    const char* a = tile + sx * 4096 + (4 * fk + (pp >> 2)) * 256 + toff;
+    const int r1 = 16 * sx + 4 * fk + (pp >> 2);
+    const int chunk = dt * 4 + 2 * g16 + ((pp & 3) >> 1);
+    const char* a = tile + r1 * 256 + ((pp & 1) << 3);
     union { bf16x8 v; s16x4 h2[2]; } u;
-    u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
-    u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
+    u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + ((chunk ^ tswz(r1)) << 4)));
+    u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048 + ((chunk ^ tswz(r1 + 8)) << 4)));
     return u.v;
 }
 __device__ __forceinline__ void split_pack(const f32x16& a, unsigned crossbits, int sx, bf16x8& same, bf16x8& cross) {
@@ -74,12 +94,14 @@ __device__ __forceinline__ void split_pack(const f32x16& a, unsigned crossbits, 
 }
 
 // ================================================================================================
-// dQ pass
-constexpr int DQ_VAR = 16384;                 // K tile 8 KiB + V tile 8 KiB (32 keys)
-constexpr int DQ_STAGE_B = 2 * DQ_VAR;
+// dQ pass: 8 waves x 32 queries per workgroup, 64-key tiles (two 32-key halves per barrier), per variant one K image
+// (row reads for S^T = K Q^T, transposed reads for dQ^T += K^T dS^T) and one V image (row reads for dP^T = V dO^T).
+constexpr int DQ_VAR = 32768;                 // K tile 16 KiB + V tile 16 KiB (64 keys)
+constexpr int DQ_STAGE_B = 2 * DQ_VAR;        // same + cross
 constexpr int DQ_LDS_B = 2 * DQ_STAGE_B + 1024;
+constexpr int DQ_BQ = 256;
 
-__global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const BridgeBwdArgs p) {
+__global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* kmask = (unsigned*)(smem + 2 * DQ_STAGE_B);
     int* qpres = (int*)(kmask + 192);
@@ -94,14 +116,14 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
     const int S = p.S;
     const long tok0 = (long)b * S;
     const int len = p.kv_len ? p.kv_len[b] : S;
-    const int q0w = qt * 128 + wave * 32;
+    const int q0w = qt * DQ_BQ + wave * 32;
     const bool active = q0w < S;
     int q = q0w + l31;
     const bool qin = q < S;
     q = qin ? q : S - 1;
 
-    const int ntile_all = (S + 31) / 32;
-    for (int t = wave; t < ntile_all; t += 4) {
+    const int n32 = (S + 31) / 32;
+    for (int t = wave; t < n32 + 1; t += 8) {
         const int key = t * 32 + l31;
         const bool vis = (key < S) && (fk == 0) && p.flag[tok0 + key] != 0;
         const unsigned long long bal = __ballot(vis);
@@ -113,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
     if (__ballot(qin && fk == 0 && q_vis)) if (lane == 0) atomicOr(&qpres[1], 1);
     if (__ballot(qin && fk == 0 && !q_vis)) if (lane == 0) atomicOr(&qpres[0], 1);
     __syncthreads();
-    const bool blkL = qpres[0] != 0, blkV = qpres[1] != 0;
+    const bool blkL = __builtin_amdgcn_readfirstlane(qpres[0]) != 0, blkV = __builtin_amdgcn_readfirstlane(qpres[1]) != 0;
     const bool wV = __ballot(q_vis && qin) != 0, wL = __ballot(!q_vis && qin) != 0;
 
     bf16x8 qf[8], dof[8];
@@ -124,8 +146,11 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
         for (int ks = 0; ks < 8; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 16); dof[ks] = *(const bf16x8*)(dp + ks * 16); }
     }
     const long sidx = ((long)b * p.H + h) * S + q;
-    const float Lq2 = p.lse[sidx] * LOG2E;
-    const float Dq = p.delta[sidx];
+    float nLq2 = -p.lse[sidx] * LOG2E;
+    float Dq = p.delta[sidx];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { pin(qf[ks]); pin(dof[ks]); }   // prologue loads have landed before any LDS-DMA is in flight
+    pin(nLq2); pin(Dq);
     const bf16_t* ks_base = p.k_same + tok0 * p.ldk + h * D128;
     const bf16_t* kc_base = p.k_cross + tok0 * p.ldkc + h * D128;
     const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * D128;
@@ -137,24 +162,31 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    int kend = (qt + 1) * 128; kend = kend < S ? kend : S;
-    const int nkt = (kend + 31) / 32;
-    auto needs = [&](int t, bool bL, bool bV, bool& same, bool& cross) {
-        const unsigned km = kmask[t];
-        int nvalid = S - t * 32; nvalid = nvalid > 32 ? 32 : nvalid;
-        const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
-        const bool kV = (km & full) != 0, kL = ((~km) & full) != 0;
-        same = (bL && kL) || (bV && kV);
-        cross = (bL && kV) || (bV && kL);
+    int kend = (qt + 1) * DQ_BQ; kend = kend < S ? kend : S;
+    const int nkt = (kend + 63) / 64;
+    // modality content of `n` (32 or 64) keys starting at mask word w0, valid keys only (wave-uniform by construction)
+    auto key_mods = [&](int w0, int n, bool& kV, bool& kL) {
+        unsigned long long m = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0]);
+        if (n == 64) m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0 + 1]) << 32;
+        int nvalid = S - w0 * 32; nvalid = nvalid > n ? n : nvalid;
+        const unsigned long long full = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        kV = (m & full) != 0; kL = ((~m) & full) != 0;
     };
     auto stage = [&](int buf, int t) {
-        bool same, cross;
-        needs(t, blkL, blkV, same, cross);
+        bool kV, kL;
+        key_mods(2 * t, 64, kV, kL);
         char* dst = smem + buf * DQ_STAGE_B;
-        if (same) { stage_t32(ks_base, p.ldk, t * 32, S, dst, wave, lane, 4); stage_t32(vs_base, p.ldv, t * 32, S, dst + 8192, wave, lane, 4); }
-        if (cross) { stage_t32(kc_base, p.ldkc, t * 32, S, dst + DQ_VAR, wave, lane, 4); stage_t32(vc_base, p.ldvc, t * 32, S, dst + DQ_VAR + 8192, wave, lane, 4); }
+        if ((blkL && kL) || (blkV && kV)) {
+            stage_t64(ks_base, (unsigned)p.ldk * 2u, t * 64, S, dst, wave, lane);
+            stage_t64(vs_base, (unsigned)p.ldv * 2u, t * 64, S, dst + 16384, wave, lane);
+        }
+        if ((blkL && kV) || (blkV && kL)) {
+            stage_t64(kc_base, (unsigned)p.ldkc * 2u, t * 64, S, dst + DQ_VAR, wave, lane);
+            stage_t64(vc_base, (unsigned)p.ldvc * 2u, t * 64, S, dst + DQ_VAR + 16384, wave, lane);
+        }
     };
     stage(0, 0);
+    int lane_o = lane;                                              // (see the forward kernel: per-tile recomputed LDS offsets)
 
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -162,49 +194,80 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
         const int cur = kt & 1;
         if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
         if (!active) continue;
-        const int kv0 = kt * 32;
+        const int kv0 = kt * 64;
         if (kv0 > q0w + 31) continue;
-        bool wsame, wcross;
-        needs(kt, wL, wV, wsame, wcross);
-        const unsigned km = kmask[kt];
-        const char* sks = smem + cur * DQ_STAGE_B;
-        const char* skc = sks + DQ_VAR;
-        f32x16 s_s, s_c, p_s, p_c;
+        asm volatile("" : "+v"(lane_o));
+        const int l31o = lane_o & 31, fko = lane_o >> 5;
+#pragma unroll 1
+        for (int kh = 0; kh < 2; ++kh) {
+            const int k0 = kv0 + kh * 32;
+            if (k0 > q0w + 31 || k0 >= S) break;
+            bool hV, hL;
+            key_mods(2 * kt + kh, 32, hV, hL);
+            const bool hsame = (wL && hL) || (wV && hV);
+            const bool hcross = (wL && hV) || (wV && hL);
+            const bool mixed = hsame && hcross;
+            const char* skc = smem + cur * DQ_STAGE_B + DQ_VAR + kh * 8192;     // cross variant: K rows of this half (V at +16384)
+            const char* img1 = hsame ? skc - DQ_VAR : skc;                      // primary variant
+            f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s_s[r] = 0.f; s_c[r] = 0.f; p_s[r] = 0.f; p_c[r] = 0.f; }
-        if (wsame) {
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) s_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sks, l31, 2 * ks + fk), qf[ks], s_s, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(img1, l31o, 2 * ks + fko), qf[ks], s, 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) p_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sks + 8192, l31, 2 * ks + fk), dof[ks], p_s, 0, 0, 0);
-        }
-        if (wcross) {
+            for (int ks = 0; ks < 8; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(img1 + 16384, l31o, 2 * ks + fko), dof[ks], dp, 0, 0, 0);
+            unsigned crossbits = 0;
+            if (mixed) {                                            // both variants present: per-element select
+                f32x16 t, u;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) s_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(skc, l31, 2 * ks + fk), qf[ks], s_c, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) { t[r] = 0.f; u[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) p_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(skc + 8192, l31, 2 * ks + fk), dof[ks], p_c, 0, 0, 0);
-        }
-        const int qabs = q0w + l31;
-        unsigned crossbits = 0;
+                for (int ks = 0; ks < 8; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(skc, l31o, 2 * ks + fko), qf[ks], t, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * fk;
-            const int key = kv0 + kl;
-            const bool cr = (((km >> kl) & 1u) != 0) != q_vis;
-            const float sv = cr ? s_c[r] : s_s[r];
-            const float dpv = cr ? p_c[r] : p_s[r];
-            const float pr = (key <= qabs && key < len) ? __builtin_amdgcn_exp2f(sv * p.sl2 - Lq2) : 0.f;
-            s_s[r] = pr * (dpv - Dq);                               // dS^T
-            crossbits |= (cr ? 1u : 0u) << r;
-        }
+                for (int ks = 0; ks < 8; ++ks) u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(skc + 16384, l31o, 2 * ks + fko), dof[ks], u, 0, 0, 0);
+                const unsigned km = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + kh]);
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            bf16x8 ds_same, ds_cross;
-            split_pack(s_s, crossbits, sx, ds_same, ds_cross);
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const bool cr = (((km >> kl) & 1u) != 0) != q_vis;
+                    s[r] = cr ? t[r] : s[r];
+                    dp[r] = cr ? u[r] : dp[r];
+                    crossbits |= (cr ? 1u : 0u) << r;
+                }
+            }
+            // P = exp2(S*sl2 - L) (recomputed), dS^T = P (dP - D)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                if (wsame) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(sks, lane, dt, sx), ds_same, dq[dt], 0, 0, 0);
-                if (wcross) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(skc, lane, dt, sx), ds_cross, dq[dt], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.sl2, nLq2));
+            if (k0 + 31 > q0w || k0 + 32 > len) {                   // causal diagonal / padded keys inside this half
+                const int qabs = q0w + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    s[r] = (key <= qabs && key < len) ? s[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= dp[r] - Dq;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                union { bf16x8 v; unsigned u[4]; } pk, pk2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
+                if (mixed) {                                        // split dS by variant (bf16 pair masks)
+                    const unsigned cr = crossbits >> (8 * sx);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned keep2 = (((cr >> (2 * j)) & 1u) ? 0xffffu : 0u) | (((cr >> (2 * j + 1)) & 1u) ? 0xffff0000u : 0u);
+                        pk2.u[j] = pk.u[j] & keep2;
+                        pk.u[j] &= ~keep2;
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(img1, lane_o, dt, sx), pk.v, dq[dt], 0, 0, 0);
+                if (mixed) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(skc, lane_o, dt, sx), pk2.v, dq[dt], 0, 0, 0);
+                }
             }
         }
     }
@@ -242,31 +305,24 @@ __global__ __launch_bounds__(256, 2) void bridge_attn_bwd_dq_kernel(const Bridge
 }
 
 // ================================================================================================
-// dK / dV pass
+// dK / dV pass.  One workgroup owns 64 keys of one (sequence, head): their four operand tiles (K/V, same/cross) stay
+// resident in LDS; 64-query tiles of Q and dO stream through a 2-deep ring (one reduction-major image each: row reads
+// for S = Q K^T / dP = dO V^T, transposed reads for dV^T += dO^T P / dK^T += Q^T dS).  8 waves = 2 roles (waves 0-3
+// accumulate dV, waves 4-7 dK: a workgroup's waves w and w+4 share a SIMD, so every SIMD carries one of each) x 2 key
+// sub-blocks of 32 x 2 query halves of the streamed tile; the two query halves' partial sums meet in LDS at the end.
 constexpr int KV_RES = 4 * 16384;             // resident K_same, K_cross, V_same, V_cross: [64 keys][128 d] each
-constexpr int QD_STAGE = 4 * 8192 + 256;      // Q row image, Q reduction-major image, dO row image, dO r-m image, L[32], D[32]
+constexpr int QD_STAGE = 2 * 16384 + 512;     // Q image, dO image (64 queries each), L[64], D[64]
 constexpr int DKV_LDS_B = KV_RES + 2 * QD_STAGE + 1024;
 
-// resident operand tile: two N-type [64 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 16 KiB
-__device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, long ld, int key0, int S, char* dst, int wave, int lane) {
+// resident operand tile: two N-type [64 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 16 KiB; 8 waves
+__device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, unsigned ld_b, int key0, int S, char* dst, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pc = wave * 4 + j;                 // 16 pieces of 1 KiB: sub-tile pc>>3, rows 8*(pc&7)..
+    for (int j = 0; j < 2; ++j) {
+        const int pc = wave * 2 + j;                 // 16 pieces of 1 KiB: sub-tile pc>>3, rows 8*(pc&7)..
         const int sub = pc >> 3, r = (pc & 7) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int key = key0 + r; key = key < S ? key : S - 1;
-        glds16(base + (long)key * ld + sub * 64 + c * 8, dst + pc * 1024);
-    }
-}
-// row image of a [32 rows][128 d] tile: two N-type [32][64] sub-tiles (4 KiB each); 8 pieces of 1 KiB over 4 waves
-__device__ __forceinline__ void stage_n32(const bf16_t* __restrict__ base, long ld, int row0, int nrows, char* dst, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pc = wave * 2 + j;
-        const int sub = pc >> 2, r = (pc & 3) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int row = row0 + r; row = row < nrows ? row : nrows - 1;
-        glds16(base + (long)row * ld + sub * 64 + c * 8, dst + pc * 1024);
+        glds16_off(base, (unsigned)key * ld_b + (unsigned)(sub * 128 + c * 16), dst + pc * 1024);
     }
 }
 // fragment (row, 8 consecutive d of k-step ks) of a row image whose sub-tiles are `sub_bytes` apart
@@ -275,15 +331,15 @@ __device__ __forceinline__ bf16x8 nfrag(const char* tile, int row, int ks, int f
     return *(const bf16x8*)(tile + sub * sub_bytes + row * 128 + (c << 4));
 }
 
-__global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
+__global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* res = smem;                                            // Ks, Kc, Vs, Vc
     char* qd = smem + KV_RES;
-    unsigned* qmask = (unsigned*)(smem + KV_RES + 2 * QD_STAGE); // per 32-query tile: bit i = query i is a vision token
+    unsigned* qmask = (unsigned*)(smem + KV_RES + 2 * QD_STAGE); // per 32 queries: bit i = query i is a vision token
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kw = wave & 1;
-    const bool role_dk = (wave >> 1) != 0;                       // waves 0,1: dV; waves 2,3: dK
+    const int kw = wave & 1, qh = (wave >> 1) & 1;
+    const bool role_dk = (wave >> 2) != 0;                       // waves 0-3: dV; waves 4-7: dK
     const int fk = lane >> 5, l31 = lane & 31;
     const int nblk = p.B * p.H * p.n_t;
     const int L = xcd_remap(blockIdx.x, nblk);
@@ -292,26 +348,29 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
     const long tok0 = (long)b * S;
-    const int len = p.kv_len ? p.kv_len[b] : S;
+    int len = p.kv_len ? p.kv_len[b] : S;
+    len = len < S ? len : S;
     const int key0 = ktile * 64;
     const int kbase_w = key0 + kw * 32;
     int key = kbase_w + l31;
     const bool kin = key < S;
     key = kin ? key : S - 1;
-    const bool k_vis = p.flag[tok0 + key] != 0;
+    int k_vis_i = p.flag[tok0 + key] != 0;
+    pin(k_vis_i);
+    const bool k_vis = k_vis_i != 0;
     const bool wkV = __ballot(k_vis && kin) != 0, wkL = __ballot(!k_vis && kin) != 0;
 
-    const int ntile_all = (S + 31) / 32;
-    for (int t = wave; t < ntile_all; t += 4) {
+    const int n32 = (S + 31) / 32;
+    for (int t = wave; t < n32 + 1; t += 8) {
         const int qq = t * 32 + l31;
         const bool vis = (qq < S) && (fk == 0) && p.flag[tok0 + qq] != 0;
         const unsigned long long bal = __ballot(vis);
         if (lane == 0) qmask[t] = (unsigned)bal;
     }
-    stage_res64(p.k_same + tok0 * p.ldk + h * D128, p.ldk, key0, S, res, wave, lane);
-    stage_res64(p.k_cross + tok0 * p.ldkc + h * D128, p.ldkc, key0, S, res + 16384, wave, lane);
-    stage_res64(p.v_same + tok0 * p.ldv + h * D128, p.ldv, key0, S, res + 32768, wave, lane);
-    stage_res64(p.v_cross + tok0 * p.ldvc + h * D128, p.ldvc, key0, S, res + 49152, wave, lane);
+    stage_res64(p.k_same + tok0 * p.ldk + h * D128, (unsigned)p.ldk * 2u, key0, S, res, wave, lane);
+    stage_res64(p.k_cross + tok0 * p.ldkc + h * D128, (unsigned)p.ldkc * 2u, key0, S, res + 16384, wave, lane);
+    stage_res64(p.v_same + tok0 * p.ldv + h * D128, (unsigned)p.ldv * 2u, key0, S, res + 32768, wave, lane);
+    stage_res64(p.v_cross + tok0 * p.ldvc + h * D128, (unsigned)p.ldvc * 2u, key0, S, res + 49152, wave, lane);
 
     const bf16_t* qbase = p.q + tok0 * p.ldq + h * D128;
     const bf16_t* dobase = p.dout + tok0 * p.ldo + h * D128;
@@ -319,105 +378,149 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     const float* dbase = p.delta + ((long)b * p.H + h) * S;
     auto stage_q = [&](int buf, int t) {
         char* dst = qd + buf * QD_STAGE;
-        stage_n32(qbase, p.ldq, t * 32, S, dst, wave, lane);                    // Q rows      (first-stage A operand)
-        stage_t32(qbase, p.ldq, t * 32, S, dst + 8192, wave, lane, 4);          // Q, r-m image (Q^T fragments for dK)
-        stage_n32(dobase, p.ldo, t * 32, S, dst + 16384, wave, lane);           // dO rows
-        stage_t32(dobase, p.ldo, t * 32, S, dst + 24576, wave, lane, 4);        // dO, r-m image (dO^T fragments for dV)
-        if (wave < 2 && lane < 32) {
-            int qi = t * 32 + lane; qi = qi < S ? qi : S - 1;
-            const float* src = (wave == 0 ? lbase : dbase) + qi;
-            __builtin_amdgcn_global_load_lds((const LIBRA_GLB void*)src, (LIBRA_LDS void*)(dst + 32768 + wave * 128), 4, 0, 0);
+        stage_t64(qbase, (unsigned)p.ldq * 2u, t * 64, S, dst, wave, lane);
+        stage_t64(dobase, (unsigned)p.ldo * 2u, t * 64, S, dst + 16384, wave, lane);
+        if (wave < 2) {                                          // 64 fp32 each: one 4-byte direct-to-LDS op
+            int qi = t * 64 + lane; qi = qi < S ? qi : S - 1;
+            glds4((wave == 0 ? lbase : dbase) + qi, dst + 32768 + wave * 256);
         }
     };
-    const int qt0 = key0 / 32;                                   // first query tile that can see this key block
-    const int nqt = ntile_all;
+    const int it0 = key0 / 64;                                   // first query tile that can see this key block
+    const int nqt = (S + 63) / 64;
     f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_s[i][r] = 0.f; acc_c[i][r] = 0.f; }
-    if (qt0 < nqt) stage_q(0, qt0);
+    if (it0 < nqt) stage_q(0, it0);
 
     const char* rK = res + kw * 32 * 128;                         // this wave's 32 key rows inside each 64-row sub-tile
-    for (int it = qt0; it < nqt; ++it) {
+    int lane_o = lane;
+    for (int it = it0; it < nqt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int cur = (it - qt0) & 1;
+        const int cur = (it - it0) & 1;
         if (it + 1 < nqt) stage_q(cur ^ 1, it + 1);
-        const int q0 = it * 32;
-        if (kbase_w >= S || q0 + 31 < kbase_w) continue;          // no (query >= key) pair for this wave in the tile
-        const char* sqn = qd + cur * QD_STAGE;
-        const char* sqt = sqn + 8192;
-        const char* sdn = sqn + 16384;
-        const char* sdt = sqn + 24576;
-        const float* sL = (const float*)(sqn + 32768);
-        const float* sD = sL + 32;
-        const unsigned qm = qmask[it];
+        const int q0 = it * 64 + qh * 32;
+        if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
+        asm volatile("" : "+v"(lane_o));
+        const int l31o = lane_o & 31, fko = lane_o >> 5;
+        const char* sq = qd + cur * QD_STAGE + qh * 8192;         // this wave's 32 query rows of the Q image (dO at +16384)
+        const float* sL = (const float*)(qd + cur * QD_STAGE + 32768) + qh * 32;
+        const float* sD = sL + 64;
+        const unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[2 * it + qh]);
         int nvalid = S - q0; nvalid = nvalid > 32 ? 32 : nvalid;
         const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
         const bool qV = (qm & full) != 0, qL = ((~qm) & full) != 0;
         const bool wsame = (qL && wkL) || (qV && wkV);
         const bool wcross = (qL && wkV) || (qV && wkL);
-        f32x16 s_s, s_c, p_s, p_c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s_s[r] = 0.f; s_c[r] = 0.f; p_s[r] = 0.f; p_c[r] = 0.f; }
-        // S = Q K^T (both roles), dP = dO V^T (dK waves only): A = row image of the streamed tile, B = resident fragments
-        if (wsame) {
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                s_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sqn, l31, ks, fk, 4096), nfrag(rK, l31, ks, fk, 8192), s_s, 0, 0, 0);
-            if (role_dk) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    p_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sdn, l31, ks, fk, 4096), nfrag(rK + 32768, l31, ks, fk, 8192), p_s, 0, 0, 0);
-            }
-        }
-        if (wcross) {
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                s_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sqn, l31, ks, fk, 4096), nfrag(rK + 16384, l31, ks, fk, 8192), s_c, 0, 0, 0);
-            if (role_dk) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    p_c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nfrag(sdn, l31, ks, fk, 4096), nfrag(rK + 49152, l31, ks, fk, 8192), p_c, 0, 0, 0);
-            }
-        }
+        const bool masked = q0 < kbase_w + 31 || q0 + 32 > S || kbase_w + 32 > len;
+
         // accumulator row r <-> query q0 + (r&3) + 8(r>>2) + 4fk ; column <-> this lane's key
-        const int kabs = kbase_w + l31;
-        unsigned crossbits = 0;
+        // S = Q K^T (both roles), dP = dO V^T (dK waves only): A = row fragments of the streamed tile, B = resident fragments
+        auto score_s = [&](const char* rk, f32x16& s) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ql = 8 * g + 4 * fk;
-            const f32x4 Lv = *(const f32x4*)(sL + ql);
-            const f32x4 Dv = *(const f32x4*)(sD + ql);
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const int qa = q0 + ql + e;
-                const bool cr = (((qm >> (ql + e)) & 1u) != 0) != k_vis;
-                const float sv = cr ? s_c[r] : s_s[r];
-                const float dpv = cr ? p_c[r] : p_s[r];
-                const float pr = (qa >= kabs && qa < S && kabs < len && kin)
-                                     ? __builtin_amdgcn_exp2f(sv * p.sl2 - Lv[e] * LOG2E) : 0.f;
-                s_s[r] = role_dk ? pr * (dpv - Dv[e]) : pr;       // dS for the dK waves, P for the dV waves
-                crossbits |= (cr ? 1u : 0u) << r;
+            for (int ks = 0; ks < 8; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sq, l31o, 2 * ks + fko), nfrag(rk, l31o, ks, fko, 8192), s, 0, 0, 0);
+        };
+        auto score_dp = [&](const char* rk, f32x16& dp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+            if (role_dk) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sq + 16384, l31o, 2 * ks + fko), nfrag(rk + 32768, l31o, ks, fko, 8192), dp, 0, 0, 0);
             }
-        }
-        const char* st = role_dk ? sqt : sdt;                     // Q^T fragments (dK) or dO^T fragments (dV)
+        };
+        // s <- P = exp2(S*sl2 - L) (dV waves) or dS = P (dP - D) (dK waves)
+        auto finish = [&](f32x16& s, const f32x16& dp) {
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            bf16x8 bS, bC;
-            split_pack(s_s, crossbits, sx, bS, bC);
+            for (int g = 0; g < 4; ++g) {
+                const int ql = 8 * g + 4 * fk;
+                const f32x4 Lv = *(const f32x4*)(sL + ql);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 af = tread_t(st, lane, dt, sx);
-                if (wsame) acc_s[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bS, acc_s[dt], 0, 0, 0);
-                if (wcross) acc_c[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bC, acc_c[dt], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) s[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * g + e], p.sl2, -Lv[e] * LOG2E));
             }
-        }
+            if (masked) {
+                const int kabs = kbase_w + l31;
+                const bool kok = kabs < len;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qa = q0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    s[r] = (qa >= kabs && qa < S && kok) ? s[r] : 0.f;
+                }
+            }
+            if (role_dk) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 Dv = *(const f32x4*)(sD + 8 * g + 4 * fk);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[4 * g + e] *= dp[4 * g + e] - Dv[e];
+                }
+            }
+        };
+        const char* st = role_dk ? sq : sq + 16384;               // Q^T fragments (dK) or dO^T fragments (dV)
+        const bool mixed = wsame && wcross;
+        // one pass per variant present (a tile pair with both modalities on either side - rare - pays S twice): every
+        // accumulator set is touched from exactly one place, which keeps all 128 of them in registers
+        auto pass = [&](const char* rk, bool cross, f32x16* acc) {
+            f32x16 s, dp;
+            score_s(rk, s);
+            score_dp(rk, dp);
+            finish(s, dp);
+            if (mixed) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    s[r] = ((((qm >> ql) & 1u) != 0) != k_vis) == cross ? s[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                union { bf16x8 v; unsigned u[4]; } pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(st, lane_o, dt, sx), pk.v, acc[dt], 0, 0, 0);
+            }
+        };
+        if (wsame) pass(rK, false, acc_s);
+        if (wcross) pass(rK + 16384, true, acc_c);
     }
-    // ---- store: each wave's two [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
+    // ---- combine the two query halves' partial sums: waves with qh = 1 hand theirs over through LDS ----
     __syncthreads();
+    {
+        float* xch = (float*)smem + ((wave >> 2) * 2 + kw) * 8192;   // 32 KiB per (role, key sub-block) pair: [acc][reg quad][lane] x4
+        if (qh == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 a, c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = acc_s[i][4 * g + e]; c[e] = acc_c[i][4 * g + e]; }
+                    *(f32x4*)(xch + ((i * 4 + g) * 64 + lane) * 4) = a;
+                    *(f32x4*)(xch + 4096 + ((i * 4 + g) * 64 + lane) * 4) = c;
+                }
+        }
+        __syncthreads();
+        if (qh == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = *(const f32x4*)(xch + ((i * 4 + g) * 64 + lane) * 4);
+                    const f32x4 c = *(const f32x4*)(xch + 4096 + ((i * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc_s[i][4 * g + e] += a[e]; acc_c[i][4 * g + e] += c[e]; }
+                }
+        }
+        __syncthreads();
+    }
+    if (qh != 0 || kbase_w >= S) return;
+    // ---- store: each wave's two [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
     constexpr int OROW = 264;
     char* so = smem + wave * (32 * OROW);
     auto store = [&](const f32x16* acc, float mul, bf16_t* dst) {
@@ -431,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                 w[1] = pack2bf(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
                 *(u32x2*)(so + l31 * OROW + d * 2) = w;
             }
+        // same-wave LDS write -> read: LDS ops of one wave execute in order and no other wave touches `so`
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
             const int r = pass * 4 + (lane >> 4);
@@ -486,6 +590,8 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
                                      int64_t S, int64_t H, float scale, void* stream) {
     if (B <= 0 || S <= 0) return LIBRA_OK;
     const int64_t HD = H * D128;
+    if (ldq >= (1 << 18) || ldk >= (1 << 18) || ldkc >= (1 << 18) || ldv >= (1 << 18) || ldvc >= (1 << 18) || lddo >= (1 << 18))
+        return LIBRA_ERR_SHAPE;                                    // 32-bit per-lane byte offsets in the tile loaders
     if (H <= 0 || S > 4096 || ldq < HD || ldk < HD || ldkc < HD || ldv < HD || ldvc < HD || ldout < HD || lddo < HD || lddq < HD || ldg < HD)
         return LIBRA_ERR_SHAPE;
     if ((ldq | ldk | ldkc | ldv | ldvc | ldout | lddo | lddq | ldg) % 8) return LIBRA_ERR_ALIGN;
@@ -512,14 +618,14 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
         attr_set = true;
     }
-    a.n_t = (int)((S + 127) / 128);
+    a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
     long nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(256), DQ_LDS_B, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(256), DKV_LDS_B, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (T + KB - 1) / KB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) pin(qf[ks]);         // Q has landed before any LDS-DMA is in flight
     stage_rows64(kbase, p.ld_qkv, 0, T, smem, wave, lane);
     stage_rows64(vbase, p.ld_vt, 0, HD, smem + KV_TILE_BYTES, wave, lane);
 
@@ -123,36 +125,45 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
                 s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[c], 0, 0, 0);
             }
         }
-        // ---- scale, mask the key tail, running max
-        float tmax = -INFINITY;
+        // ---- mask the key tail (last tile only), running max (advanced only when a tile exceeds it by 2^DEFER_THR:
+        //      P <= 256 then, which bf16 carries at the same relative precision), exponentiate
+        if (kv0 + KB > T) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = s[c][r] * p.sl2;
-                v = key < T ? v : -INFINITY;
-                s[c][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    s[c][r] = key < T ? s[c][r] : -INFINITY;
+                }
+        }
+        float tmax = max3f(s[0][0], s[0][1], s[1][0]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) tmax = max3f(tmax, s[0][r], s[0][r + 1]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) tmax = max3f(tmax, s[1][r], s[1][r + 1]);
+        tmax = fmaxf(tmax, s[1][15]);
+        tmax = half_swap_max(tmax * p.sl2);
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__any(m_new > m_run + DEFER_THR)) {          // wave-uniform; the first tile always lands here
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float nm = -m_run;
         float psum = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[c][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[c][r], p.sl2, nm));
                 s[c][r] = e;
                 psum += e;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T : k-step (c, sx) consumes S^T accumulator registers 8sx..8sx+7, i.e. for this
         // lane half the keys  c*32 + 16sx + 4half + {0,1,2,3, 8,9,10,11}

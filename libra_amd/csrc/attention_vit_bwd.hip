@@ -245,9 +245,11 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
         if (wave < 2) {                                         // 64 fp32 each: one 4-byte direct-to-LDS op
             int qi = r0 + lane; qi = qi < T ? qi : T - 1;
             const float* src = (wave == 0 ? lbase : dbase) + qi;
-            __builtin_amdgcn_global_load_lds((const LIBRA_GLB void*)src, (LIBRA_LDS void*)(st + 4 * TILE + wave * 256), 4, 0, 0);
+            glds4(src, st + 4 * TILE + wave * 256);
         }
     };
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { pin(kf[ks]); pin(vf[ks]); }   // K/V fragments have landed before any LDS-DMA is in flight
     stage_all(smem, 0);
 
     for (int it = 0; it < nqt; ++it) {

@@ -19,15 +19,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
-// round-to-nearest-even, NaN kept quiet (matches torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN kept quiet (matches torch's float->bfloat16): gfx950's v_cvt_pk_bf16_f32
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const hw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2));
 }
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
 #pragma unroll
@@ -55,9 +53,47 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // 16-byte async global -> LDS copy. LDS destination is wave-uniform base + lane*16.
+// Issued as inline asm on purpose: for the builtin, hipcc's waitcnt pass cannot tell which LDS bytes a pending
+// LDS-DMA will write and drains the whole VMEM queue (s_waitcnt vmcnt(0)) before the next ds_read of ANY address,
+// which serialises every prefetch with the compute it was meant to hide under.  Hidden from that pass, the copies
+// are ordered only by the kernels' own explicit `s_waitcnt vmcnt(n)` + barrier (every kernel has one per tile).
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const LIBRA_GLB void*)gsrc, (LIBRA_LDS void*)lds_wave_base, 16, 0, 0);
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
 }
+
+// 4-byte-per-lane variant (wave-uniform base + lane*4), same reasoning as glds16.
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
+}
+// 16-byte copy addressed as wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: no 64-bit
+// per-lane address arithmetic and no VGPR pair per source pointer.
+__device__ __forceinline__ void glds16_off(const void* sbase, unsigned voff, void* lds_wave_base) {
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+// Make the compiler finish (wait for) whatever produces `v` HERE: values loaded in a prologue and first used inside a
+// tile loop would otherwise get their s_waitcnt vmcnt inside the loop, where it also drains the hidden LDS-DMA queue.
+template <typename T>
+__device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
+
+// max of three without fmaxf's NaN-quieting canonicalisation moves (scores are finite or -inf here)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// max(v, v of lane ^ 32): one v_permlane32_swap instead of an LDS round trip
+__device__ __forceinline__ float half_swap_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+constexpr float DEFER_THR = 8.f;   // online-softmax running max is only advanced when a tile exceeds it by 2^8
 
 // XCD-aware, bijective remap of a linear block id so that each of the 8 XCDs (block b runs on
 // XCD b % 8) receives a contiguous range of the logical tile space (L2 locality; speed only).

@@ -1,0 +1,40 @@
+"""Bridge-attention kernels at the Libra-11B decoder shape (B=8, S=2048, H=32, d=128, one 578-token image span per
+sequence): time forward / backward and print algorithmic TFLOP/s (causal-minimal: 2*2*S^2/2*d per head forward)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from libra_amd import kernels as K
+
+B, S, H = 8, 2048, 32
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+N, D = B * S, H * 128
+g = torch.Generator(device="cuda").manual_seed(0)
+q, ks, kc, vs, vc, do = [torch.randn(N, D, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(6)]
+flag = torch.zeros(B, S, dtype=torch.uint8); flag[:, 1:579] = 1
+flag = flag.reshape(N).cuda()
+lens = torch.full((B,), S, dtype=torch.int32).cuda()
+sc = 128 ** -0.5
+fl_fwd = B * H * 2 * 2 * (S * (S + 1) / 2) * 128
+
+
+def timeit(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+res = {}
+o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True)
+if which in ("all", "fwd"):
+    ms = timeit(lambda: K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True))
+    res["fwd_ms"] = round(ms, 3); res["fwd_TF"] = round(fl_fwd / ms / 1e9, 1)
+if which in ("all", "bwd"):
+    ms = timeit(lambda: K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag, lens, lse, B, S, H, sc))
+    res["bwd_ms"] = round(ms, 3); res["bwd_TF"] = round(2.5 * fl_fwd / ms / 1e9, 1)
+print(json.dumps(res))
