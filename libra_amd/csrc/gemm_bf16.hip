@@ -158,11 +158,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f;
 
+    // fused operands (row map, aux, residual) of all 8 row passes are fetched up front: one round trip, not eight
+    const bool want_aux = (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) != 0, want_res = (p.flags & LIBRA_GEMM_RESIDUAL) != 0;
+    int oms[8];
+    u32x4 xaux[8], xres[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int gm = m0 + pass * 16 + (tid >> 4);
+        oms[pass] = (gm < p.M && p.c_rows) ? p.c_rows[gm] : gm;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int gm = m0 + pass * 16 + (tid >> 4);
+        const bool ok = gm < p.M && full8;
+        xaux[pass] = u32x4{0, 0, 0, 0}; xres[pass] = u32x4{0, 0, 0, 0};
+        if (want_aux && ok) xaux[pass] = *(const u32x4*)(p.aux + (long)oms[pass] * p.ldaux + gn);
+        if (want_res && ok) xres[pass] = *(const u32x4*)(p.resid + (long)oms[pass] * p.ldr + gn);
+    }
+#pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 16 + (tid >> 4);
         const int gm = m0 + row;
         if (gm >= p.M) break;
-        const int om = p.c_rows ? p.c_rows[gm] : gm;
+        const int om = oms[pass];
         float v[8];
         const f32x4 lo = *(const f32x4*)(ct + row * BN + cgrp * 8);
         const f32x4 hi = *(const f32x4*)(ct + row * BN + cgrp * 8 + 4);
@@ -182,14 +200,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
         }
         if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
             float a[8];
-            if (full8) unpack8(*(const u32x4*)(p.aux + (long)om * p.ldaux + gn), a);
+            if (full8) unpack8(xaux[pass], a);
             else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f(a[e]);
         }
         if (p.flags & LIBRA_GEMM_RESIDUAL) {
             float a[8];
-            if (full8) unpack8(*(const u32x4*)(p.resid + (long)om * p.ldr + gn), a);
+            if (full8) unpack8(xres[pass], a);
             else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
@@ -219,19 +237,40 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
                                          float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
                                          int64_t a_phys_rows, const int32_t* c_rows, void* stream);
 
-// Tile-structure choice (speed only): the 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of
-// workgroups but runs 1 workgroup / CU (256 slots) against 2 / CU (512 slots) for the 128^2 kernel.
-static int pick_256(int64_t M, int64_t N, int64_t K) {
+// Tile-structure choice (speed only).  The 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of workgroups but
+// runs 1 workgroup / CU (256 slots, a partly filled last wave costs a whole one) against 2 / CU (512 slots) for the 128^2
+// kernel.  The plan gives the leading `rows256` output rows (whole waves of 256^2 tiles) to the big kernel and the
+// remaining rows - the would-be partial wave - to the small one as a second launch: e.g. M=18464, N=1024 (ViT-L proj / fc2
+// at bs 32) = 73 x 4 tiles = 1.14 waves becomes one full wave + 136 small tiles instead of two waves.
+// Costs are microseconds fitted on MI355X (tools/prim.sh + tools/gemm_bench.py); kt = K / 64.
+static double cost256(double tiles, double kt) { return 8.6 + ceil(tiles / 256.0) * (1.74 * kt + 3.0); }
+static double cost128(double tiles, double kt) {
+    const double full = floor(tiles / 512.0), rest = tiles - full * 512.0;
+    return full * (5.8 + 1.245 * kt) + (rest <= 0 ? 0.0 : rest <= 256.0 ? 4.8 + 0.606 * kt      // <= 1 block / CU: it owns the CU
+                                                                          : 5.8 + 1.245 * kt);
+}
+static int64_t plan_rows256(int64_t M, int64_t N, int64_t K) {
     static int mode = -1;                          // LIBRA_GEMM_KERNEL = 128 | 256 forces a structure (benchmarks)
     if (mode < 0) { const char* e = getenv("LIBRA_GEMM_KERNEL"); mode = e ? atoi(e) : 0; }
     if (mode == 128) return 0;
-    if (mode == 256) return 1;
+    if (mode == 256) return M;
     if (M < 256 || N < 256 || K < 256) return 0;
-    const double b256 = (double)((M + 255) / 256) * ((N + 255) / 256);
-    const double b128 = (double)((M + 127) / 128) * ((N + 127) / 128);
-    const double t256 = ceil(b256 / 256.0) * 1.6;                        // one 256^2 block = 4 x the work at ~1.25x the CU rate
-    const double t128 = ceil(b128 / 512.0) * 1.0;
-    return t256 <= t128;
+    const double kt = (double)K / 64.0;
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tn128 = (N + 127) / 128;
+    double best = cost128((double)((M + 127) / 128) * tn128, kt);            // everything on the small kernel
+    int64_t rows = 0;
+    const double all256 = cost256((double)(tm * tn), kt);
+    if (all256 <= best) { best = all256; rows = M; }
+    // j full waves on the big kernel, then the small one.  Only worth a second launch (~10 us of boundary + cold start)
+    // when the partial wave is a large share of the problem, i.e. for few waves.
+    for (int64_t j = (tm * tn) / 256; j >= 1 && j <= 2; --j) {
+        const int64_t r = (256 * j) / tn;
+        if (r <= 0 || r >= tm) continue;
+        const int64_t rem = M - r * 256;
+        const double c = cost256((double)(r * tn), kt) + cost128((double)((rem + 127) / 128) * tn128, kt) + 10.0;
+        if (c < 0.95 * best) { best = c; rows = r * 256; }
+    }
+    return rows;
 }
 
 // ---- split-K (wgrad-shaped problems: small M,N, very long K): the 256^2 kernel over K slices + a deterministic
@@ -295,9 +334,24 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
     if ((flags & LIBRA_GEMM_STORE_PREACT) && (!preact || (ldpre % 8) || ldpre < N || ((uintptr_t)preact & 15))) return LIBRA_ERR_ALIGN;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return LIBRA_ERR_SHAPE;
 
-    if (pick_256(M, N, K))
-        return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha,
-                                     alpha_cols, flags, nullptr, 1, a_rows, c_rows, stream);
+    // ---- leading rows on the 256^2 kernel, the rest (if any) on the 128^2 kernel below ----
+    const int64_t rows256 = plan_rows256(M, N, K);
+    if (rows256 > 0) {
+        const int rc = libra_gemm256_launch_(A, lda, B, ldb, C, ldc, rows256, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre,
+                                             alpha, alpha_cols, flags, nullptr, 1, a_rows, c_rows, stream);
+        if (rc != LIBRA_OK || rows256 >= M) return rc;
+        // remaining output rows [rows256, M): gathered / scattered operands advance their row maps, the others their base
+        const int64_t m0 = rows256;
+        if (a_rows) a_rows += m0; else A = (const bf16_t*)A + (at ? m0 : m0 * lda);
+        if (c_rows) c_rows += m0;
+        else {
+            C = (bf16_t*)C + m0 * ldc;
+            if (resid) resid = (const bf16_t*)resid + m0 * ldr;
+            if (aux) aux = (const bf16_t*)aux + m0 * ldaux;
+            if (preact) preact = (bf16_t*)preact + m0 * ldpre;
+        }
+        M -= m0;
+    }
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;

@@ -205,7 +205,27 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         if (full8) unpack8(*(const u32x4*)(p.bias + gn), bias);
         else for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
     }
-    auto epi = [&](const f32x16& c0, const f32x16& c1, const int i) {
+    // The fused operands (row map, aux, residual) of 32-row slab i+1 are fetched before slab i is processed: the
+    // epilogue was a chain of 16 dependent global-load round trips per wave (a third of the launch at K = 1024).
+    const bool want_aux = (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) && !p.slab, want_res = (p.flags & LIBRA_GEMM_RESIDUAL) && !p.slab;
+    struct Extras { int om[4]; u32x4 aux[4], res[4]; };
+    auto fetch = [&](const int i, Extras& x) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int gm = m0 + wr * 128 + i * 32 + pass * 8 + (lane >> 3);
+            const bool ok = gm < p.M && ncol_ok;
+            x.om[pass] = (ok && p.c_rows) ? p.c_rows[gm] : gm;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int gm = m0 + wr * 128 + i * 32 + pass * 8 + (lane >> 3);
+            const bool ok = gm < p.M && full8;
+            x.aux[pass] = u32x4{0, 0, 0, 0}; x.res[pass] = u32x4{0, 0, 0, 0};
+            if (want_aux && ok) x.aux[pass] = *(const u32x4*)(p.aux + (long)x.om[pass] * p.ldaux + gn);
+            if (want_res && ok) x.res[pass] = *(const u32x4*)(p.resid + (long)x.om[pass] * p.ldr + gn);
+        }
+    };
+    auto epi = [&](const f32x16& c0, const f32x16& c1, const int i, const Extras& ex) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
             const int row = pass * 8 + (lane >> 3);
             const int gm = m0 + wr * 128 + i * 32 + row;
             if (gm < p.M && ncol_ok) {
-                const int om = p.c_rows ? p.c_rows[gm] : gm;
+                const int om = ex.om[pass];
                 float v[8];
                 const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
                 const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
@@ -242,14 +262,14 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
                 }
                 if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
                     float x[8];
-                    if (full8) unpack8(*(const u32x4*)(p.aux + (long)om * p.ldaux + gn), x);
+                    if (full8) unpack8(ex.aux[pass], x);
                     else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad(x[e]);
                 }
                 if (p.flags & LIBRA_GEMM_RESIDUAL) {
                     float x[8];
-                    if (full8) unpack8(*(const u32x4*)(p.resid + (long)om * p.ldr + gn), x);
+                    if (full8) unpack8(ex.res[pass], x);
                     else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += x[e];
@@ -260,10 +280,15 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
             }
         }
     };
-    epi(acc[0][0], acc[0][1], 0);
-    epi(acc[1][0], acc[1][1], 1);
-    epi(acc[2][0], acc[2][1], 2);
-    epi(acc[3][0], acc[3][1], 3);
+    Extras e0, e1;
+    fetch(0, e0);
+    fetch(1, e1);
+    epi(acc[0][0], acc[0][1], 0, e0);
+    fetch(2, e0);
+    epi(acc[1][0], acc[1][1], 1, e1);
+    fetch(3, e1);
+    epi(acc[2][0], acc[2][1], 2, e0);
+    epi(acc[3][0], acc[3][1], 3, e1);
 }
 
 // out[m][n] = bf16( sum_s slab[s][m][n] ), 8 elements per thread (deterministic split-K second stage)

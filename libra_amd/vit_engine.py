@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -153,7 +155,7 @@ class _SideStream:
     def __init__(self, device):
         self.main = torch.cuda.current_stream(device)
         self.side = torch.cuda.Stream(device=device)
-        self.enabled = True
+        self.enabled = os.environ.get("LIBRA_NO_SIDE_STREAM", "0") != "1"     # (diagnostics: serial launch order)
 
     def run(self, fn, *operands):
         if not self.enabled:
