@@ -112,22 +112,18 @@ int libra_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t cols, flo
                       size_t workspace_bytes, void* stream);
 
 /* ---- ViT self-attention, flash style (CLIPAttention.forward, modeling_clip.py:287-363) -------------
- * qkv [B*T, 3*H*64] bf16 (q | k | v, head h at columns h*64 of each third; q UNscaled), vt = V^T
- * [H*64, vt_ld] bf16 with token (b,t) at column b*T_pad + t (T_pad % 8 == 0, keys t >= T ignored).
+ * qkv [B*T, 3*H*64] bf16 (q | k | v, head h at columns h*64 of each third; q UNscaled).
  * out [B*T, H*64] bf16, lse [B,H,T] fp32 (natural-log-sum-exp of the scaled scores; may be NULL).
- * head_dim is fixed at 64 (CLIP ViT-L/14).                                                          */
-int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, const void* vt, int64_t ld_vt, int64_t T_pad,
-                       void* out, int64_t ld_out, float* lse, int64_t B, int64_t T, int64_t H,
-                       float scale, void* stream);
+ * head_dim is fixed at 64 (CLIP ViT-L/14).  K and V tiles are read where they lie (no transposed copies). */
+int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B,
+                       int64_t T, int64_t H, float scale, void* stream);
 /* D = rowsum(dO * O) per (image, head, token): delta [B,H,T] fp32.                                   */
 int libra_vit_attn_delta(const void* out, const void* dout, int64_t ld, float* delta, int64_t B,
                          int64_t T, int64_t H, void* stream);
 /* Backward (autograd of modeling_clip.py:308-348): from qkv, dO [B*T,H*64], lse and delta produce
  * dqkv [B*T, 3*H*64] (dq/dk already multiplied by `scale`, i.e. gradients w.r.t. the UNscaled q, k).
- * qkt = [Q^T ; K^T] as a [2*H*64, ld_t] matrix and dot_t = dO^T [H*64, ld_t], token (b,t) at column
- * b*T_pad + t, zero padded (libra_transpose_bf16).  Deterministic: two passes, no atomics.          */
-int libra_vit_attn_bwd(const void* qkv, int64_t ld_qkv, const void* qkt, const void* dot_t, int64_t ld_t,
-                       int64_t T_pad, const void* dout, int64_t ld_out, const float* lse,
+ * Deterministic: two passes (dQ; dK/dV), no atomics, no transposed operand copies.                    */
+int libra_vit_attn_bwd(const void* qkv, int64_t ld_qkv, const void* dout, int64_t ld_out, const float* lse,
                        const float* delta, void* dqkv, int64_t ld_dqkv, int64_t B, int64_t T, int64_t H,
                        float scale, void* stream);
 

@@ -34,9 +34,9 @@ SIGNATURES = {
     "libra_patch_col2im": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_vit_embed_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
     "libra_transpose_bf16": [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P],
-    "libra_vit_attn_fwd": [_P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
+    "libra_vit_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
     "libra_vit_attn_delta": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
-    "libra_vit_attn_bwd": [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
+    "libra_vit_attn_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
     "libra_feature_select": [_P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_feature_select_bwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "libra_lfq_encode": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
@@ -59,7 +59,7 @@ SIGNATURES = {
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LibraHipError(RuntimeError):

@@ -10,15 +10,16 @@
 // so the row max / row sum need one cross-half exchange instead of a 32-lane butterfly and P never
 // moves between lanes or through LDS.
 //
-// K tiles [64 keys][64 d] and V^T tiles [64 d][64 keys] stream HBM -> LDS with 16-byte direct-to-LDS
-// loads (source-side XOR swizzle, mirrored on the fragment reads), double buffered, one barrier per
-// tile.  V^T ([H*64, B*T_pad], token-contiguous) is produced once per layer by libra_transpose_bf16.
+// K and V tiles [64 keys][64 d] stream HBM -> LDS with 16-byte direct-to-LDS loads (source-side XOR swizzle,
+// mirrored on the fragment reads; attn_tiles64.hpp), double buffered, one barrier per tile.  V is staged as it lies in
+// the fused qkv activation and read with the LDS transpose load: no V^T copy exists.
 // Work-group ids are XCD-remapped so the 5 query tiles that share one (image, head)'s K/V run on the
 // same XCD/L2.
 //
 // Scores are kept in fp32 (never rounded to bf16), P is rounded to bf16 only as the MFMA operand and
 // the row sum is taken from the un-rounded fp32 P; the output is normalised once at the end.
 #include "hip_common.hpp"
+#include "attn_tiles64.hpp"
 #include "../../include/libra_hip.h"
 
 namespace libra {
@@ -31,27 +32,11 @@ constexpr int ATT_LDS = 4 * KV_TILE_BYTES;   // K0 V0 K1 V1 = 32 KiB
 
 struct AttnFwdArgs {
     const bf16_t* qkv; long ld_qkv;
-    const bf16_t* vt; long ld_vt; int T_pad;
     bf16_t* out; long ld_out;
     float* lse;
     int B, T, H, n_qt;
     float sl2;      // scale * log2(e)
 };
-
-// 64 rows x 128 B tile; wave w copies rows [16w, 16w+16) with two 1-KiB direct-to-LDS instructions.
-__device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, long ld, int row_lo, int row_hi_excl,
-                                             char* lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wave * 16 + j * 8 + (lane >> 3);
-        int gr = row_lo + r;
-        gr = gr < row_hi_excl ? gr : row_hi_excl - 1;
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        glds16(base + (long)gr * ld + c * 8, lds_tile + (wave * 16 + j * 8) * 128);
-    }
-}
-
-__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
     }
 
     const bf16_t* kbase = p.qkv + tok0 * p.ld_qkv + (long)p.H * HD + h * HD;            // K rows of this image/head
-    const bf16_t* vbase = p.vt + (long)h * HD * p.ld_vt + (long)b * p.T_pad;             // V^T rows d, cols tokens
+    const bf16_t* vbase = kbase + (long)p.H * HD;                                          // V rows of this image/head
 
     f32x16 o[2];
 #pragma unroll
@@ -96,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
     const int nkt = (T + KB - 1) / KB;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) pin(qf[ks]);         // Q has landed before any LDS-DMA is in flight
-    stage_rows64(kbase, p.ld_qkv, 0, T, smem, wave, lane);
-    stage_rows64(vbase, p.ld_vt, 0, HD, smem + KV_TILE_BYTES, wave, lane);
+    stage_tile64(kbase, p.ld_qkv, 0, T, smem, wave, lane);
+    stage_tile64(vbase, p.ld_qkv, 0, T, smem + KV_TILE_BYTES, wave, lane);
 
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -105,8 +90,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
         const int cur = kt & 1;
         if (kt + 1 < nkt) {
             char* nb = smem + (cur ^ 1) * 2 * KV_TILE_BYTES;
-            stage_rows64(kbase, p.ld_qkv, (kt + 1) * KB, T, nb, wave, lane);
-            stage_rows64(vbase + (kt + 1) * KB, p.ld_vt, 0, HD, nb + KV_TILE_BYTES, wave, lane);
+            stage_tile64(kbase, p.ld_qkv, (kt + 1) * KB, T, nb, wave, lane);
+            stage_tile64(vbase, p.ld_qkv, (kt + 1) * KB, T, nb + KV_TILE_BYTES, wave, lane);
         }
         if (!active) continue;
         const char* sk = smem + cur * 2 * KV_TILE_BYTES;
@@ -121,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
             for (int r = 0; r < 16; ++r) s[c][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(sk + swz_off(c * 32 + l31, ks * 2 + half));
+                const bf16x8 kf = *(const bf16x8*)(sk + off64(c * 32 + l31, ks * 2 + half));
                 s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[c], 0, 0, 0);
             }
         }
@@ -166,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
         l_run += psum;
 
         // ---- O^T += V^T P^T : k-step (c, sx) consumes S^T accumulator registers 8sx..8sx+7, i.e. for this
-        // lane half the keys  c*32 + 16sx + 4half + {0,1,2,3, 8,9,10,11}
+        // lane half the keys  c*32 + 16sx + 4half + {0,1,2,3, 8,9,10,11}; V^T fragments come from the V tile by
+        // LDS transpose reads (clamped tail rows meet P = 0)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -174,17 +160,9 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
                 union { bf16x8 v; unsigned u[4]; } pb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pb.u[j] = pack2bf(s[c][8 * sx + 2 * j], s[c][8 * sx + 2 * j + 1]);
-                const int kloc = c * 32 + 16 * sx + 4 * half;          // local key of slot j=0 (multiple of 4)
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + l31;
-                    // keys kloc..kloc+3 (8 bytes) and kloc+8..kloc+11 (next 16-byte chunk)
-                    const int ch = kloc >> 3, sub = (kloc & 7) * 2;
-                    union { bf16x8 v; u32x2 h2[2]; } va;
-                    va.h2[0] = *(const u32x2*)(sv + swz_off(d, ch) + sub);
-                    va.h2[1] = *(const u32x2*)(sv + swz_off(d, ch + 1) + sub);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, o[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread64(sv, lane, dt, c * 2 + sx), pb.v, o[dt], 0, 0, 0);
             }
     }
 
@@ -231,17 +209,14 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
 
 using namespace libra;
 
-extern "C" int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, const void* vt, int64_t ld_vt, int64_t T_pad,
-                                  void* out, int64_t ld_out, float* lse, int64_t B, int64_t T, int64_t H, float scale,
+extern "C" int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t T, int64_t H, float scale,
                                   void* stream) {
     if (B <= 0 || T <= 0) return LIBRA_OK;
     if (H <= 0 || ld_qkv < 3 * H * HD || ld_out < H * HD) return LIBRA_ERR_SHAPE;
-    const int64_t T64 = (T + KB - 1) / KB * KB;
-    if (T_pad < T64 || (T_pad % 8) || ld_vt < B * T_pad) return LIBRA_ERR_SHAPE;
-    if ((ld_qkv % 8) || (ld_vt % 8) || (ld_out % 8)) return LIBRA_ERR_ALIGN;
-    if (!qkv || !vt || !out || (((uintptr_t)qkv | (uintptr_t)vt | (uintptr_t)out) & 15)) return LIBRA_ERR_ALIGN;
+    if ((ld_qkv % 8) || (ld_out % 8)) return LIBRA_ERR_ALIGN;
+    if (!qkv || !out || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return LIBRA_ERR_ALIGN;
     AttnFwdArgs a;
-    a.qkv = (const bf16_t*)qkv; a.ld_qkv = ld_qkv; a.vt = (const bf16_t*)vt; a.ld_vt = ld_vt; a.T_pad = (int)T_pad;
+    a.qkv = (const bf16_t*)qkv; a.ld_qkv = ld_qkv;
     a.out = (bf16_t*)out; a.ld_out = ld_out; a.lse = lse;
     a.B = (int)B; a.T = (int)T; a.H = (int)H; a.n_qt = (int)((T + QB - 1) / QB);
     a.sl2 = scale * 1.4426950408889634f;

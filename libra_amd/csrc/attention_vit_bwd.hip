@@ -9,13 +9,14 @@
 // accumulator registers, so P / dS never leave their lane:
 //   * dq kernel : workgroup = 128 query rows (lane <-> query), loops over 64-key tiles.
 //                 S^T = K Q^T, dP^T = V dO^T (A from LDS, B = Q / dO fragments in registers),
-//                 dQ^T += K^T dS^T          (A = K^T tile from the token-contiguous transposed copy)
+//                 dQ^T += K^T dS^T          (A = K^T fragments: LDS transpose reads of the same K tile)
 //   * dkv kernel: workgroup = 128 keys (lane <-> key), loops over 64-query tiles.
 //                 S = Q K^T, dP = dO V^T    (A from LDS, B = K / V fragments in registers),
-//                 dV^T += dO^T P, dK^T += Q^T dS   (A = dO^T / Q^T tiles from transposed copies)
-// Transposed copies (Q^T,K^T of qkv and dO^T; [cols, B*T_pad], zero padded) come from
-// libra_transpose_bf16; D = rowsum(dO*O) from libra_vit_attn_delta.
+//                 dV^T += dO^T P, dK^T += Q^T dS   (A = dO^T / Q^T fragments: LDS transpose reads of the dO / Q tiles)
+// Every operand tile is staged once, as it lies in HBM, in the dual-use image of attn_tiles64.hpp; D = rowsum(dO*O)
+// comes from libra_vit_attn_delta.
 #include "hip_common.hpp"
+#include "attn_tiles64.hpp"
 #include "../../include/libra_hip.h"
 
 namespace libra {
@@ -24,37 +25,13 @@ constexpr int HD = 64, KB = 64, TILE = KB * HD * 2;    // 8 KiB tiles of 64 rows
 
 struct AttnBwdArgs {
     const bf16_t* qkv; long ld_qkv;
-    const bf16_t* qkt; long ld_t; int T_pad;     // [2*H*64, ld_t]: rows 0..H*64-1 = Q^T, then K^T
     const bf16_t* dout; long ld_out;
-    const bf16_t* dot;                            // dO^T [H*64, ld_t]
     const float* lse; const float* delta;
     bf16_t* dqkv; long ld_dqkv;
     int B, T, H, n_t;
     float sl2, scale;
 };
 
-__device__ __forceinline__ void stage64(const bf16_t* __restrict__ base, long ld, int row_lo, int row_hi_excl,
-                                        char* lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wave * 16 + j * 8 + (lane >> 3);
-        int gr = row_lo + r;
-        gr = gr < row_hi_excl ? gr : row_hi_excl - 1;
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        glds16(base + (long)gr * ld + c * 8, lds_tile + (wave * 16 + j * 8) * 128);
-    }
-}
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// A-operand fragment of a transposed tile X^T[d][64 tokens]: slots (half, j) <-> tokens
-// tloc + {0,1,2,3} and tloc + 8 + {0,1,2,3}  (tloc = c*32 + 16*sx + 4*half), matching accumulator regs 8sx..8sx+7
-__device__ __forceinline__ bf16x8 tfrag(const char* tile, int d, int tloc) {
-    const int ch = tloc >> 3, sub = (tloc & 7) * 2;
-    union { bf16x8 v; u32x2 h2[2]; } u;
-    u.h2[0] = *(const u32x2*)(tile + swz(d, ch) + sub);
-    u.h2[1] = *(const u32x2*)(tile + swz(d, ch + 1) + sub);
-    return u.v;
-}
 __device__ __forceinline__ bf16x8 pack_regs(const f32x16& a, int sx) {
     union { bf16x8 v; unsigned u[4]; } pb;
 #pragma unroll
@@ -95,8 +72,8 @@ __device__ __forceinline__ void store_wave_tile(const f32x16* acc, float mul, ch
 
 // ------------------------------------------------------------------------------------------------
 // dQ pass
-constexpr int DQ_STAGE = 3 * TILE;               // K, V, K^T
-constexpr int DQ_LDS = 2 * DQ_STAGE;             // 48 KiB
+constexpr int DQ_STAGE = 2 * TILE;               // K, V
+constexpr int DQ_LDS = 2 * DQ_STAGE;             // 32 KiB
 
 __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dq_kernel(const AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,12 +100,11 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dq_kernel(const AttnBwdAr
         for (int ks = 0; ks < 4; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 16); dof[ks] = *(const bf16x8*)(dp + ks * 16); }
     }
     const long sidx = ((long)b * p.H + h) * T + q;
-    const float Lq2 = p.lse[sidx] * 1.4426950408889634f;
-    const float Dq = p.delta[sidx];
+    float Lq2 = p.lse[sidx] * 1.4426950408889634f;
+    float Dq = p.delta[sidx];
 
     const bf16_t* kbase = p.qkv + tok0 * p.ld_qkv + (long)p.H * HD + h * HD;
     const bf16_t* vbase = kbase + (long)p.H * HD;
-    const bf16_t* ktbase = p.qkt + ((long)p.H * HD + h * HD) * p.ld_t + (long)b * p.T_pad;
 
     f32x16 dq[2];
 #pragma unroll
@@ -137,9 +113,11 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dq_kernel(const AttnBwdAr
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
     const int nkt = (T + KB - 1) / KB;
-    stage64(kbase, p.ld_qkv, 0, T, smem, wave, lane);
-    stage64(vbase, p.ld_qkv, 0, T, smem + TILE, wave, lane);
-    stage64(ktbase, p.ld_t, 0, HD, smem + 2 * TILE, wave, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { pin(qf[ks]); pin(dof[ks]); }   // prologue loads have landed before any LDS-DMA is in flight
+    pin(Lq2); pin(Dq);
+    stage_tile64(kbase, p.ld_qkv, 0, T, smem, wave, lane);
+    stage_tile64(vbase, p.ld_qkv, 0, T, smem + TILE, wave, lane);
 
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,14 +125,12 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dq_kernel(const AttnBwdAr
         const int cur = kt & 1;
         if (kt + 1 < nkt) {
             char* nb = smem + (cur ^ 1) * DQ_STAGE;
-            stage64(kbase, p.ld_qkv, (kt + 1) * KB, T, nb, wave, lane);
-            stage64(vbase, p.ld_qkv, (kt + 1) * KB, T, nb + TILE, wave, lane);
-            stage64(ktbase + (kt + 1) * KB, p.ld_t, 0, HD, nb + 2 * TILE, wave, lane);
+            stage_tile64(kbase, p.ld_qkv, (kt + 1) * KB, T, nb, wave, lane);
+            stage_tile64(vbase, p.ld_qkv, (kt + 1) * KB, T, nb + TILE, wave, lane);
         }
         if (!active) continue;
         const char* sk = smem + cur * DQ_STAGE;
         const char* sv = sk + TILE;
-        const char* skt = sk + 2 * TILE;
         const int kv0 = kt * KB;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -163,27 +139,26 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dq_kernel(const AttnBwdAr
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(sk + swz(c * 32 + l31, ks * 2 + half));
+                const bf16x8 kf = *(const bf16x8*)(sk + off64(c * 32 + l31, ks * 2 + half));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 vf = *(const bf16x8*)(sv + swz(c * 32 + l31, ks * 2 + half));
+                const bf16x8 vf = *(const bf16x8*)(sv + off64(c * 32 + l31, ks * 2 + half));
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float pr = key < T ? __builtin_amdgcn_exp2f(s[r] * p.sl2 - Lq2) : 0.f;
-                s[r] = pr * (dp[r] - Dq);                      // dS^T
+                const float pr = key < T ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.sl2, -Lq2)) : 0.f;
+                s[r] = pr * (dp[r] - Dq);                      // dS^T (clamped tail keys: exactly 0)
             }
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
                 const bf16x8 dsb = pack_regs(s, sx);
-                const int tloc = c * 32 + 16 * sx + 4 * half;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(skt, dt * 32 + l31, tloc), dsb, dq[dt], 0, 0, 0);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread64(sk, lane, dt, c * 2 + sx), dsb, dq[dt], 0, 0, 0);
             }
         }
     }
@@ -196,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dq_kernel(const AttnBwdAr
 
 // ------------------------------------------------------------------------------------------------
 // dK / dV pass
-constexpr int DKV_STAGE = 4 * TILE + 512;        // Q, dO, Q^T, dO^T, L[64], D[64]
-constexpr int DKV_LDS = 2 * DKV_STAGE;           // 66.5 KiB
+constexpr int DKV_STAGE = 2 * TILE + 512;        // Q, dO, L[64], D[64]
+constexpr int DKV_LDS = 2 * DKV_STAGE;           // 33 KiB
 
 __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -224,8 +199,6 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
     }
     const bf16_t* qbase = p.qkv + tok0 * p.ld_qkv + h * HD;
     const bf16_t* dobase = p.dout + tok0 * p.ld_out + h * HD;
-    const bf16_t* qtbase = p.qkt + ((long)h * HD) * p.ld_t + (long)b * p.T_pad;
-    const bf16_t* dotbase = p.dot + ((long)h * HD) * p.ld_t + (long)b * p.T_pad;
     const float* lbase = p.lse + ((long)b * p.H + h) * T;
     const float* dbase = p.delta + ((long)b * p.H + h) * T;
 
@@ -238,14 +211,12 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
     const int nqt = (T + KB - 1) / KB;
     auto stage_all = [&](char* st, int qtile) {
         const int r0 = qtile * KB;
-        stage64(qbase, p.ld_qkv, r0, T, st, wave, lane);
-        stage64(dobase, p.ld_out, r0, T, st + TILE, wave, lane);
-        stage64(qtbase + r0, p.ld_t, 0, HD, st + 2 * TILE, wave, lane);
-        stage64(dotbase + r0, p.ld_t, 0, HD, st + 3 * TILE, wave, lane);
+        stage_tile64(qbase, p.ld_qkv, r0, T, st, wave, lane);
+        stage_tile64(dobase, p.ld_out, r0, T, st + TILE, wave, lane);
         if (wave < 2) {                                         // 64 fp32 each: one 4-byte direct-to-LDS op
             int qi = r0 + lane; qi = qi < T ? qi : T - 1;
             const float* src = (wave == 0 ? lbase : dbase) + qi;
-            glds4(src, st + 4 * TILE + wave * 256);
+            glds4(src, st + 2 * TILE + wave * 256);
         }
     };
 #pragma unroll
@@ -260,9 +231,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
         if (!active) continue;
         const char* sq = smem + cur * DKV_STAGE;
         const char* sdo = sq + TILE;
-        const char* sqt = sq + 2 * TILE;
-        const char* sdot = sq + 3 * TILE;
-        const float* sL = (const float*)(sq + 4 * TILE);
+        const float* sL = (const float*)(sq + 2 * TILE);
         const float* sD = sL + 64;
         const int q0 = it * KB;
 #pragma unroll
@@ -272,12 +241,12 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *(const bf16x8*)(sq + swz(c * 32 + l31, ks * 2 + half));
+                const bf16x8 a = *(const bf16x8*)(sq + off64(c * 32 + l31, ks * 2 + half));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *(const bf16x8*)(sdo + swz(c * 32 + l31, ks * 2 + half));
+                const bf16x8 a = *(const bf16x8*)(sdo + off64(c * 32 + l31, ks * 2 + half));
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf[ks], dp, 0, 0, 0);
             }
             // accumulator row (r) <-> query  q0 + c*32 + (r&3) + 8*(r>>2) + 4*half ; column <-> this lane's key
@@ -290,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
                     const float pr = (q0 + ql + e) < T
-                                         ? __builtin_amdgcn_exp2f(s[r] * p.sl2 - Lv[e] * 1.4426950408889634f) : 0.f;
+                                         ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.sl2, -Lv[e] * 1.4426950408889634f)) : 0.f;
                     s[r] = pr;                                   // P
                     dp[r] = pr * (dp[r] - Dv[e]);                // dS
                 }
@@ -299,11 +268,10 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
             for (int sx = 0; sx < 2; ++sx) {
                 const bf16x8 pb = pack_regs(s, sx);
                 const bf16x8 dsb = pack_regs(dp, sx);
-                const int tloc = c * 32 + 16 * sx + 4 * half;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sdot, dt * 32 + l31, tloc), pb, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sqt, dt * 32 + l31, tloc), dsb, dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread64(sdo, lane, dt, c * 2 + sx), pb, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread64(sq, lane, dt, c * 2 + sx), dsb, dk[dt], 0, 0, 0);
                 }
             }
         }
@@ -361,20 +329,17 @@ extern "C" int libra_vit_attn_delta(const void* out, const void* dout, int64_t l
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
 
-extern "C" int libra_vit_attn_bwd(const void* qkv, int64_t ld_qkv, const void* qkt, const void* dot_t, int64_t ld_t,
-                                  int64_t T_pad, const void* dout, int64_t ld_out, const float* lse,
+extern "C" int libra_vit_attn_bwd(const void* qkv, int64_t ld_qkv, const void* dout, int64_t ld_out, const float* lse,
                                   const float* delta, void* dqkv, int64_t ld_dqkv, int64_t B, int64_t T, int64_t H,
                                   float scale, void* stream) {
     if (B <= 0 || T <= 0) return LIBRA_OK;
     if (H <= 0 || ld_qkv < 3 * H * HD || ld_out < H * HD || ld_dqkv < 3 * H * HD) return LIBRA_ERR_SHAPE;
-    const int64_t T64 = (T + KB - 1) / KB * KB;
-    if (T_pad < T64 || (T_pad % 8) || ld_t < B * T_pad) return LIBRA_ERR_SHAPE;
-    if ((ld_qkv % 8) || (ld_t % 8) || (ld_out % 8) || (ld_dqkv % 8)) return LIBRA_ERR_ALIGN;
-    if (!qkv || !qkt || !dot_t || !dout || !lse || !delta || !dqkv) return LIBRA_ERR_ALIGN;
-    if (((uintptr_t)qkv | (uintptr_t)qkt | (uintptr_t)dot_t | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return LIBRA_ERR_ALIGN;
+    if ((ld_qkv % 8) || (ld_out % 8) || (ld_dqkv % 8)) return LIBRA_ERR_ALIGN;
+    if (!qkv || !dout || !lse || !delta || !dqkv) return LIBRA_ERR_ALIGN;
+    if (((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return LIBRA_ERR_ALIGN;
     AttnBwdArgs a;
-    a.qkv = (const bf16_t*)qkv; a.ld_qkv = ld_qkv; a.qkt = (const bf16_t*)qkt; a.ld_t = ld_t; a.T_pad = (int)T_pad;
-    a.dout = (const bf16_t*)dout; a.ld_out = ld_out; a.dot = (const bf16_t*)dot_t; a.lse = lse; a.delta = delta;
+    a.qkv = (const bf16_t*)qkv; a.ld_qkv = ld_qkv;
+    a.dout = (const bf16_t*)dout; a.ld_out = ld_out; a.lse = lse; a.delta = delta;
     a.dqkv = (bf16_t*)dqkv; a.ld_dqkv = ld_dqkv;
     a.B = (int)B; a.T = (int)T; a.H = (int)H; a.n_t = (int)((T + 127) / 128);
     a.scale = scale; a.sl2 = scale * 1.4426950408889634f;

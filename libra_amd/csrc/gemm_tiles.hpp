@@ -20,7 +20,6 @@
 
 namespace libra {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // ---- fragment addressing (per lane, computed once) ----
 struct FragAddr {

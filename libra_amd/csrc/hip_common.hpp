@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;     // operand type of the LDS transpose read builtin
 #define LIBRA_LDS __attribute__((address_space(3)))
 #define LIBRA_GLB __attribute__((address_space(1)))
 

@@ -188,7 +188,7 @@ static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK
 
 using namespace libra;
 
-extern "C" int libra_hip_abi_version(void) { return 1; }
+extern "C" int libra_hip_abi_version(void) { return 2; }
 
 extern "C" int libra_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows,
                                     int64_t cols, int64_t rows_pad, float* colsum, int64_t batch,

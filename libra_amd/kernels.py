@@ -227,35 +227,31 @@ def vit_embed_ln(patches, cls, pos, gamma, beta, B: int, T: int, eps: float, *, 
     return emb, hs0, mean, rstd
 
 
-def vit_attn_fwd(qkv: torch.Tensor, vt: torch.Tensor, B: int, T: int, H: int, T_pad: int, scale: float, *,
-                 need_lse: bool = True, out: Optional[torch.Tensor] = None):
-    _chk2d(qkv, "qkv"); _chk2d(vt, "vt")
+def vit_attn_fwd(qkv: torch.Tensor, B: int, T: int, H: int, scale: float, *, need_lse: bool = True,
+                 out: Optional[torch.Tensor] = None):
+    _chk2d(qkv, "qkv")
     if out is None:
         out = torch.empty((B * T, H * 64), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device) if need_lse else None
-    rc = _lib.lib().libra_vit_attn_fwd(qkv.data_ptr(), qkv.stride(0), vt.data_ptr(), vt.stride(0), T_pad,
-                                       out.data_ptr(), out.stride(0), _ptr(lse), B, T, H, float(scale), _stream())
+    rc = _lib.lib().libra_vit_attn_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), _ptr(lse), B, T, H,
+                                       float(scale), _stream())
     _lib.check(rc, "vit_attn_fwd")
     return out, lse
 
 
-def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, T_pad: int, scale: float, *,
+def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, scale: float, *,
                  out_dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk2d(qkv, "qkv"); _chk2d(out, "out"); _chk2d(dout, "dout")
     dev = qkv.device
-    HD = H * 64
     delta = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+    if dout.stride(0) != out.stride(0):
+        raise ValueError("vit_attn_bwd: out/dout leading dims differ")
     rc = _lib.lib().libra_vit_attn_delta(out.data_ptr(), dout.data_ptr(), out.stride(0), delta.data_ptr(), B, T, H,
                                          _stream())
     _lib.check(rc, "vit_attn_delta")
-    if dout.stride(0) != out.stride(0):
-        raise ValueError("vit_attn_bwd: out/dout leading dims differ")
-    qkt = transpose_tokens(qkv[:, : 2 * HD], B, T, T_pad)
-    dot = transpose_tokens(dout, B, T, T_pad)
     dqkv = torch.empty_like(qkv) if out_dqkv is None else out_dqkv
-    rc = _lib.lib().libra_vit_attn_bwd(qkv.data_ptr(), qkv.stride(0), qkt.data_ptr(), dot.data_ptr(), qkt.stride(0),
-                                       T_pad, dout.data_ptr(), dout.stride(0), lse.data_ptr(), delta.data_ptr(),
-                                       dqkv.data_ptr(), dqkv.stride(0), B, T, H, float(scale), _stream())
+    rc = _lib.lib().libra_vit_attn_bwd(qkv.data_ptr(), qkv.stride(0), dout.data_ptr(), dout.stride(0), lse.data_ptr(),
+                                       delta.data_ptr(), dqkv.data_ptr(), dqkv.stride(0), B, T, H, float(scale), _stream())
     _lib.check(rc, "vit_attn_bwd")
     return dqkv
 

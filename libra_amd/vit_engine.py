@@ -118,8 +118,7 @@ def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: 
         xn1, m1, r1 = K.layernorm_fwd(x, params[pre + "layer_norm1.weight"], params[pre + "layer_norm1.bias"], dims.eps,
                                       save_stats=save, out=rows(D))
         qkv = K.gemm_nt(xn1, pk["wqkv"], bias=pk["bqkv"])
-        vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, dims.t_pad)
-        o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, dims.t_pad, scale, need_lse=save, out=rows(D))
+        o, lse = K.vit_attn_fwd(qkv, B, T, H, scale, need_lse=save, out=rows(D))
         x_mid = K.gemm_nt(o, params[pre + "self_attn.out_proj.weight"], bias=params[pre + "self_attn.out_proj.bias"],
                           resid=x)
         xn2, m2, r2 = K.layernorm_fwd(x_mid, params[pre + "layer_norm2.weight"], params[pre + "layer_norm2.bias"],
@@ -231,7 +230,7 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
         param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D)
         do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
-        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, dims.t_pad, scale, out_dqkv=dev_rows(3 * D))
+        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dev_rows(3 * D))
         param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D)                   # [3D, D]
         dwqkv = grads.pop(pre + "self_attn.qkv_packed")
         o0 = cursor[0] - 3 * D

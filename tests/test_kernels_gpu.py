@@ -184,8 +184,7 @@ def test_attention_fwd(K, B, T, H):
     D = H * 64
     qkv = rnd(B * T, 3 * D, seed=T)
     Tp = K.round_up(T, 64)
-    vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, Tp)
-    o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, Tp, 0.125)
+    o, lse = K.vit_attn_fwd(qkv, B, T, H, 0.125)
     ro, rl = _attn_ref(qkv, B, T, H, 0.125)
     close(o, ro, rel=2e-3, what="attn out")        # P is fed to the MFMA in bf16 (as the reference's bmm does)
     close(lse, rl, rel=1e-4, what="lse")
@@ -197,8 +196,7 @@ def test_attention_fwd_spiky_rows(K):
     qkv = rnd(B * T, 192, seed=3)
     qkv[:, 64:128][150] = qkv[:, 64:128][150] * 40
     Tp = 256
-    vt = K.transpose_tokens(qkv[:, 128:], B, T, Tp)
-    o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, Tp, 0.125)
+    o, lse = K.vit_attn_fwd(qkv, B, T, H, 0.125)
     ro, rl = _attn_ref(qkv, B, T, H, 0.125)
     close(o, ro, rel=2e-3, what="attn out spiky")
     close(lse, rl, rel=1e-4, what="lse spiky")
@@ -210,9 +208,8 @@ def test_attention_bwd(K, B, T, H):
     qkv = rnd(B * T, 3 * D, seed=T + 1)
     do = rnd(B * T, D, seed=T + 2)
     Tp = K.round_up(T, 64)
-    vt = K.transpose_tokens(qkv[:, 2 * D:], B, T, Tp)
-    o, lse = K.vit_attn_fwd(qkv, vt, B, T, H, Tp, 0.125)
-    dqkv = K.vit_attn_bwd(qkv, o, do, lse, B, T, H, Tp, 0.125)
+    o, lse = K.vit_attn_fwd(qkv, B, T, H, 0.125)
+    dqkv = K.vit_attn_bwd(qkv, o, do, lse, B, T, H, 0.125)
     ref_in = qkv.float().requires_grad_(True)
     ro, _ = _attn_ref(ref_in, B, T, H, 0.125)
     ro.backward(do.float())
