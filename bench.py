@@ -159,6 +159,16 @@ def cpu_baseline(sample_iters=3):
                       f"({warm:.1f} s)"}
 
 
+def hbm_traffic(workload):
+    """Mean HBM bytes per GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/); None if absent."""
+    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            return round(json.load(f)["gemm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,7 +249,8 @@ def main():
         step()
     recs = prof.finish()
     os.environ.pop("LIBRA_NO_SIDE_STREAM", None)
-    gem = [(w, t) for k, w, t in recs if k == "gemm"]
+    gem = [(w[0], t) for k, w, t in recs if k == "gemm"]
+    gbytes = sum(w[1] for k, w, t in recs if k == "gemm") / max(len(gem), 1)
     gflop = sum(w for w, _ in gem) / 1e9
     gms = sum(t for _, t in gem)
     achieved = gflop / gms if gms > 0 else 0.0        # GFLOP/ms == TFLOP/s
@@ -250,7 +261,8 @@ def main():
         dec_bwd = 32 * (595.0 + 153.34 + 2.5 * 34.4 + 153.34) + 385.0 + 2 * 4.8
         gflop_step_img = GFLOP_FWD_PER_IMG + 25440.0 + dec_bwd
     roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(args.workload),
+            "traffic_unit": "HBM bytes / launch (PMC, profiles/)", "algorithmic_bytes_per_launch": round(gbytes),
             "timing": "serial re-run of the step (side stream off), HIP events on the launch stream",
             "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1),
             "gemm_ms_per_step": round(gms, 2),

@@ -66,66 +66,96 @@ struct RopeArgs {
 
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
 
+// One thread = 4 channels d in [4c, 4c+4) and their RoPE partners d + 64.  It keeps those 8 channels' rows of B_k / B_v
+// (64 dwords) in registers across ROPE_TOK consecutive tokens and reloads them only when the modality flips: read per
+// token from L2 they were 128 KB of weight traffic per token (2.1 GB per call at N = 16384, more than the activations).
+constexpr int ROPE_TOK = 16;
+
+__device__ __forceinline__ void unpack4(const u32x2 v, float* f) {
+    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+__device__ __forceinline__ u32x2 pack4(const float* f) {
+    u32x2 v; v[0] = pack2bf(f[0], f[1]); v[1] = pack2bf(f[2], f[3]); return v;
+}
+
 __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = p.N * p.H * 8;
-    if (i >= total) return;
-    const int c = (int)(i & 7);
-    const long th = i >> 3;
-    const int h = (int)(th % p.H);
-    const long n = th / p.H;
-    const int s = (int)(n % p.S);
-    const bool vis = p.flag[n] != 0;
+    const int LT = p.H * 16;                                  // threads per token
+    const int tpb = LT >= 256 ? 1 : 256 / LT;                 // token slots per block
+    const int slot = LT >= 256 ? 0 : (int)threadIdx.x / LT;
+    const int lt = LT >= 256 ? (int)(blockIdx.y * 256 + threadIdx.x) : (int)threadIdx.x % LT;
+    if (slot >= tpb || lt >= LT) return;
+    const int c = lt & 15, h = lt >> 4;
     const int HD = p.H * 128;
-    float tk[8], tv[8];
-    unpack8(*(const u32x4*)(p.tb + n * p.ldt), tk);
-    unpack8(*(const u32x4*)(p.tb + n * p.ldt + 8), tv);
-    const bf16_t* bk = vis ? p.bk_v : p.bk_l;
-    const bf16_t* bv = vis ? p.bv_v : p.bv_l;
-    float cs[2][8], sn[2][8];
-    float q[2][8], k[2][8], v[2][8], kb[2][8], vb[2][8];
+    const long n_first = (long)blockIdx.x * ROPE_TOK * tpb + slot;
+    u32x4 wk[2][4], wv[2][4];
+    int cur_mod = -1;
+    for (int j = 0; j < ROPE_TOK; ++j) {
+        const long n = n_first + (long)j * tpb;
+        if (n >= p.N) break;
+        const int s = (int)(n % p.S);
+        const int vis = p.flag[n] != 0;
+        if (vis != cur_mod) {
+            const bf16_t* bk = vis ? p.bk_v : p.bk_l;
+            const bf16_t* bv = vis ? p.bv_v : p.bv_l;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int d = hf * 64 + c * 8;
-        const long col = (long)h * 128 + d;
-        unpack8(*(const u32x4*)(p.cos + (long)s * 128 + d), cs[hf]);
-        unpack8(*(const u32x4*)(p.sin + (long)s * 128 + d), sn[hf]);
-        unpack8(*(const u32x4*)(p.qkv + n * p.ld + col), q[hf]);
-        unpack8(*(const u32x4*)(p.qkv + n * p.ld + HD + col), k[hf]);
-        unpack8(*(const u32x4*)(p.qkv + n * p.ld + 2 * HD + col), v[hf]);
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float wk[8], wv[8];
-            unpack8(*(const u32x4*)(bk + (col + e) * 8), wk);
-            unpack8(*(const u32x4*)(bv + (col + e) * 8), wv);
-            float a = 0.f, b2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { a = fmaf(tk[r], wk[r], a); b2 = fmaf(tv[r], wv[r], b2); }
-            kb[hf][e] = rbf(a);
-            vb[hf][e] = rbf(b2);
+                for (int e = 0; e < 4; ++e) {
+                    const long col = (long)h * 128 + hf * 64 + c * 4 + e;
+                    wk[hf][e] = *(const u32x4*)(bk + col * 8);
+                    wv[hf][e] = *(const u32x4*)(bv + col * 8);
+                }
+            cur_mod = vis;
         }
-    }
-    float qo[2][8], ko[2][8], kc[2][8], vc[2][8];
+        float tk[8], tv[8];
+        unpack8(*(const u32x4*)(p.tb + n * p.ldt), tk);
+        unpack8(*(const u32x4*)(p.tb + n * p.ldt + 8), tv);
+        float cs[2][4], sn[2][4];
+        float q[2][4], k[2][4], v[2][4], kb[2][4], vb[2][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float kx0 = rbf(k[0][e] + kb[0][e]), kx1 = rbf(k[1][e] + kb[1][e]);
-        // x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
-        qo[0][e] = rbf(rbf(q[0][e] * cs[0][e]) + rbf(-q[1][e] * sn[0][e]));
-        qo[1][e] = rbf(rbf(q[1][e] * cs[1][e]) + rbf(q[0][e] * sn[1][e]));
-        ko[0][e] = rbf(rbf(k[0][e] * cs[0][e]) + rbf(-k[1][e] * sn[0][e]));
-        ko[1][e] = rbf(rbf(k[1][e] * cs[1][e]) + rbf(k[0][e] * sn[1][e]));
-        kc[0][e] = rbf(rbf(kx0 * cs[0][e]) + rbf(-kx1 * sn[0][e]));
-        kc[1][e] = rbf(rbf(kx1 * cs[1][e]) + rbf(kx0 * sn[1][e]));
-        vc[0][e] = v[0][e] + vb[0][e];
-        vc[1][e] = v[1][e] + vb[1][e];
-    }
+        for (int hf = 0; hf < 2; ++hf) {
+            const int d = hf * 64 + c * 4;
+            const long col = (long)h * 128 + d;
+            unpack4(*(const u32x2*)(p.cos + (long)s * 128 + d), cs[hf]);
+            unpack4(*(const u32x2*)(p.sin + (long)s * 128 + d), sn[hf]);
+            unpack4(*(const u32x2*)(p.qkv + n * p.ld + col), q[hf]);
+            unpack4(*(const u32x2*)(p.qkv + n * p.ld + HD + col), k[hf]);
+            unpack4(*(const u32x2*)(p.qkv + n * p.ld + 2 * HD + col), v[hf]);
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const long col = (long)h * 128 + hf * 64 + c * 8;
-        *(u32x4*)(p.qkv + n * p.ld + col) = pack8(qo[hf]);
-        *(u32x4*)(p.qkv + n * p.ld + HD + col) = pack8(ko[hf]);
-        *(u32x4*)(p.k_cross + n * p.ldc + col) = pack8(kc[hf]);
-        *(u32x4*)(p.v_cross + n * p.ldc + col) = pack8(vc[hf]);
+            for (int e = 0; e < 4; ++e) {
+                float wkf[8], wvf[8];
+                unpack8(wk[hf][e], wkf);
+                unpack8(wv[hf][e], wvf);
+                float a = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { a = fmaf(tk[r], wkf[r], a); b2 = fmaf(tv[r], wvf[r], b2); }
+                kb[hf][e] = rbf(a);
+                vb[hf][e] = rbf(b2);
+            }
+        }
+        float qo[2][4], ko[2][4], kc[2][4], vc[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float kx0 = rbf(k[0][e] + kb[0][e]), kx1 = rbf(k[1][e] + kb[1][e]);
+            // x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
+            qo[0][e] = rbf(rbf(q[0][e] * cs[0][e]) + rbf(-q[1][e] * sn[0][e]));
+            qo[1][e] = rbf(rbf(q[1][e] * cs[1][e]) + rbf(q[0][e] * sn[1][e]));
+            ko[0][e] = rbf(rbf(k[0][e] * cs[0][e]) + rbf(-k[1][e] * sn[0][e]));
+            ko[1][e] = rbf(rbf(k[1][e] * cs[1][e]) + rbf(k[0][e] * sn[1][e]));
+            kc[0][e] = rbf(rbf(kx0 * cs[0][e]) + rbf(-kx1 * sn[0][e]));
+            kc[1][e] = rbf(rbf(kx1 * cs[1][e]) + rbf(kx0 * sn[1][e]));
+            vc[0][e] = v[0][e] + vb[0][e];
+            vc[1][e] = v[1][e] + vb[1][e];
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const long col = (long)h * 128 + hf * 64 + c * 4;
+            *(u32x2*)(p.qkv + n * p.ld + col) = pack4(qo[hf]);
+            *(u32x2*)(p.qkv + n * p.ld + HD + col) = pack4(ko[hf]);
+            *(u32x2*)(p.k_cross + n * p.ldc + col) = pack4(kc[hf]);
+            *(u32x2*)(p.v_cross + n * p.ldc + col) = pack4(vc[hf]);
+        }
     }
 }
 
@@ -259,8 +289,10 @@ extern "C" int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t 
     a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
     a.flag = flag; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
     a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
-    const long total = N * H * 8;
-    hipLaunchKernelGGL(rope_bridge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    const long LT = H * 16, tpb = LT >= 256 ? 1 : 256 / LT;
+    const long gx = (N + ROPE_TOK * tpb - 1) / (ROPE_TOK * tpb), gy = LT >= 256 ? (LT + 255) / 256 : 1;
+    if (gx > 0x7fffffffL || gy > 65535) return LIBRA_ERR_SHAPE;
+    hipLaunchKernelGGL(rope_bridge_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, a);
     return launched();
 }
 

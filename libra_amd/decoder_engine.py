@@ -11,7 +11,8 @@ accumulation is fp32 in the MFMA.  Reference file:line citations: include/libra_
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Optional
+import os
+from typing import Dict, List, Optional
 
 import torch
 
@@ -282,9 +283,51 @@ def _compact(t2d: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return buf[:n]
 
 
-def _wg(dy_c: torch.Tensor, x_c: torch.Tensor) -> torch.Tensor:
-    """dW[out, in] = sum_tokens dy[t, out] x[t, in]; both operands token-major, padded (LIBRA_GEMM_A_T | _B_T)."""
-    return K.gemm_nt(_full(dy_c), _full(x_c), a_t=True, b_t=True)
+class _WgradStream:
+    """Weight gradients are off the backward's critical path (nothing downstream consumes them), so they are enqueued on
+    a second HIP stream: their workgroups fill the CUs that the partial last waves of the dgrad GEMMs and the row kernels
+    leave idle.  Ordering is by stream waits; operands are pinned against the caching allocator with record_stream (they
+    are fresh compact buffers or saved activations - nothing the main stream later overwrites in place)."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = torch.cuda.Stream(device=device)
+        self.enabled = os.environ.get("LIBRA_NO_SIDE_STREAM", "0") != "1"     # (diagnostics: serial launch order)
+        self.outs: List[torch.Tensor] = []
+
+    def run(self, fn, *operands):
+        if not self.enabled:
+            return fn()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in operands:
+            t.record_stream(self.side)
+        self.outs.extend(out if isinstance(out, tuple) else (out,))
+        return out
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t in self.outs:
+                t.record_stream(self.main)
+        self.outs = []
+
+
+_wgrad_stream: Optional[_WgradStream] = None
+
+
+def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None):
+    """dW[out, in] = sum_tokens dy[t, out] x[t, in]; both operands token-major, padded (LIBRA_GEMM_A_T | _B_T).
+    `post` (slicing that launches copies) runs on the same stream as the GEMM."""
+    a, b = _full(dy_c), _full(x_c)
+
+    def work():
+        o = K.gemm_nt(a, b, a_t=True, b_t=True)
+        return post(o) if post is not None else o
+    if _wgrad_stream is None:
+        return work()
+    return _wgrad_stream.run(work, a, b)
 
 
 def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
@@ -296,6 +339,8 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     dev = flag.device
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     cos, sin, lens = sv["cos"], sv["sin"], sv["lens"]
+    global _wgrad_stream
+    _wgrad_stream = _WgradStream(dev)
     g: Dict[str, torch.Tensor] = {}
     f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
     w = lambda name: name in want
@@ -375,6 +420,8 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         tok = sv["input_ids"][0].reshape(-1).index_select(0, lang_idx.long())
         acc.index_add_(0, tok, dx.index_select(0, lang_idx.long()).float())
         g["model.embed_tokens.weight"] = acc.to(BF16)
+    _wgrad_stream.join()
+    _wgrad_stream = None
     return g
 
 
@@ -465,9 +512,9 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         if w(nk) or w(nv):
             tbc = _compact(tb, idx)
             if w(nk):
-                g[nk] = _wg(_compact(dkb, idx), tbc[:, 0:8])[:, :d.rank].contiguous()
+                g[nk] = _wg(_compact(dkb, idx), tbc[:, 0:8], post=lambda o: o[:, :d.rank].contiguous())
             if w(nv):
-                g[nv] = _wg(_compact(dvb, idx), tbc[:, 8:16])[:, :d.rank].contiguous()
+                g[nv] = _wg(_compact(dvb, idx), tbc[:, 8:16], post=lambda o: o[:, :d.rank].contiguous())
     dh = torch.empty((N, H), dtype=BF16, device=dev)
     if n_l:
         K.gemm_nt(dqkv, pk["wqkv"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)
@@ -481,8 +528,8 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
         if w(nk) or w(nv):
             hl = _compact(h, lang_idx) if hl is None else hl
-            dab = _wg(_compact(dtb, lang_idx), hl)                                          # [64, H]
-            g[nk], g[nv] = dab[0:d.rank].contiguous(), dab[8:8 + d.rank].contiguous()
+            g[nk], g[nv] = _wg(_compact(dtb, lang_idx), hl,                                  # [64, H]
+                               post=lambda o: (o[0:d.rank].contiguous(), o[8:8 + d.rank].contiguous()))
     if n_v:
         t = sv["t"]
         dqkv_v = _compact(dqkv, vis_idx)                                                    # [n_v, 3H]
@@ -500,8 +547,8 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
                 g[a + f"vision_{nm}_proj.weight_A"] = da[j * r:(j + 1) * r]
         nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
         if w(nk) or w(nv):
-            dab = _wg(_compact(dtb, vis_idx), hv)
-            g[nk], g[nv] = dab[0:d.rank].contiguous(), dab[8:8 + d.rank].contiguous()
+            g[nk], g[nv] = _wg(_compact(dtb, vis_idx), hv,
+                               post=lambda o: (o[0:d.rank].contiguous(), o[8:8 + d.rank].contiguous()))
     ln_l, ln_v = pre + "input_layernorm.weight", pre + "vision_input_layernorm.weight"
     dx = K.rmsnorm_routed_bwd(dh, sv["x"], sd[ln_l], sd[ln_v], flag, sv["rstd1"], dres=dx_mid)
     if w(ln_l) or w(ln_v):

@@ -362,7 +362,8 @@ def _gemm_flops(a, b, **kw):
     a_t, b_t = kw.get("a_t", False), kw.get("b_t", False)
     k = kw.get("k") or (a.shape[0] if a_t else a.shape[1])
     m = kw["a_rows"].numel() if kw.get("a_rows") is not None else (a.shape[1] if a_t else a.shape[0])
-    return 2.0 * m * (b.shape[1] if b_t else b.shape[0]) * k
+    n = b.shape[1] if b_t else b.shape[0]
+    return (2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))          # (FLOP, algorithmic operand + result bytes)
 
 
 gemm_nt = _profiled("gemm", _gemm_flops)(gemm_nt)

@@ -1,0 +1,25 @@
+"""rope_bridge / rope_bridge_bwd at the Libra-11B shape (N = 8 x 2048 tokens, H = 32)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from libra_amd import kernels as K
+from oracle import libra_oracle as LO    # (rope tables only; this is a bench tool, not the product path)
+B, S, H = 8, 2048, 32
+N, D = B * S, H * 128
+bf = torch.bfloat16
+qkv = torch.randn(N, 3 * D, device="cuda").to(bf)
+tb = torch.zeros(N, 64, device="cuda", dtype=bf); tb[:, :16] = torch.randn(N, 16, device="cuda").to(bf)
+w = [torch.randn(D, 8, device="cuda").to(bf) * 0.3 for _ in range(4)]
+flag = torch.zeros(B, S, dtype=torch.uint8); flag[:, 1:579] = 1
+flag = flag.reshape(N).cuda()
+cosf, sinf = LO.rope_tables(128, S)
+cos, sin = cosf.to(bf).cuda(), sinf.to(bf).cuda()
+def run():
+    K.rope_bridge(qkv, tb, *w, flag, cos, sin, S, H)
+for _ in range(3): run()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); s.record()
+for _ in range(10): run()
+e.record(); torch.cuda.synchronize()
+us = s.elapsed_time(e) * 100
+print(f"rope_bridge: {us:.1f} us  ({(qkv.numel() * 2 * (1 + 2 / 3) + 2 * N * D * 2) / us / 1e6:.2f} TB/s algorithmic)")
