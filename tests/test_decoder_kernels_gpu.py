@@ -131,6 +131,24 @@ def test_bridge_attention_bwd(K, B, S, H, mode):
         assert torch.isfinite(g.float()).all(), n
 
 
+def test_bridge_attention_bwd_deterministic(K):
+    """No atomics anywhere: two runs are bit-identical (also a race screen for the LDS-DMA / barrier ordering)."""
+    B, S, H = 2, 1100, 2
+    N, D = B * S, H * 128
+    q, ks, kc, vs, vc = [rnd(N, D, seed=40 + i) for i in range(5)]
+    do = rnd(N, D, seed=50)
+    flag = _flags(N, 11, "span").cuda()
+    lens = torch.tensor([S, S - 300], dtype=torch.int32).cuda()
+    sc = 128 ** -0.5
+    runs = []
+    for _ in range(3):
+        o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True)
+        runs.append((o, lse) + tuple(K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag, lens, lse, B, S, H, sc)))
+    for r in runs[1:]:
+        for x, y in zip(runs[0], r):
+            assert torch.equal(x, y)
+
+
 def test_rope_bridge(K):
     from oracle import libra_oracle as LO
     B, S, H = 2, 24, 2

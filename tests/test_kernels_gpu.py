@@ -92,6 +92,39 @@ def test_gemm_epilogues(K):
     assert float(wide[:, :64].abs().max()) == 0.0
 
 
+def test_gemm_row_split_dispatch(K):
+    """Problems whose 256^2 tiles fill 1-2 waves plus a partial one are split by rows: whole waves on the 256^2 kernel,
+    the rest on the 128^2 kernel (gemm_bf16.hip plan_rows256).  Every fused operand must follow the split: row gather /
+    scatter maps, residual, aux, pre-activation store, transposed A."""
+    M, N, K_ = 18464, 1024, 4096                   # 73 x 4 tiles = 1.14 waves -> rows [0, 16384) + [16384, 18464)
+    a, b = rnd(M, K_, seed=21, scale=0.5), rnd(N, K_, seed=22, scale=0.1)
+    base = a.float() @ b.float().t()
+    close(K.gemm_nt(a, b), base, what="split plain")
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    close(K.gemm_nt(a, b, bias=bias, resid=res), base + bias.float() + res.float(), what="split bias+resid")
+    aux = rnd(M, N, seed=25)
+    x = aux.float(); sg = torch.sigmoid(1.702 * x)
+    close(K.gemm_nt(a, b, qgelu_grad_of=aux), base * (sg * (1 + 1.702 * x * (1 - sg))), what="split qgelu_grad")
+    pre = torch.empty(M, N, dtype=BF, device="cuda")
+    out = K.gemm_nt(a, b, bias=bias, quick_gelu=True, preact_out=pre)
+    close(pre, base + bias.float(), what="split preact")
+    close(out, pre.float() * torch.sigmoid(1.702 * pre.float()), what="split quick_gelu")
+    # transposed operands
+    close(K.gemm_nt(a.t().contiguous(), b.t().contiguous(), a_t=True, b_t=True), base, what="split TT")
+    # routed: gather A rows from a taller buffer, scatter C rows into a taller buffer with a residual read there
+    g = torch.Generator().manual_seed(5)
+    phys = M + 1000
+    rows = torch.randperm(phys, generator=g)[:M].to(torch.int32).cuda()
+    abig = rnd(phys, K_, seed=26, scale=0.5)
+    rbig = rnd(phys, N, seed=27)
+    cbig = torch.zeros(phys, N, dtype=BF, device="cuda")
+    K.gemm_nt(abig, b, out=cbig, a_rows=rows, c_rows=rows, resid=rbig)
+    ref = abig[rows.long()].float() @ b.float().t() + rbig[rows.long()].float()
+    close(cbig[rows.long()], ref, what="split routed")
+    untouched = torch.ones(phys, dtype=torch.bool, device="cuda"); untouched[rows.long()] = False
+    assert float(cbig[untouched].abs().max()) == 0.0
+
+
 def test_gemm_rejects_bad_shapes(K):
     a, b = rnd(64, 96), rnd(64, 96)
     with pytest.raises(ValueError):
