@@ -61,6 +61,15 @@ int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t
                               int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
                               const int32_t* c_rows, void* stream);
 
+/* Grouped launch: `groups` (<= 4) GEMMs of identical shape, strides, flags (A_T / B_T only) and row maps but different
+ * operand pointers run as ONE launch (blockIdx.z = group), so that several mid-sized problems fill whole waves of
+ * workgroups together - e.g. the three low-rank vision projections LibraLinear.weight_B of q, k, v (modeling_libra.py:64-90),
+ * each 1.19 waves of 256^2 tiles on their own.  No fused epilogue operands.                                          */
+int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* const* B, int64_t ldb, void* const* C,
+                               int64_t ldc, int64_t groups, int64_t M, int64_t N, int64_t K, float alpha,
+                               int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
+                               const int32_t* c_rows, void* stream);
+
 /* split-K variant for wgrad-shaped problems (small M,N, very long K; no epilogue): K slices on the 256^2
  * kernel, fp32 partial slabs in `workspace`, deterministic reduction to bf16 C.  plan() suggests the number
  * of slices for a shape (1 = use libra_gemm_bf16_nt).  N % 8 == 0; flags: LIBRA_GEMM_A_T / _B_T only.                                  */

@@ -43,6 +43,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     float alpha; int alpha_cols;
     int flags;
+    const bf16_t* Ag[3]; const bf16_t* Bg[3]; bf16_t* Cg[3];   // grouped launch: operands of groups 1..3 (blockIdx.z)
 };
 
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
@@ -70,6 +71,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
     const int tm = first_m + (u % width) % gsz;
     const int tn = (u % width) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
+    const bf16_t* Ap = p.A; const bf16_t* Bp = p.B; bf16_t* Cp = p.C;          // grouped launch: blockIdx.z picks the group
+    {   // (constant indices + selects: a dynamically indexed kernel-argument array would be copied to scratch)
+        const int g = blockIdx.z;
+        if (g == 1) { Ap = p.Ag[0]; Bp = p.Bg[0]; Cp = p.Cg[0]; }
+        else if (g == 2) { Ap = p.Ag[1]; Bp = p.Bg[1]; Cp = p.Cg[1]; }
+        else if (g == 3) { Ap = p.Ag[2]; Bp = p.Bg[2]; Cp = p.Cg[2]; }
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -90,8 +98,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
     const long kstepA = ktile_stride<AT>(p.lda), kstepB = ktile_stride<BT>(p.ldb);
     auto stage = [&](int buf, int kt) {
         char* da = smem + buf * 2 * TILE_BYTES + wave * 4096;
-        const bf16_t* ga = p.A + kt * kstepA;
-        const bf16_t* gb = p.B + kt * kstepB;
+        const bf16_t* ga = Ap + kt * kstepA;
+        const bf16_t* gb = Bp + kt * kstepB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(ga + srcA[j], da + j * 1024);
 #pragma unroll
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
         }
-        bf16_t* dst = p.C + (long)om * p.ldc + gn;
+        bf16_t* dst = Cp + (long)om * p.ldc + gn;
         if (full8) {
             *(u32x4*)dst = pack8(v);
         } else {
@@ -229,7 +237,8 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                      int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
                                      float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
-                                     const int* a_rows, const int* c_rows, void* stream);
+                                     const int* a_rows, const int* c_rows, void* stream, int groups,
+                                     const void* const* Ag, const void* const* Bg, void* const* Cg);
 
 extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                          int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
@@ -249,14 +258,14 @@ static double cost128(double tiles, double kt) {
     return full * (5.8 + 1.245 * kt) + (rest <= 0 ? 0.0 : rest <= 256.0 ? 4.8 + 0.606 * kt      // <= 1 block / CU: it owns the CU
                                                                           : 5.8 + 1.245 * kt);
 }
-static int64_t plan_rows256(int64_t M, int64_t N, int64_t K) {
+static int64_t plan_rows256(int64_t M, int64_t N, int64_t K, int64_t groups = 1) {
     static int mode = -1;                          // LIBRA_GEMM_KERNEL = 128 | 256 forces a structure (benchmarks)
     if (mode < 0) { const char* e = getenv("LIBRA_GEMM_KERNEL"); mode = e ? atoi(e) : 0; }
     if (mode == 128) return 0;
     if (mode == 256) return M;
     if (M < 256 || N < 256 || K < 256) return 0;
     const double kt = (double)K / 64.0;
-    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tn128 = (N + 127) / 128;
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256 * groups, tn128 = (N + 127) / 128 * groups;   // per tile row, all groups
     double best = cost128((double)((M + 127) / 128) * tn128, kt);            // everything on the small kernel
     int64_t rows = 0;
     const double all256 = cost256((double)(tm * tn), kt);
@@ -301,7 +310,7 @@ extern "C" int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void*
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) return LIBRA_ERR_ALIGN;
     if (!workspace || workspace_bytes < libra_gemm_splitk_workspace_bytes(M, N, splits)) return LIBRA_ERR_ALIGN;
     return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 1.0f, 0, flags,
-                                 (float*)workspace, (int)splits, nullptr, nullptr, stream);
+                                 (float*)workspace, (int)splits, nullptr, nullptr, stream, 1, nullptr, nullptr, nullptr);
 }
 
 extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
@@ -312,11 +321,13 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
                                      alpha_cols, flags, nullptr, M, nullptr, stream);
 }
 
-extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                         int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
-                                         int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
-                                         float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
-                                         int64_t a_phys_rows, const int32_t* c_rows, void* stream) {
+// Shared body of the plain / routed / grouped entry points.  `groups` problems of identical shape, strides and row maps;
+// A/B/C = group 0, Ag/Bg/Cg = groups 1.. (fused epilogue operands only with groups == 1).
+static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, const void* bias, const void* resid, int64_t ldr, const void* aux, int64_t ldaux, void* preact,
+                    int64_t ldpre, float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
+                    const int32_t* c_rows, void* stream, int groups, const void* const* Ag_in, const void* const* Bg_in,
+                    void* const* Cg_in) {
     if (M <= 0 || N <= 0) return LIBRA_OK;                       // empty problem: nothing to do
     if (!A || !B || !C || K <= 0 || (K % BK) != 0) return LIBRA_ERR_SHAPE;
     const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
@@ -333,19 +344,30 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
     if ((flags & LIBRA_GEMM_MUL_QGELU_GRAD) && (!aux || (ldaux % 8) || ((uintptr_t)aux & 15))) return LIBRA_ERR_ALIGN;
     if ((flags & LIBRA_GEMM_STORE_PREACT) && (!preact || (ldpre % 8) || ldpre < N || ((uintptr_t)preact & 15))) return LIBRA_ERR_ALIGN;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return LIBRA_ERR_SHAPE;
+    const void* Ag[3] = {nullptr, nullptr, nullptr}; const void* Bg[3] = {nullptr, nullptr, nullptr};
+    void* Cg[3] = {nullptr, nullptr, nullptr};
+    for (int g = 0; g + 1 < groups; ++g) {
+        Ag[g] = Ag_in[g]; Bg[g] = Bg_in[g]; Cg[g] = Cg_in[g];
+        if (!Ag[g] || !Bg[g] || !Cg[g] || (((uintptr_t)Ag[g] | (uintptr_t)Bg[g] | (uintptr_t)Cg[g]) & 15)) return LIBRA_ERR_ALIGN;
+    }
 
     // ---- leading rows on the 256^2 kernel, the rest (if any) on the 128^2 kernel below ----
-    const int64_t rows256 = plan_rows256(M, N, K);
+    const int64_t rows256 = plan_rows256(M, N, K, groups);
     if (rows256 > 0) {
         const int rc = libra_gemm256_launch_(A, lda, B, ldb, C, ldc, rows256, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre,
-                                             alpha, alpha_cols, flags, nullptr, 1, a_rows, c_rows, stream);
+                                             alpha, alpha_cols, flags, nullptr, 1, a_rows, c_rows, stream, groups, Ag, Bg, Cg);
         if (rc != LIBRA_OK || rows256 >= M) return rc;
         // remaining output rows [rows256, M): gathered / scattered operands advance their row maps, the others their base
         const int64_t m0 = rows256;
-        if (a_rows) a_rows += m0; else A = (const bf16_t*)A + (at ? m0 : m0 * lda);
+        if (a_rows) a_rows += m0;
+        else {
+            A = (const bf16_t*)A + (at ? m0 : m0 * lda);
+            for (int g = 0; g + 1 < groups; ++g) Ag[g] = (const bf16_t*)Ag[g] + (at ? m0 : m0 * lda);
+        }
         if (c_rows) c_rows += m0;
         else {
             C = (bf16_t*)C + m0 * ldc;
+            for (int g = 0; g + 1 < groups; ++g) Cg[g] = (bf16_t*)Cg[g] + m0 * ldc;
             if (resid) resid = (const bf16_t*)resid + m0 * ldr;
             if (aux) aux = (const bf16_t*)aux + m0 * ldaux;
             if (preact) preact = (bf16_t*)preact + m0 * ldpre;
@@ -360,6 +382,7 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     p.alpha = alpha; p.alpha_cols = (int)alpha_cols; p.flags = flags;
     p.a_rows = a_rows; p.c_rows = c_rows;
+    for (int g = 0; g < 3; ++g) { p.Ag[g] = (const bf16_t*)Ag[g]; p.Bg[g] = (const bf16_t*)Bg[g]; p.Cg[g] = (bf16_t*)Cg[g]; }
 
     const long nblk = (long)p.tiles_m * p.tiles_n;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
@@ -370,6 +393,26 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         attr_set[at * 2 + bt] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(GEMM_THREADS), GEMM_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, 1, (unsigned)groups), dim3(GEMM_THREADS), GEMM_LDS, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+}
+
+extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                         int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                         int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                         float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
+                                         int64_t a_phys_rows, const int32_t* c_rows, void* stream) {
+    return gemm_run(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha, alpha_cols, flags,
+                    a_rows, a_phys_rows, c_rows, stream, 1, nullptr, nullptr, nullptr);
+}
+
+extern "C" int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* const* B, int64_t ldb, void* const* C,
+                                          int64_t ldc, int64_t groups, int64_t M, int64_t N, int64_t K, float alpha,
+                                          int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
+                                          const int32_t* c_rows, void* stream) {
+    if (groups <= 0) return LIBRA_OK;
+    if (groups > 4 || !A || !B || !C) return LIBRA_ERR_SHAPE;
+    if (flags & ~(LIBRA_GEMM_A_T | LIBRA_GEMM_B_T)) return LIBRA_ERR_SHAPE;          // no fused epilogue operands in a grouped launch
+    return gemm_run(A[0], lda, B[0], ldb, C[0], ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, alpha, alpha_cols,
+                    flags, a_rows, a_phys_rows, c_rows, stream, (int)groups, A + 1, B + 1, C + 1);
 }

@@ -38,6 +38,7 @@ struct Gemm256Args {
     float alpha; int alpha_cols;
     int flags;
     float* slab; int splitk;          // split-K: raw fp32 partial tiles to slab[split][M][N] (no epilogue)
+    const bf16_t* Ag[3]; const bf16_t* Bg[3]; bf16_t* Cg[3];   // grouped launch: operands of groups 1..3 (blockIdx.z)
 };
 
 __device__ __forceinline__ float qgelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
@@ -68,6 +69,14 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     const int tm = first_m + (u % width) % gsz;
     const int tn = (u % width) / gsz;
     const int m0 = tm * 256, n0 = tn * 256;
+    // grouped launch (same shapes / strides / row maps, different operands): blockIdx.z picks the group
+    const bf16_t* Ap = p.A; const bf16_t* Bp = p.B; bf16_t* Cp = p.C;
+    {   // (constant indices + selects: a dynamically indexed kernel-argument array would be copied to scratch)
+        const int g = blockIdx.z;
+        if (g == 1) { Ap = p.Ag[0]; Bp = p.Bg[0]; Cp = p.Cg[0]; }
+        else if (g == 2) { Ap = p.Ag[1]; Bp = p.Bg[1]; Cp = p.Cg[1]; }
+        else if (g == 3) { Ap = p.Ag[2]; Bp = p.Bg[2]; Cp = p.Cg[2]; }
+    }
 
     // ---- per-lane source offsets (elements) of this wave's 2 x 1-KiB pieces of every half-tile type
     unsigned srcA[2][2], srcB[2][2];
@@ -83,13 +92,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
 
     auto stageA = [&](int h, int kt) {
         char* dst = smem + (kt & 1) * KTB + h * HB + ldst;
-        const bf16_t* base = p.A + kt * kstepA;
+        const bf16_t* base = Ap + kt * kstepA;
         glds16(base + srcA[h][0], dst);
         glds16(base + srcA[h][1], dst + 1024);
     };
     auto stageB = [&](int h, int kt) {
         char* dst = smem + (kt & 1) * KTB + (2 + h) * HB + ldst;
-        const bf16_t* base = p.B + kt * kstepB;
+        const bf16_t* base = Bp + kt * kstepB;
         glds16(base + srcB[h][0], dst);
         glds16(base + srcB[h][1], dst + 1024);
     };
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += x[e];
                 }
-                bf16_t* dst = p.C + (long)om * p.ldc + gn;
+                bf16_t* dst = Cp + (long)om * p.ldc + gn;
                 if (full8) *(u32x4*)dst = pack8(v);
                 else for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
             }
@@ -319,9 +328,14 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
                                      int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
                                      float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
-                                     const int* a_rows, const int* c_rows, void* stream) {
+                                     const int* a_rows, const int* c_rows, void* stream, int groups,
+                                     const void* const* Ag, const void* const* Bg, void* const* Cg) {
     Gemm256Args p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
+    for (int g = 0; g < 3; ++g) {
+        const bool on = g + 1 < groups;
+        p.Ag[g] = on ? (const bf16_t*)Ag[g] : nullptr; p.Bg[g] = on ? (const bf16_t*)Bg[g] : nullptr; p.Cg[g] = on ? (bf16_t*)Cg[g] : nullptr;
+    }
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldpre = ldpre;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
@@ -339,7 +353,8 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
         attr_set[at * 2 + bt] = true;
     }
     const long nblk = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)p.splitk), dim3(G256_THREADS), G256_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)p.splitk, (unsigned)(groups < 1 ? 1 : groups)), dim3(G256_THREADS), G256_LDS,
+                       (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     if (slab) {
         const long MN = (long)M * N;

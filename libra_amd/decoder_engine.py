@@ -158,9 +158,10 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
         K.gemm_nt(h, pk["ab_l"], out=tb, a_rows=lang_idx, c_rows=lang_idx)
     if n_v:
         t = K.gemm_nt(h, pk["aqkv"], a_rows=vis_idx, out=_rows(n_v, 3 * r, dev, save))                  # [n_v, 3r]
-        for j, nm in enumerate(("q", "k", "v")):
-            K.gemm_nt(t[:, j * r:(j + 1) * r], sd[a + f"vision_{nm}_proj.weight_B"], out=qkv[:, j * H:(j + 1) * H],
-                      c_rows=vis_idx)
+        # the three rank-r expansions share one launch (each alone is 1.2 waves of 256^2 tiles)
+        K.gemm_nt_grouped([t[:, j * r:(j + 1) * r] for j in range(3)],
+                          [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
+                          [qkv[:, j * H:(j + 1) * H] for j in range(3)], c_rows=vis_idx)
         K.gemm_nt(h, pk["ab_v"], out=tb, a_rows=vis_idx, c_rows=vis_idx)
     kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
     o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
@@ -184,8 +185,8 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     if n_v:
         tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save))               # [n_v, 2 rg]
         guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
-        K.gemm_nt(tg[:, :rg], sd[m + "vision_gate_proj.weight_B"], out=guv[:, :I])
-        K.gemm_nt(tg[:, rg:], sd[m + "vision_up_proj.weight_B"], out=guv[:, I:])
+        K.gemm_nt_grouped([tg[:, :rg], tg[:, rg:]], [sd[m + "vision_gate_proj.weight_B"], sd[m + "vision_up_proj.weight_B"]],
+                          [guv[:, :I], guv[:, I:]])
         actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save))
         td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save))
         K.gemm_nt(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)
@@ -461,8 +462,8 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         dguv = K.alloc_rows(n_v, 2 * I, dev)[:n_v]
         K.swiglu_bwd(dactv, guv[:, :I], guv[:, I:], dguv[:, :I], dguv[:, I:])
         dtg = K.alloc_rows(n_v, 2 * rg, dev)[:n_v]
-        K.gemm_nt(dguv[:, :I], sd[m + "vision_gate_proj.weight_B"], b_t=True, out=dtg[:, :rg])
-        K.gemm_nt(dguv[:, I:], sd[m + "vision_up_proj.weight_B"], b_t=True, out=dtg[:, rg:])
+        K.gemm_nt_grouped([dguv[:, :I], dguv[:, I:]], [sd[m + "vision_gate_proj.weight_B"], sd[m + "vision_up_proj.weight_B"]],
+                          [dtg[:, :rg], dtg[:, rg:]], b_t=True)
         if w(m + "vision_gate_proj.weight_B"):
             g[m + "vision_gate_proj.weight_B"] = _wg(dguv[:, :I], tg[:, :rg])
         if w(m + "vision_up_proj.weight_B"):
@@ -534,8 +535,10 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         t = sv["t"]
         dqkv_v = _compact(dqkv, vis_idx)                                                    # [n_v, 3H]
         dt = K.alloc_rows(n_v, 3 * r, dev)[:n_v]
+        K.gemm_nt_grouped([dqkv_v[:, j * H:(j + 1) * H] for j in range(3)],
+                          [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
+                          [dt[:, j * r:(j + 1) * r] for j in range(3)], b_t=True)
         for j, nm in enumerate(("q", "k", "v")):
-            K.gemm_nt(dqkv_v[:, j * H:(j + 1) * H], sd[a + f"vision_{nm}_proj.weight_B"], b_t=True, out=dt[:, j * r:(j + 1) * r])
             if w(a + f"vision_{nm}_proj.weight_B"):
                 g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r])
         K.gemm_nt(dt, pk["aqkv"], b_t=True, out=dh, c_rows=vis_idx)

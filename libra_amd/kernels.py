@@ -117,6 +117,48 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     return out
 
 
+def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], *,
+                    a_t: bool = False, b_t: bool = False, a_rows: Optional[torch.Tensor] = None,
+                    c_rows: Optional[torch.Tensor] = None) -> Sequence[torch.Tensor]:
+    """outs[g] = A_g @ B_g^T for up to 4 problems of identical shape / strides / row maps in ONE launch (the groups
+    share whole waves of workgroups).  Same operand conventions as gemm_nt; no fused epilogue operands."""
+    G = len(a_list)
+    if not (1 <= G <= 4) or len(b_list) != G or len(outs) != G:
+        raise ValueError("gemm_nt_grouped: 1..4 groups, one a / b / out each")
+    for t in list(a_list) + list(b_list) + list(outs):
+        _chk2d(t, "gemm_nt_grouped operand")
+    a0, b0, o0 = a_list[0], b_list[0], outs[0]
+    for a, b, o in zip(a_list, b_list, outs):
+        if a.shape != a0.shape or b.shape != b0.shape or o.shape != o0.shape or a.stride(0) != a0.stride(0) \
+                or b.stride(0) != b0.stride(0) or o.stride(0) != o0.stride(0):
+            raise ValueError("gemm_nt_grouped: all groups must share shapes and row strides")
+    (Ka, M) = a0.shape if a_t else a0.shape[::-1]
+    a_phys = a0.shape[0]
+    if a_rows is not None:
+        if a_t:
+            raise ValueError("gemm_nt_grouped: a_rows needs a K-contiguous A")
+        M = a_rows.numel()
+    (Kb, N) = b0.shape if b_t else b0.shape[::-1]
+    if Ka != Kb or Ka % 64:
+        raise ValueError(f"gemm_nt_grouped: inner dims {Ka} vs {Kb} (must match, multiple of 64)")
+    if c_rows is None and o0.shape != (M, N):
+        raise ValueError("gemm_nt_grouped: out shape")
+    if c_rows is not None and (c_rows.numel() != M or o0.shape[1] != N):
+        raise ValueError("gemm_nt_grouped: c_rows / out shape")
+    arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
+    flags = (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0)
+    prof = LaunchProfile.active
+    if prof is not None:
+        ev = prof.bracket("gemm", (2.0 * M * N * Ka * G, 2.0 * G * (M * Ka + N * Ka + M * N)))
+        ev[0].record()
+    rc = _lib.lib().libra_gemm_bf16_nt_grouped(arr(a_list), a0.stride(0), arr(b_list), b0.stride(0), arr(outs), o0.stride(0),
+                                               G, M, N, Ka, 1.0, 0, flags, _ptr(a_rows), a_phys, _ptr(c_rows), _stream())
+    if prof is not None:
+        ev[1].record()
+    _lib.check(rc, f"gemm_nt_grouped G={G} M={M} N={N} K={Ka}")
+    return outs
+
+
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, save_stats: bool = True,
                   out: Optional[torch.Tensor] = None):
     _chk2d(x, "x")

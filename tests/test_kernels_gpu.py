@@ -306,3 +306,24 @@ def test_lfq_encode(K, E):
         close(xpre, x.float(), what="xpre")
     else:
         assert torch.equal(quant.float().cpu(), sign)
+
+
+@pytest.mark.parametrize("M,N,K_,G,b_t", [(300, 264, 128, 3, False), (4624, 4096, 1024, 3, False), (4624, 1024, 4096, 3, True),
+                                          (4624, 2816, 1408, 2, False), (130, 72, 64, 4, True)])
+def test_gemm_grouped(K, M, N, K_, G, b_t):
+    """Several same-shape GEMMs in one launch (blockIdx.z = group), incl. column-slice operands, the row-split dispatch
+    and a scatter map."""
+    abig = rnd(M, G * K_, seed=31, scale=0.5)
+    a_list = [abig[:, g * K_:(g + 1) * K_] for g in range(G)]              # column slices of one buffer (shared row stride)
+    b_list = [rnd(*((K_, N) if b_t else (N, K_)), seed=40 + g, scale=0.2) for g in range(G)]
+    phys = M + 77
+    gen = torch.Generator().manual_seed(9)
+    rows = torch.randperm(phys, generator=gen)[:M].to(torch.int32).cuda()
+    cbig = torch.zeros(phys, G * N, dtype=BF, device="cuda")
+    outs = [cbig[:, g * N:(g + 1) * N] for g in range(G)]
+    K.gemm_nt_grouped(a_list, b_list, outs, b_t=b_t, c_rows=rows)
+    for g in range(G):
+        ref = a_list[g].float() @ (b_list[g].float() if b_t else b_list[g].float().t())
+        close(outs[g][rows.long()], ref, what=f"grouped gemm group {g}")
+    untouched = torch.ones(phys, dtype=torch.bool, device="cuda"); untouched[rows.long()] = False
+    assert float(cbig[untouched].abs().max()) == 0.0
