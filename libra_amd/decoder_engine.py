@@ -77,9 +77,11 @@ def pack(sd: Dict[str, torch.Tensor], d: DecDims):
             t[:, :d.rank] = sd[a + name + ".weight_B"].detach()
             return t
         out.append(dict(
-            wqkv=cat([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]),
-            aqkv=cat([a + "vision_q_proj.weight_A", a + "vision_k_proj.weight_A", a + "vision_v_proj.weight_A"]),
-            ab_l=bridge_a("language"), ab_v=bridge_a("vision"),
+            # the rank-8 bridge A's ride along as 64 extra output rows of the q/k/v projection of their modality: one GEMM
+            # produces [q | k | v | t_k t_v 0...] (and one dgrad / wgrad GEMM handles both in the backward)
+            wqkv_ab=torch.cat([cat([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]), bridge_a("language")], 0),
+            aqkv_ab=torch.cat([cat([a + "vision_q_proj.weight_A", a + "vision_k_proj.weight_A", a + "vision_v_proj.weight_A"]),
+                               bridge_a("vision")], 0),
             bk_l=bridge_b("vision_k_bridge_on_language"), bk_v=bridge_b("vision_k_bridge_on_vision"),
             bv_l=bridge_b("vision_v_bridge_on_language"), bv_v=bridge_b("vision_v_bridge_on_vision"),
             wgu=cat([m + "gate_proj.weight", m + "up_proj.weight"]),
@@ -150,19 +152,19 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     # ---- attention block
     h, rstd1 = K.rmsnorm_routed(x, sd[pre + "input_layernorm.weight"], sd[pre + "vision_input_layernorm.weight"], flag, d.eps,
                                 save_rstd=True)
-    qkv = torch.empty((N, 3 * H), dtype=BF16, device=dev)
-    tb = torch.empty((N, 64), dtype=BF16, device=dev)
+    qkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)       # [q | k | v | bridge low-rank activations t_k t_v 0..]
+    qkv, tb = qkvt[:, :3 * H], qkvt[:, 3 * H:]
     t = None
     if n_l:
-        K.gemm_nt(h, pk["wqkv"], out=qkv, a_rows=lang_idx, c_rows=lang_idx)
-        K.gemm_nt(h, pk["ab_l"], out=tb, a_rows=lang_idx, c_rows=lang_idx)
+        K.gemm_nt(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)
     if n_v:
-        t = K.gemm_nt(h, pk["aqkv"], a_rows=vis_idx, out=_rows(n_v, 3 * r, dev, save))                  # [n_v, 3r]
+        t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save))      # [n_v, 3r + 64]
+        t = t_ext[:, :3 * r]
+        tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])          # 64 columns of the vision rows: plumbing copy
         # the three rank-r expansions share one launch (each alone is 1.2 waves of 256^2 tiles)
         K.gemm_nt_grouped([t[:, j * r:(j + 1) * r] for j in range(3)],
                           [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
                           [qkv[:, j * H:(j + 1) * H] for j in range(3)], c_rows=vis_idx)
-        K.gemm_nt(h, pk["ab_v"], out=tb, a_rows=vis_idx, c_rows=vis_idx)
     kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
     o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
                                (H // d.heads) ** -0.5, need_lse=save)
@@ -497,12 +499,13 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
     dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
                                                sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5)
-    dqkv = torch.empty((N, 3 * H), dtype=BF16, device=dev)
+    dqkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)     # [dq | dk | dv | dt_k dt_v 0..], mirrors the forward's qkvt
+    dqkv, dtb = dqkvt[:, :3 * H], dqkvt[:, 3 * H:]
+    dtb.zero_()
     dkb = torch.empty((N, H), dtype=BF16, device=dev)
     K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb)
     dvb = dvc
     # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
-    dtb = torch.zeros((N, 64), dtype=BF16, device=dev)
     h = sv["h"]
     for idx, which, bk, bv in ((lang_idx, "language", pk["bk_l"], pk["bv_l"]), (vis_idx, "vision", pk["bk_v"], pk["bv_v"])):
         if idx.numel() == 0:
@@ -518,40 +521,45 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
                 g[nv] = _wg(_compact(dvb, idx), tbc[:, 8:16], post=lambda o: o[:, :d.rank].contiguous())
     dh = torch.empty((N, H), dtype=BF16, device=dev)
     if n_l:
-        K.gemm_nt(dqkv, pk["wqkv"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)
-        K.gemm_nt(dtb, pk["ab_l"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh, resid=dh)
-        hl = None
+        K.gemm_nt(dqkvt, pk["wqkv_ab"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)       # K = 3H + 64
+        nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
         if any_l([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]):
             hl = _compact(h, lang_idx)
-            dw = _wg(_compact(dqkv, lang_idx), hl)
+            dw, gk, gv = _wg(_compact(dqkvt, lang_idx), hl,                              # [3H + 64, H]
+                             post=lambda o: (o, o[3 * H:3 * H + d.rank].contiguous(), o[3 * H + 8:3 * H + 8 + d.rank].contiguous()))
             for j, nm in enumerate(("q", "k", "v")):
                 g[a + f"{nm}_proj.weight"] = dw[j * H:(j + 1) * H]
-        nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
-        if w(nk) or w(nv):
-            hl = _compact(h, lang_idx) if hl is None else hl
+            if w(nk) or w(nv):
+                g[nk], g[nv] = gk, gv
+        elif w(nk) or w(nv):                                   # frozen language projections (pretraining): bridge A's only
+            hl = _compact(h, lang_idx)
             g[nk], g[nv] = _wg(_compact(dtb, lang_idx), hl,                                  # [64, H]
                                post=lambda o: (o[0:d.rank].contiguous(), o[8:8 + d.rank].contiguous()))
     if n_v:
         t = sv["t"]
         dqkv_v = _compact(dqkv, vis_idx)                                                    # [n_v, 3H]
-        dt = K.alloc_rows(n_v, 3 * r, dev)[:n_v]
+        dt_buf = K.alloc_rows(n_v, 3 * r + 64, dev)                  # [dt_q | dt_k | dt_v | dt_bridge], mirrors the forward's t_ext
+        dt_ext = dt_buf[:n_v]
+        dt = dt_ext[:, :3 * r]
         K.gemm_nt_grouped([dqkv_v[:, j * H:(j + 1) * H] for j in range(3)],
                           [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
                           [dt[:, j * r:(j + 1) * r] for j in range(3)], b_t=True)
         for j, nm in enumerate(("q", "k", "v")):
             if w(a + f"vision_{nm}_proj.weight_B"):
                 g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r])
-        K.gemm_nt(dt, pk["aqkv"], b_t=True, out=dh, c_rows=vis_idx)
-        K.gemm_nt(dtb, pk["ab_v"], b_t=True, a_rows=vis_idx, c_rows=vis_idx, out=dh, resid=dh)
-        hv = _compact(h, vis_idx)
-        if any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"]):
-            da = _wg(dt, hv)
-            for j, nm in enumerate(("q", "k", "v")):
-                g[a + f"vision_{nm}_proj.weight_A"] = da[j * r:(j + 1) * r]
+        K.copy_rows(dtb, vis_idx, n_v, dt_buf, 3 * r)                # the vision rows' 64 bridge columns
+        K.gemm_nt(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx)                   # K = 3r + 64
         nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
-        if w(nk) or w(nv):
-            g[nk], g[nv] = _wg(_compact(dtb, vis_idx), hv,
-                               post=lambda o: (o[0:d.rank].contiguous(), o[8:8 + d.rank].contiguous()))
+        want_a = any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"])
+        if want_a or w(nk) or w(nv):
+            hv = _compact(h, vis_idx)
+            da, gk, gv = _wg(dt_ext, hv,                                                   # [3r + 64, H]
+                             post=lambda o: (o, o[3 * r:3 * r + d.rank].contiguous(), o[3 * r + 8:3 * r + 8 + d.rank].contiguous()))
+            if want_a:
+                for j, nm in enumerate(("q", "k", "v")):
+                    g[a + f"vision_{nm}_proj.weight_A"] = da[j * r:(j + 1) * r]
+            if w(nk) or w(nv):
+                g[nk], g[nv] = gk, gv
     ln_l, ln_v = pre + "input_layernorm.weight", pre + "vision_input_layernorm.weight"
     dx = K.rmsnorm_routed_bwd(dh, sv["x"], sd[ln_l], sd[ln_v], flag, sv["rstd1"], dres=dx_mid)
     if w(ln_l) or w(ln_v):
