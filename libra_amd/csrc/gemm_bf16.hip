@@ -46,9 +46,9 @@ struct GemmArgs {
     const bf16_t* Ag[3]; const bf16_t* Bg[3]; bf16_t* Cg[3];   // grouped launch: operands of groups 1..3 (blockIdx.z)
 };
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }   // (v_rcp_f32: 1 ulp, the result is rounded to bf16)
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
-    const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
