@@ -86,10 +86,13 @@ int libra_layernorm_fwd(const void* x, const void* gamma, const void* beta, void
                         float* rstd, int64_t rows, int64_t D, float eps, void* stream);
 /* dx [rows,D] bf16 (optionally dx += dres, the residual-branch gradient, bf16 [rows,D]);
  * dgamma/dbeta: fp32 [D], ADDED to (deterministic two-stage reduction through `workspace`, no atomics),
- * may both be NULL (then no workspace is needed).  D <= 4096.                                         */
+ * may both be NULL (then no workspace is needed).  dxsum (fp32 [D], may be NULL; needs dgamma/dbeta): ADDED the
+ * column sum of the dx this call writes = the bias gradient of the nn.Linear whose output gradient dx is
+ * (modeling_clip.py:404-414: dx of layer_norm2 feeds out_proj, dx of layer_norm1 feeds the previous layer's fc2),
+ * which saves a separate column-sum pass over dx.  D <= 4096.                                         */
 size_t libra_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
 int libra_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
-                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum,
                         void* workspace, size_t workspace_bytes, int64_t rows, int64_t D, void* stream);
 
 /* ---- patch embedding front end (CLIPVisionEmbeddings.forward, modeling_clip.py:193-228) -----------

@@ -30,7 +30,7 @@ SIGNATURES = {
     "libra_colsum_bf16": [_P, _I64, _I64, _I64, _P, _P, C.c_size_t, _P],
     "libra_layernorm_bwd_workspace_bytes": [_I64, _I64],
     "libra_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
-    "libra_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
+    "libra_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
     "libra_patch_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_patch_col2im": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_vit_embed_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],

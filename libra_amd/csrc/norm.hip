@@ -74,33 +74,51 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_fwd_kernel(
     }
 }
 
-// dx = rstd * (g*dy - mean_D(g*dy) - xhat * mean_D(g*dy*xhat)) [+ dres];  dgamma += dy*xhat; dbeta += dy.
-// Each block walks a strip of rows so the parameter-gradient partials stay in registers; one atomic
-// per (block, column) at the end.
-template <int NC>
+// dx = rstd * (g*dy - mean_D(g*dy) - xhat * mean_D(g*dy*xhat)) [+ dres];  dgamma += dy*xhat; dbeta += dy; optionally
+// dxsum += dx (the column sum of the OUTPUT = the bias gradient of the Linear whose dY this dx is: it saves the separate
+// column-sum pass over dx).  Each block walks a strip of rows so the parameter-gradient partials stay in registers; the
+// next row's operands are fetched while the current row is reduced (one row at a time was latency bound: 2.9 TB/s).
+template <int NC, bool DXSUM>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
     const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const bf16_t* __restrict__ dres,
-    bf16_t* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D,
-    int rows_per_block) {
+    bf16_t* __restrict__ dx, float* __restrict__ part, long rows, int D, int rows_per_block) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunks = D >> 3;
+    constexpr int NP = DXSUM ? 3 : 2;
     float g[NC][8];
     load_row<NC>(gamma, nchunks, lane, g);
-    float ag[NC][8], ab[NC][8];
+    float ag[NC][8], ab[NC][8], ad[DXSUM ? NC : 1][8];
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; if (DXSUM) ad[i][e] = 0.f; }
 
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
-    for (long row = r0 + wave; row < r1; row += ROWS_PER_BLOCK) {
+    struct RowIn { u32x4 y[NC], x[NC], r[NC]; float mean, rstd; };
+    auto fetch = [&](long row, RowIn& in) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < nchunks;
+            in.y[i] = ok ? *(const u32x4*)(dy + row * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
+            in.x[i] = ok ? *(const u32x4*)(x + row * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
+            in.r[i] = (ok && dres) ? *(const u32x4*)(dres + row * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+        in.mean = mean_i[row]; in.rstd = rstd_i[row];
+    };
+    RowIn cur, nxt;
+    long row = r0 + wave;
+    if (row < r1) fetch(row, cur);
+    for (; row < r1; row += ROWS_PER_BLOCK) {
+        const bool more = row + ROWS_PER_BLOCK < r1;
+        if (more) fetch(row + ROWS_PER_BLOCK, nxt);
         float vy[NC][8], vx[NC][8];
-        load_row<NC>(dy + row * D, nchunks, lane, vy);
-        load_row<NC>(x + row * D, nchunks, lane, vx);
-        const float mean = mean_i[row], rstd = rstd_i[row];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { unpack8(cur.y[i], vy[i]); unpack8(cur.x[i], vx[i]); }
+        const float mean = cur.mean, rstd = cur.rstd;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i)
@@ -123,42 +141,53 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_bwd_kernel(
                 for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] * vy[i][e] - s1 - vx[i][e] * s2);
                 if (dres) {
                     float r[8];
-                    unpack8(*(const u32x4*)(dres + row * D + c * 8), r);
+                    unpack8(cur.r[i], r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += r[e];
                 }
-                *(u32x4*)(dx + row * D + c * 8) = pack8(o);
+                const u32x4 ob = pack8(o);
+                *(u32x4*)(dx + row * D + c * 8) = ob;
+                if (DXSUM) {                                   // sum of the values as stored (bf16), like a column sum of dx
+                    float q[8];
+                    unpack8(ob, q);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ad[i][e] += q[e];
+                }
             }
         }
+        if (more) cur = nxt;
     }
-    if (dgamma) {
-        // per-wave partial rows [part][2][D] (deterministic second stage: ln_param_reduce_kernel) — no atomics
-        float* pg = dgamma + ((long)(blockIdx.x * ROWS_PER_BLOCK + wave) * 2) * D;
-        float* pb = pg + D;
+    if (part) {
+        // per-wave partial rows [part][NP][D] (deterministic second stage: ln_param_reduce_kernel) — no atomics
+        float* pg = part + ((long)(blockIdx.x * ROWS_PER_BLOCK + wave) * NP) * D;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunks) {
                 *(f32x4*)(pg + c * 8) = f32x4{ag[i][0], ag[i][1], ag[i][2], ag[i][3]};
                 *(f32x4*)(pg + c * 8 + 4) = f32x4{ag[i][4], ag[i][5], ag[i][6], ag[i][7]};
-                *(f32x4*)(pb + c * 8) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
-                *(f32x4*)(pb + c * 8 + 4) = f32x4{ab[i][4], ab[i][5], ab[i][6], ab[i][7]};
+                *(f32x4*)(pg + D + c * 8) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
+                *(f32x4*)(pg + D + c * 8 + 4) = f32x4{ab[i][4], ab[i][5], ab[i][6], ab[i][7]};
+                if (DXSUM) {
+                    *(f32x4*)(pg + 2 * D + c * 8) = f32x4{ad[i][0], ad[i][1], ad[i][2], ad[i][3]};
+                    *(f32x4*)(pg + 2 * D + c * 8 + 4) = f32x4{ad[i][4], ad[i][5], ad[i][6], ad[i][7]};
+                }
             }
         }
     }
 }
 
-// out_gamma[d] += sum_p part[p][0][d];  out_beta[d] += sum_p part[p][1][d].  32 columns x 32 row groups per block.
-__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int D,
-                                                               float* __restrict__ out_gamma,
-                                                               float* __restrict__ out_beta) {
+// out_k[d] += sum_p part[p][k][d] for the np (2 or 3) accumulators of the backward.  32 columns x 32 row groups per block.
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int np, int D,
+                                                               float* __restrict__ out_gamma, float* __restrict__ out_beta,
+                                                               float* __restrict__ out_dxsum) {
     __shared__ float red[32][33];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int which = blockIdx.y;
     const int col = blockIdx.x * 32 + c;
     float s = 0.f;
     if (col < D) {
-        for (int p = rg; p < nparts; p += 32) s += part[((long)p * 2 + which) * D + col];
+        for (int p = rg; p < nparts; p += 32) s += part[((long)p * np + which) * D + col];
     }
     red[rg][c] = s;
     __syncthreads();
@@ -166,7 +195,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 32; ++i) t += red[i][c];
-        float* o = which ? out_beta : out_gamma;
+        float* o = which == 0 ? out_gamma : which == 1 ? out_beta : out_dxsum;
         o[col] += t;
     }
 }
@@ -256,17 +285,17 @@ extern "C" size_t libra_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) {
     if (rows <= 0 || D <= 0) return 0;
     const long rpb = ln_bwd_rows_per_block(rows);
     const long grid = (rows + rpb - 1) / rpb;
-    return (size_t)grid * ROWS_PER_BLOCK * 2 * D * sizeof(float);
+    return (size_t)grid * ROWS_PER_BLOCK * 3 * D * sizeof(float);                // room for the optional dx column sum
 }
 
 extern "C" int libra_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
-                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum,
                                    void* workspace, size_t workspace_bytes, int64_t rows, int64_t D, void* stream) {
     if (rows <= 0) return LIBRA_OK;
     if (D <= 0 || (D % 8) || D > 4096) return LIBRA_ERR_SHAPE;     // the whole row + partials stay in registers
     if (!dy || !x || !gamma || !mean || !rstd || !dx) return LIBRA_ERR_ALIGN;
     if (!al16(dy) || !al16(x) || !al16(gamma) || !al16(dx) || (dres && !al16(dres))) return LIBRA_ERR_ALIGN;
-    if ((dgamma == nullptr) != (dbeta == nullptr)) return LIBRA_ERR_ALIGN;
+    if ((dgamma == nullptr) != (dbeta == nullptr) || (dxsum && !dgamma)) return LIBRA_ERR_ALIGN;
     const long rpb = ln_bwd_rows_per_block(rows);
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     float* part = nullptr;
@@ -276,14 +305,21 @@ extern "C" int libra_layernorm_bwd(const void* dy, const void* x, const void* ga
         part = (float*)workspace;
     }
     const int rc = dispatch_nc((int)D, [&](auto nc) {
-        hipLaunchKernelGGL((layernorm_bwd_kernel<decltype(nc)::value>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0,
-                           (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, mean,
-                           rstd, (const bf16_t*)dres, (bf16_t*)dx, part, (float*)nullptr, (long)rows, (int)D, (int)rpb);
+        constexpr int NCV = decltype(nc)::value;
+        if (dxsum)
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NCV, true>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, (hipStream_t)stream,
+                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres,
+                               (bf16_t*)dx, part, (long)rows, (int)D, (int)rpb);
+        else
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NCV, false>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, (hipStream_t)stream,
+                               (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres,
+                               (bf16_t*)dx, part, (long)rows, (int)D, (int)rpb);
         return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
     });
     if (rc != LIBRA_OK || !dgamma) return rc;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((D + 31) / 32), 2), dim3(1024), 0, (hipStream_t)stream,
-                       part, (int)(grid * ROWS_PER_BLOCK), (int)D, dgamma, dbeta);
+    const int np = dxsum ? 3 : 2;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)np), dim3(1024), 0, (hipStream_t)stream,
+                       part, (int)(grid * ROWS_PER_BLOCK), np, (int)D, dgamma, dbeta, dxsum);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
 

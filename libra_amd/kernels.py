@@ -176,8 +176,8 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=None, out=None):
-    """dx = LN'(dy) [+ dres]; dgamma/dbeta are fp32 [D] accumulators (added to), or None."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=None, dxsum=None, out=None):
+    """dx = LN'(dy) [+ dres]; dgamma/dbeta (and dxsum += column sum of dx) are fp32 [D] accumulators (added to), or None."""
     _chk2d(dy, "dy"); _chk2d(x, "x")
     rows, D = x.shape
     if dy.shape != x.shape or not (dy.is_contiguous() and x.is_contiguous()):
@@ -189,7 +189,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=Non
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     rc = _lib.lib().libra_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta),
-                                        _ptr(ws), ws_bytes, rows, D, _stream())
+                                        _ptr(dxsum), _ptr(ws), ws_bytes, rows, D, _stream())
     _lib.check(rc, f"layernorm_bwd rows={rows} D={D}")
     return dx
 

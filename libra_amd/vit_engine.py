@@ -207,28 +207,33 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
         return arena[o:o + n]
     side = _SideStream(dev)
 
-    def param_grads(wname, bname, dy, x, nb):
-        bslice = f32(nb, bname)
+    def param_grads(wname, bname, dy, x, nb, bias_slice=None):
+        """weight gradient (+ the bias gradient = column sum of dy, unless the kernel that produced dy already summed it
+        into `bias_slice`)."""
+        bslice = f32(nb, bname) if bias_slice is None else None
 
         def work():
             g = _wgrad(dy, x, m_pad)
-            K.colsum(dy, bslice)
+            if bslice is not None:
+                K.colsum(dy, bslice)
             return g
         grads[wname] = side.run(work, dy, x)
 
+    dx_sum = None          # fp32 column sum of dx when the LayerNorm backward that produced dx already took it
     for i in range(min(top, L) - 1, -1, -1):
         pre = f"{P}encoder.layers.{i}."
         s = saved["layers"][i]
         # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
-        param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dx, s["act"], D)
+        param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dx, s["act"], D, bias_slice=dx_sum)
         dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dev_rows(I))
         param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dh, s["xn2"], I)
         dxn2 = K.gemm_nt(dh, params[pre + "mlp.fc1.weight"], b_t=True)                       # [M, D]
         dg2, dbt2 = f32(D, pre + "layer_norm2.weight"), f32(D, pre + "layer_norm2.bias")
+        bo = f32(D, pre + "self_attn.out_proj.bias")              # = column sum of dx_mid, taken by the LN backward itself
         dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
-                                 dgamma=dg2, dbeta=dbt2, out=dev_rows(D))
+                                 dgamma=dg2, dbeta=dbt2, dxsum=bo, out=dev_rows(D))
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
-        param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D)
+        param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D, bias_slice=bo)
         do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
         dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dev_rows(3 * D))
         param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D)                   # [3D, D]
@@ -239,8 +244,12 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
             small.append((pre + f"self_attn.{n}_proj.bias", o0 + j * D, D))
         dxn1 = K.gemm_nt(dqkv, packed["layers"][i]["wqkv"], b_t=True)
         dg1, dbt1 = f32(D, pre + "layer_norm1.weight"), f32(D, pre + "layer_norm1.bias")
+        # this dx is the dY of layer i-1's fc2: its column sum is that bias gradient, unless a hidden-state cotangent is
+        # still to be added to dx below (then the separate column-sum pass runs on the final dx)
+        fuse = i > 0 and dhs[i] is None
+        dx_sum = f32(D, f"{P}encoder.layers.{i - 1}.mlp.fc2.bias") if fuse else None
         dx = K.layernorm_bwd(dxn1, s["x"], params[pre + "layer_norm1.weight"], s["m1"], s["r1"], dres=dx_mid,
-                             dgamma=dg1, dbeta=dbt1, out=dev_rows(D))
+                             dgamma=dg1, dbeta=dbt1, dxsum=dx_sum, out=dev_rows(D))
         if dhs[i] is not None:
             K.add_(dx, dhs[i].reshape(M, D).to(BF16).contiguous())
     # ---- embeddings: hs0 = LN(emb); emb = [cls ; patches] + pos

@@ -149,6 +149,13 @@ def test_layernorm_fwd_bwd(K, rows, D):
     close(dx, xf.grad + dres.float(), what="ln dx")
     close(K.f32_to_bf16(dg), gf.grad, rel=2e-3, what="ln dgamma")
     close(K.f32_to_bf16(db), bf.grad, rel=2e-3, what="ln dbeta")
+    # fused column sum of the output (= the bias gradient of the Linear that dx is the dY of): exactly the sum of the
+    # stored bf16 values, and the other outputs are unchanged by asking for it
+    dg2 = torch.zeros(D, device="cuda"); db2 = torch.zeros(D, device="cuda"); ds = torch.full((D,), 3.0, device="cuda")
+    dx2 = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dg2, dbeta=db2, dxsum=ds)
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    ref_sum = dx.float().sum(0) + 3.0
+    assert float((ds - ref_sum).abs().max()) <= 1e-4 * max(1.0, float(ref_sum.abs().max()))
 
 
 def test_transpose(K):
