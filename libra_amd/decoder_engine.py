@@ -11,8 +11,7 @@ accumulation is fp32 in the MFMA.  Reference file:line citations: include/libra_
 from __future__ import annotations
 
 from dataclasses import dataclass
-import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 
@@ -286,51 +285,12 @@ def _compact(t2d: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return buf[:n]
 
 
-class _WgradStream:
-    """Weight gradients are off the backward's critical path (nothing downstream consumes them), so they are enqueued on
-    a second HIP stream: their workgroups fill the CUs that the partial last waves of the dgrad GEMMs and the row kernels
-    leave idle.  Ordering is by stream waits; operands are pinned against the caching allocator with record_stream (they
-    are fresh compact buffers or saved activations - nothing the main stream later overwrites in place)."""
-
-    def __init__(self, device):
-        self.main = torch.cuda.current_stream(device)
-        self.side = torch.cuda.Stream(device=device)
-        self.enabled = os.environ.get("LIBRA_NO_SIDE_STREAM", "0") != "1"     # (diagnostics: serial launch order)
-        self.outs: List[torch.Tensor] = []
-
-    def run(self, fn, *operands):
-        if not self.enabled:
-            return fn()
-        self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
-            out = fn()
-        for t in operands:
-            t.record_stream(self.side)
-        self.outs.extend(out if isinstance(out, tuple) else (out,))
-        return out
-
-    def join(self):
-        if self.enabled:
-            self.main.wait_stream(self.side)
-            for t in self.outs:
-                t.record_stream(self.main)
-        self.outs = []
-
-
-_wgrad_stream: Optional[_WgradStream] = None
-
-
 def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None):
     """dW[out, in] = sum_tokens dy[t, out] x[t, in]; both operands token-major, padded (LIBRA_GEMM_A_T | _B_T).
-    `post` (slicing that launches copies) runs on the same stream as the GEMM."""
-    a, b = _full(dy_c), _full(x_c)
-
-    def work():
-        o = K.gemm_nt(a, b, a_t=True, b_t=True)
-        return post(o) if post is not None else o
-    if _wgrad_stream is None:
-        return work()
-    return _wgrad_stream.run(work, a, b)
+    (Measured: running these on a second stream, as the ViT engine does, is 1.5-3 % SLOWER here - the decoder's
+    memory-bound row kernels and the big dgrad GEMMs leave no idle CUs to fill - so everything stays on one stream.)"""
+    o = K.gemm_nt(_full(dy_c), _full(x_c), a_t=True, b_t=True)
+    return post(o) if post is not None else o
 
 
 def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
@@ -342,8 +302,6 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     dev = flag.device
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     cos, sin, lens = sv["cos"], sv["sin"], sv["lens"]
-    global _wgrad_stream
-    _wgrad_stream = _WgradStream(dev)
     g: Dict[str, torch.Tensor] = {}
     f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
     w = lambda name: name in want
@@ -423,8 +381,6 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         tok = sv["input_ids"][0].reshape(-1).index_select(0, lang_idx.long())
         acc.index_add_(0, tok, dx.index_select(0, lang_idx.long()).float())
         g["model.embed_tokens.weight"] = acc.to(BF16)
-    _wgrad_stream.join()
-    _wgrad_stream = None
     return g
 
 

@@ -15,8 +15,6 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
-import os
-
 import torch
 
 from . import kernels as K
@@ -145,34 +143,6 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
     return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True)
 
 
-class _SideStream:
-    """Weight / bias gradients are off the critical path (nothing in the backward consumes them), so they are
-    enqueued on a second HIP stream: their workgroups fill the CUs that the tail wave of the dgrad GEMMs, the
-    attention kernels and the row kernels leave idle.  Ordering is by events; operands are pinned against the
-    caching allocator with record_stream."""
-
-    def __init__(self, device):
-        self.main = torch.cuda.current_stream(device)
-        self.side = torch.cuda.Stream(device=device)
-        self.enabled = os.environ.get("LIBRA_NO_SIDE_STREAM", "0") != "1"     # (diagnostics: serial launch order)
-
-    def run(self, fn, *operands):
-        if not self.enabled:
-            return fn()
-        self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
-            out = fn()
-        for t in operands:
-            t.record_stream(self.side)
-        return out
-
-    def join(self, *outs):
-        if self.enabled:
-            self.main.wait_stream(self.side)
-            for t in outs:
-                t.record_stream(self.main)
-
-
 def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
              *, need_pixel_grad: bool = True):
     """Given d(loss)/d(hidden_states[i]) (None = zero) return (d_pixel or None, {param name: bf16 grad}).
@@ -205,19 +175,17 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
         if name is not None:
             small.append((name, o, n))
         return arena[o:o + n]
-    side = _SideStream(dev)
 
     def param_grads(wname, bname, dy, x, nb, bias_slice=None):
         """weight gradient (+ the bias gradient = column sum of dy, unless the kernel that produced dy already summed it
         into `bias_slice`)."""
         bslice = f32(nb, bname) if bias_slice is None else None
 
-        def work():
-            g = _wgrad(dy, x, m_pad)
-            if bslice is not None:
-                K.colsum(dy, bslice)
-            return g
-        grads[wname] = side.run(work, dy, x)
+        # (Weight gradients used to run on a second stream; once the kernels were tuned that overlap measured as no gain -
+        # 56.6 vs 56.5 ms/step - so the whole backward is one stream and per-launch timings mean what they say.)
+        grads[wname] = _wgrad(dy, x, m_pad)
+        if bslice is not None:
+            K.colsum(dy, bslice)
 
     dx_sum = None          # fp32 column sum of dx when the LayerNorm backward that produced dx already took it
     for i in range(min(top, L) - 1, -1, -1):
@@ -256,7 +224,6 @@ def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Ten
     dg0, db0 = f32(D, P + "pre_layrnorm.weight"), f32(D, P + "pre_layrnorm.bias")
     demb = K.layernorm_bwd(dx, saved["emb"], params[P + "pre_layrnorm.weight"], saved["mean0"], saved["rstd0"],
                            dgamma=dg0, dbeta=db0)
-    side.join(*[g for g in grads.values() if g.ndim == 2])
     small_bf16 = K.f32_to_bf16(arena)
     for name, o, n in small:
         grads[name] = small_bf16[o:o + n]

@@ -1,9 +1,8 @@
-"""Per-shape GEMM time inside one step of a bench workload (serial launch order, HIP events per launch).
+"""Per-shape GEMM time inside one step of a bench workload (HIP events per launch).
 usage: python tools/gemm_shapes.py [vit|libra]"""
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["LIBRA_NO_SIDE_STREAM"] = "1"
 import torch
 import bench
 from libra_amd import kernels as K

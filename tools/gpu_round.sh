@@ -11,6 +11,5 @@ nproc > gpurun_out/host.txt; lscpu | head -20 >> gpurun_out/host.txt
 timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -3 gpurun_out/bench.log
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1 ); echo "prof rc=$?"
 find gpurun_out/prof -name "*stats*" | head
-# serial-order profile (matches the roofline leg of bench.py) and HBM traffic of the GEMM launches
-( cd /tmp && LIBRA_NO_SIDE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_vit_serial -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_vit_serial.log 2>&1 ); echo "serial prof rc=$?"
+# HBM traffic of the GEMM launches (PMC)
 ./tools/hbm_traffic.sh vit > gpurun_out/hbm_vit.log 2>&1; tail -2 gpurun_out/hbm_vit.log | cut -c1-400
