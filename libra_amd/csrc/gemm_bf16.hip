@@ -285,7 +285,9 @@ static int64_t plan_rows256(int64_t M, int64_t N, int64_t K, int64_t groups = 1)
 // ---- split-K (wgrad-shaped problems: small M,N, very long K): the 256^2 kernel over K slices + a deterministic
 // fp32 slab reduction.  plan() returns the number of slices (1 = not worth it).
 extern "C" int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
-    if (M < 256 || N < 256 || K < 4096 || (M % 8) || (N % 8)) return 1;
+    // (skinny outputs included: the rank-8 bridge weight gradients are [4096, 8] and [64, 4096] with K = 4.6k-11.8k tokens -
+    //  as ordinary launches they occupy 16-32 workgroups; sliced over K they fill the chip and run at HBM speed)
+    if (M < 8 || N < 8 || K < 4096 || (M % 8) || (N % 8)) return 1;
     const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles > 128) return 1;
     long s = 256 / tiles;

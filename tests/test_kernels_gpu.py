@@ -334,3 +334,13 @@ def test_gemm_grouped(K, M, N, K_, G, b_t):
         close(outs[g][rows.long()], ref, what=f"grouped gemm group {g}")
     untouched = torch.ones(phys, dtype=torch.bool, device="cuda"); untouched[rows.long()] = False
     assert float(cbig[untouched].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K_", [(4096, 8, 11776), (64, 4096, 4672), (8, 8, 4096), (520, 16, 8192)])
+def test_gemm_splitk_skinny(K, M, N, K_):
+    """Skinny weight-gradient shapes (rank-8 bridges) go through the K-sliced 256^2 kernel + deterministic slab reduce."""
+    a, b = rnd(K_, M, seed=51, scale=0.3), rnd(K_, N, seed=52, scale=0.3)           # both reduction-major, as wgrad operands are
+    out = K.gemm_nt(a, b, a_t=True, b_t=True)
+    close(out, a.float().t() @ b.float(), rel=2e-3, what=f"skinny split-K {M}x{N}x{K_}")
+    out2 = K.gemm_nt(a, b, a_t=True, b_t=True)
+    assert torch.equal(out, out2)
