@@ -109,15 +109,6 @@ int libra_vit_embed_ln(const void* patches, const void* cls, const void* pos, co
                        const void* beta, void* emb, void* hs0, float* mean, float* rstd, int64_t B,
                        int64_t T, int64_t D, float eps, void* stream);
 
-/* ---- bf16 2-D transpose with zero padding: out[c, r] = in[r, c], r < rows; out[c, rows..rows_pad) = 0
- * in: [rows, cols] ld_in; out: [cols, rows_pad] ld_out; `batch` independent problems at element
- * strides in_bstride / out_bstride (% 8 == 0).  Used to build the K-contiguous operands of the dgrad /
- * wgrad GEMMs and the V^T operand of attention.  Optionally accumulates the column sums of `in`
- * (== bias gradient) into colsum_f32[cols] (fp32, caller-zeroed, atomics) when non-NULL.            */
-int libra_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows,
-                         int64_t cols, int64_t rows_pad, float* colsum_f32, int64_t batch,
-                         int64_t in_bstride, int64_t out_bstride, void* stream);
-
 /* ---- column sums (bias gradient db[n] = sum_m dY[m,n]); out fp32 [cols] is ADDED to; deterministic two-stage */
 size_t libra_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int libra_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, void* workspace,

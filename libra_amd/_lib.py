@@ -34,7 +34,6 @@ SIGNATURES = {
     "libra_patch_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_patch_col2im": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_vit_embed_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
-    "libra_transpose_bf16": [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P],
     "libra_vit_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
     "libra_vit_attn_delta": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_vit_attn_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],

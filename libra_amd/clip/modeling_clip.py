@@ -104,8 +104,7 @@ class _VitFunction(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("backward through CLIPVisionModel requested but no activations were saved")
         dhs = [None if g is None else g for g in dhs]
-        pb = model._packed_backward(ctx.pd, ctx.packed)
-        dpixel, grads = E.backward(ctx.pd, ctx.packed, pb, ctx.saved, dhs, model._dims,
+        dpixel, grads = E.backward(ctx.pd, ctx.packed, ctx.saved, dhs, model._dims,
                                    need_pixel_grad=ctx.pixel_needs_grad)
         out = []
         for n, p in ctx.pd.items():
@@ -169,13 +168,8 @@ class CLIPVisionModel(PreTrainedModel):
     def _packed_forward(self, pd):
         key = E._versions(pd)
         if self._pack.key != key:
-            self._pack.key, self._pack.fwd, self._pack.bwd = key, E.pack_forward(pd, self._dims), None
+            self._pack.key, self._pack.fwd = key, E.pack_forward(pd, self._dims)
         return self._pack.fwd
-
-    def _packed_backward(self, pd, fwd):
-        if self._pack.bwd is None:
-            self._pack.bwd = E.pack_backward(pd, self._dims, fwd)
-        return self._pack.bwd
 
     def forward(self, pixel_values: Optional[torch.FloatTensor] = None, output_attentions: Optional[bool] = None,
                 output_hidden_states: Optional[bool] = None, return_dict: Optional[bool] = None,

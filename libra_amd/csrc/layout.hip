@@ -1,65 +1,9 @@
-// Layout / data-movement kernels (all HBM-bound): bf16 transpose (+column sums), patch im2col / col2im,
+// Layout / data-movement kernels (all HBM-bound): patch im2col / col2im,
 // vision-tower feature select (+backward), fp32->bf16, bf16 add.
 #include "hip_common.hpp"
 #include "../../include/libra_hip.h"
 
 namespace libra {
-
-// ---- transpose: out[c, r] = in[r, c]; 64x64 tiles through LDS; reads and writes are both 16-byte
-// row-contiguous accesses.  Optionally accumulates the column sums of `in` (bias gradients).
-constexpr int TT = 64;
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ld_in,
-                                                             bf16_t* __restrict__ out, long ld_out, int rows,
-                                                             int cols, int rows_pad, float* __restrict__ colsum,
-                                                             long in_bstride, long out_bstride) {
-    __shared__ bf16_t tile[TT][TT + 2];          // +2 elements: odd dword stride -> conflict-free column reads
-    in += (long)blockIdx.z * in_bstride;
-    out += (long)blockIdx.z * out_bstride;
-    const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
-    const int tid = threadIdx.x;
-    // load: thread -> (row = tid/8 + 32*p, 8 columns at (tid%8)*8)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = (tid >> 3) + 32 * p;
-        const int cc = (tid & 7) * 8;
-        const int gr = r0 + r, gc = c0 + cc;
-        bf16_t v[8];
-        if (gr < rows && gc + 8 <= cols) {
-            *(u32x4*)v = *(const u32x4*)(in + (long)gr * ld_in + gc);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (gr < rows && gc + e < cols) ? in[(long)gr * ld_in + gc + e] : (bf16_t)0;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tile[r][cc + e] = v[e];
-    }
-    __syncthreads();
-    if (colsum) {
-        // thread t < 64 sums column t of the tile (rows beyond `rows` were zero-filled)
-        if (tid < TT && c0 + tid < cols) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < TT; ++r) s += bf2f(tile[r][tid]);
-            atomicAdd(colsum + c0 + tid, s);
-        }
-    }
-    // store: thread -> (out row = column c = tid/8 + 32*p, 8 consecutive r at (tid%8)*8)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int c = (tid >> 3) + 32 * p;
-        const int rr = (tid & 7) * 8;
-        const int gc = c0 + c, gr = r0 + rr;
-        if (gc >= cols || gr >= rows_pad) continue;
-        bf16_t v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tile[rr + e][c];
-        if (gr + 8 <= rows_pad) {
-            *(u32x4*)(out + (long)gc * ld_out + gr) = *(u32x4*)v;
-        } else {
-            for (int e = 0; e < 8 && gr + e < rows_pad; ++e) out[(long)gc * ld_out + gr + e] = v[e];
-        }
-    }
-}
 
 // ---- im2col for non-overlapping PxP patches. One thread per 8 output columns.
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const bf16_t* __restrict__ pix, bf16_t* __restrict__ cols,
@@ -189,20 +133,6 @@ static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK
 using namespace libra;
 
 extern "C" int libra_hip_abi_version(void) { return 2; }
-
-extern "C" int libra_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows,
-                                    int64_t cols, int64_t rows_pad, float* colsum, int64_t batch,
-                                    int64_t in_bstride, int64_t out_bstride, void* stream) {
-    if (cols <= 0 || rows_pad <= 0 || batch <= 0) return LIBRA_OK;
-    if (rows < 0 || rows_pad < rows || ld_in < cols || ld_out < rows_pad || batch > 65535) return LIBRA_ERR_SHAPE;
-    if ((ld_in % 8) || (ld_out % 8) || (in_bstride % 8) || (out_bstride % 8)) return LIBRA_ERR_ALIGN;
-    if (!in || !out || !al16(in) || !al16(out)) return LIBRA_ERR_ALIGN;
-    dim3 grid((unsigned)((cols + TT - 1) / TT), (unsigned)((rows_pad + TT - 1) / TT), (unsigned)batch);
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (long)ld_in,
-                       (bf16_t*)out, (long)ld_out, (int)rows, (int)cols, (int)rows_pad, colsum, (long)in_bstride,
-                       (long)out_bstride);
-    return launched();
-}
 
 extern "C" int libra_patch_im2col(const void* pixel, void* cols, int64_t B, int64_t C, int64_t H, int64_t W,
                                   int64_t P, int64_t Kpad, void* stream) {

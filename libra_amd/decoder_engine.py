@@ -1,4 +1,4 @@
-"""Forward schedule of Libra's routed ("bridge") decoder on the gfx950 kernels — SURVEY §8 rows a12-a21.
+"""Forward and backward schedule of Libra's routed ("bridge") decoder on the gfx950 kernels — SURVEY §8 rows a12-a21.
 
 Routing without permutation passes: activations stay in sequence order [B*S, H]; the two modality streams
 are index lists (``lang_idx``, ``vis_idx``) that the GEMM uses to gather its A rows and scatter its C rows

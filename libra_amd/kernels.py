@@ -194,21 +194,6 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=Non
     return dx
 
 
-def transpose(x: torch.Tensor, rows_pad: Optional[int] = None, *, colsum: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[c, r] = x[r, c]; columns [rows, rows_pad) of out are zero.  colsum (fp32 [cols]) += column sums of x."""
-    _chk2d(x, "x")
-    rows, cols = x.shape
-    rows_pad = rows if rows_pad is None else rows_pad
-    if out is None:
-        out = torch.empty((cols, rows_pad), dtype=BF16, device=x.device)
-    _chk2d(out, "out")
-    rc = _lib.lib().libra_transpose_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols,
-                                         rows_pad, _ptr(colsum), 1, 0, 0, _stream())
-    _lib.check(rc, f"transpose {rows}x{cols}")
-    return out
-
-
 def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out (fp32 [cols]) += column sums of x (bf16 [rows, cols])."""
     _chk2d(x, "x")

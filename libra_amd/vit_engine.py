@@ -1,9 +1,9 @@
 """Forward / backward schedule of the CLIP ViT encoder on the gfx950 kernels.
 
 This is the host-side "graph" of the hot path a1-a7 of SURVEY.md §8: which kernel runs on which
-buffer, what is saved for backward, and which K-contiguous operand copies the NT GEMM needs
-(transposed weights for dgrad, transposed activations/gradients for wgrad).  All math is in
-``libra_amd/csrc``; torch supplies memory and streams only.
+buffer and what is saved for backward.  No operand is ever copied into another layout: dgrad reads the weights and
+wgrad reads dY / X where they lie, as reduction-major GEMM operands (LDS transpose loads).  All math is in
+``libra_amd/csrc``; torch supplies memory and the stream only.
 
 Reference semantics being reproduced (file:line relative to /root/reference/libra/models/clip):
   modeling_clip.py:193-228 embeddings, :893 pre_layrnorm, :390-428 encoder layer (pre-LN residual),
@@ -46,20 +46,14 @@ class VitDims:
     def kpe(self):           # im2col width, padded to the GEMM's K granule
         return K.round_up(self.channels * self.patch * self.patch, 64)
 
-    @property
-    def t_pad(self):         # token padding of the transposed (token-contiguous) attention operands
-        return K.round_up(self.tokens, 64)
-
 
 class _Packed:
     """Device-side operand copies derived from the parameters (rebuilt when a parameter changes):
-    fused [q;k;v] weight/bias, the zero-padded patch-embedding matrix, and — for backward — the
-    transposed (K-contiguous for dgrad) weights."""
+    fused [q;k;v] weight/bias and the zero-padded patch-embedding matrix."""
 
     def __init__(self):
         self.key = None
         self.fwd = None
-        self.bwd = None
 
 
 def _versions(params: Dict[str, torch.Tensor]):
@@ -80,12 +74,6 @@ def pack_forward(params: Dict[str, torch.Tensor], dims: VitDims):
             "bqkv": torch.cat([params[pre + f"{n}_proj.bias"].detach() for n in "qkv"], 0).contiguous(),
         })
     return out
-
-
-def pack_backward(params, dims: VitDims, fwd):
-    """Nothing to build: dgrad reads the weights themselves as reduction-major B operands (LIBRA_GEMM_B_T) and
-    wgrad reads dY / X token-major (LIBRA_GEMM_A_T | _B_T) through the LDS transpose loads."""
-    return {}
 
 
 def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: VitDims, *, save: bool,
@@ -143,7 +131,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
     return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True)
 
 
-def backward(params, packed, packed_bwd, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
+def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
              *, need_pixel_grad: bool = True):
     """Given d(loss)/d(hidden_states[i]) (None = zero) return (d_pixel or None, {param name: bf16 grad}).
 

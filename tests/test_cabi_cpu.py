@@ -32,7 +32,7 @@ def lib_path():
 def test_header_declares_the_expected_surface():
     d = _declared()
     for name in ("libra_gemm_bf16_nt", "libra_layernorm_fwd", "libra_layernorm_bwd", "libra_vit_attn_fwd",
-                 "libra_vit_attn_bwd", "libra_lfq_encode", "libra_patch_im2col", "libra_transpose_bf16"):
+                 "libra_vit_attn_bwd", "libra_lfq_encode", "libra_patch_im2col", "libra_gemm_bf16_nt_grouped"):
         assert name in d
     assert len(d) >= 16
 

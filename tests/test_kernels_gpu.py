@@ -158,24 +158,6 @@ def test_layernorm_fwd_bwd(K, rows, D):
     assert float((ds - ref_sum).abs().max()) <= 1e-4 * max(1.0, float(ref_sum.abs().max()))
 
 
-def test_transpose(K):
-    x = rnd(577, 200, seed=9)
-    cs = torch.zeros(200, device="cuda")
-    t = K.transpose(x, 640, colsum=cs)
-    assert t.shape == (200, 640)
-    assert torch.equal(t[:, :577], x.t())
-    assert float(t[:, 577:].abs().max()) == 0.0
-    close(cs, x.float().sum(0), what="colsum")
-    # batched token transpose of a column slice
-    B, T, Tp, C = 3, 17, 64, 256
-    big = rnd(B * T, 3 * C, seed=10)
-    out = K.transpose_tokens(big[:, 2 * C:], B, T, Tp)
-    assert out.shape == (C, B * Tp)
-    for b in range(B):
-        assert torch.equal(out[:, b * Tp: b * Tp + T], big[b * T:(b + 1) * T, 2 * C:].t())
-        assert float(out[:, b * Tp + T:(b + 1) * Tp].abs().max()) == 0.0
-
-
 @pytest.mark.parametrize("rows,cols", [(577, 200), (18464, 1024), (100, 4096), (3, 8)])
 def test_colsum(K, rows, cols):
     x = rnd(rows, cols, seed=rows)
