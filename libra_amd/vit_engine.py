@@ -148,8 +148,12 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
     top = max((i for i, g in enumerate(dhs) if g is not None), default=-1)
     if top < 0:
         return None, grads
+    # Gradient buffers that later serve as reduction-major wgrad operands (zero pad rows) are allocated ONCE per backward and
+    # reused by every layer (one stream: a layer's kernels are enqueued after every reader of the previous contents).
     dev_rows = lambda c: K.alloc_rows(M, c, dev)[:M]
-    dx = dev_rows(D)
+    dx_ring = [dev_rows(D), dev_rows(D)]                       # dx of layer i is read while layer i-1 writes its own
+    dh_buf, dxmid_buf, dqkv_buf = dev_rows(I), dev_rows(D), dev_rows(3 * D)
+    dx = dx_ring[0]
     dx.copy_(dhs[top].reshape(M, D))
     # one zeroed fp32 arena for every small (bias / LayerNorm) gradient of this backward; converted to bf16 once
     n_small = (min(top, L)) * (9 * D + I) + 2 * D
@@ -181,17 +185,17 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
         s = saved["layers"][i]
         # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
         param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dx, s["act"], D, bias_slice=dx_sum)
-        dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dev_rows(I))
+        dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dh_buf)
         param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dh, s["xn2"], I)
         dxn2 = K.gemm_nt(dh, params[pre + "mlp.fc1.weight"], b_t=True)                       # [M, D]
         dg2, dbt2 = f32(D, pre + "layer_norm2.weight"), f32(D, pre + "layer_norm2.bias")
         bo = f32(D, pre + "self_attn.out_proj.bias")              # = column sum of dx_mid, taken by the LN backward itself
         dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
-                                 dgamma=dg2, dbeta=dbt2, dxsum=bo, out=dev_rows(D))
+                                 dgamma=dg2, dbeta=dbt2, dxsum=bo, out=dxmid_buf)
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
         param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D, bias_slice=bo)
         do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
-        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dev_rows(3 * D))
+        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dqkv_buf)
         param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D)                   # [3D, D]
         dwqkv = grads.pop(pre + "self_attn.qkv_packed")
         o0 = cursor[0] - 3 * D
@@ -205,7 +209,7 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
         fuse = i > 0 and dhs[i] is None
         dx_sum = f32(D, f"{P}encoder.layers.{i - 1}.mlp.fc2.bias") if fuse else None
         dx = K.layernorm_bwd(dxn1, s["x"], params[pre + "layer_norm1.weight"], s["m1"], s["r1"], dres=dx_mid,
-                             dgamma=dg1, dbeta=dbt1, dxsum=dx_sum, out=dev_rows(D))
+                             dgamma=dg1, dbeta=dbt1, dxsum=dx_sum, out=dx_ring[1] if dx is dx_ring[0] else dx_ring[0])
         if dhs[i] is not None:
             K.add_(dx, dhs[i].reshape(M, D).to(BF16).contiguous())
     # ---- embeddings: hs0 = LN(emb); emb = [cls ; patches] + pos
