@@ -157,16 +157,20 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     // hoisted to kernel entry they are ten long-lived registers that hipcc spills around the tile loop, and a scratch
     // reload inside the loop is a vmcnt(0) drain of the LDS-DMA queue.
     int lane_o = lane;
-    // S^T (32 keys x 32 queries) of one key half from the K image at `kimg`
-    auto qk_half = [&](const char* kimg, f32x16& s) {
+    // S^T (2 x 32 keys x 32 queries) of both key halves of the K image at `kimg`.  The two accumulators alternate: eight
+    // back-to-back MFMAs on ONE accumulator are a dependent chain that runs at half rate (round-1 cycle stamps: 1400 cycles
+    // for the 16 QK MFMAs of a tile).
+    auto qk_pair = [&](const char* kimg, f32x16& s0, f32x16& s1) {
         const int l31o = lane_o & 31, fko = lane_o >> 5;
         const int kswz = (l31o >> 1) & 7;
         const char* krow = kimg + l31o * 128;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int c = (2 * (ks & 3) + fko) ^ kswz;
-            const bf16x8 kf = *(const bf16x8*)(krow + (ks >> 2) * 4096 + (c << 4));
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            const bf16x8 k0 = *(const bf16x8*)(krow + (ks >> 2) * 4096 + (c << 4));
+            const bf16x8 k1 = *(const bf16x8*)(krow + 8192 + (ks >> 2) * 4096 + (c << 4));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
         }
     };
     // O^T += V^T P^T for one 16-key step: `vstep` = V image + 4096 * step
@@ -215,15 +219,13 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
         f32x16 sA, sB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; }
-        qk_half(img1, sA);
-        qk_half(img1 + 8192, sB);
+        qk_pair(img1, sA, sB);
         unsigned crA = 0, crB = 0;                                  // bit r: element r takes the cross variant (mixed tiles)
         if (mixed) {
             f32x16 tA, tB;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { tA[r] = 0.f; tB[r] = 0.f; }
-            qk_half(skc, tA);
-            qk_half(skc + 8192, tB);
+            qk_pair(skc, tA, tB);
             const unsigned km0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt]);
             const unsigned km1 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + 1]);
 #pragma unroll
