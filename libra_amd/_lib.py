@@ -54,7 +54,8 @@ SIGNATURES = {
     "libra_rmsnorm_wgrad_workspace_bytes": [_I64, _I64],
     "libra_rmsnorm_routed_wgrad": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
     "libra_swiglu_bwd": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P],
-    "libra_rope_bridge_bwd": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P],
+    "libra_rope_bridge_bwd": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64,
+                              _I64, _I64, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
 }

@@ -168,56 +168,130 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
 
 // ---------------------------------------------------------------------------------------------------
 // RoPE / bridge backward.  Forward:  q' = R q,  K_same = R k,  K_cross = R (k + kb),  V_cross = v + vb  (R = rotation by
-// position).  So  dq = R^T dq',  dk = R^T (dK_same + dK_cross),  dkb = R^T dK_cross,  dv = dV_same + dV_cross,  dvb = dV_cross.
+// position), kb = B_k[m] t_k, vb = B_v[m] t_v.  So  dq = R^T dq',  dk = R^T (dK_same + dK_cross),  dkb = R^T dK_cross,
+// dv = dV_same + dV_cross,  dvb = dV_cross, and the gradient of the rank-8 bridge activations dt_k = B_k[m]^T dkb,
+// dt_v = B_v[m]^T dvb - taken here, while dkb / dvb are in registers, instead of by four skinny GEMMs that re-read them.
 // R^T: (y1, y2) at (d, d+64) with c, s:  x1 = y1 c + y2 s,  x2 = y2 c - y1 s.
+// One thread = 4 channels d in [4c, 4c+4) and their partners d + 64; a workgroup = all H*16 threads of one token at a time,
+// ROPE_BWD_TOK consecutive tokens; the thread's rows of B_k / B_v stay in registers and are reloaded when the modality flips.
 struct RopeBwdArgs {
     const bf16_t* dq; const bf16_t* dks; const bf16_t* dkc; const bf16_t* dvs; const bf16_t* dvc; long ld;   // [N, H*128]
     const bf16_t* cos; const bf16_t* sin;
     bf16_t* dqkv; long ldo;      // [N, 3*H*128]
     bf16_t* dkb; long ldb;       // [N, H*128]
+    const bf16_t* bk_l; const bf16_t* bk_v; const bf16_t* bv_l; const bf16_t* bv_v;   // weight_B [H*128, 8]
+    const unsigned char* flag;
+    bf16_t* dtb; long ldt;       // [N, >= 16]: cols 0..7 = dt_k, 8..15 = dt_v
     long N; int S, H;
 };
-__global__ __launch_bounds__(256) void rope_bridge_bwd_kernel(const RopeBwdArgs p) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = p.N * p.H * 8;
-    if (i >= total) return;
-    const int c = (int)(i & 7);
-    const long th = i >> 3;
-    const int h = (int)(th % p.H);
-    const long n = th / p.H;
-    const int s = (int)(n % p.S);
+constexpr int ROPE_BWD_TOK = 16;
+
+__device__ __forceinline__ void unpack4b(const u32x2 v, float* f) {
+    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+__device__ __forceinline__ u32x2 pack4b(const float* f) {
+    u32x2 v; v[0] = pack2bf(f[0], f[1]); v[1] = pack2bf(f[2], f[3]); return v;
+}
+
+__global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs p) {
+    __shared__ float part[2][8][16];                          // [token parity][wave][16 partial sums]
+    const int LT = p.H * 16;                                  // threads per token (blockDim.x = LT rounded up to 64)
+    const int lt = threadIdx.x;
+    const bool on = lt < LT;
+    const int c = lt & 15, h = on ? lt >> 4 : 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nwaves = (blockDim.x + 63) >> 6;
     const int HD = p.H * 128;
-    const long col0 = (long)h * 128 + c * 8, col1 = col0 + 64;
-    float cs[8], sn[8];
-    unpack8(*(const u32x4*)(p.cos + (long)s * 128 + c * 8), cs);
-    unpack8(*(const u32x4*)(p.sin + (long)s * 128 + c * 8), sn);
-    auto ld2 = [&](const bf16_t* t, float* a, float* b) {
-        unpack8(*(const u32x4*)(t + n * p.ld + col0), a);
-        unpack8(*(const u32x4*)(t + n * p.ld + col1), b);
-    };
-    float q1[8], q2[8], ks1[8], ks2[8], kc1[8], kc2[8], vs1[8], vs2[8], vc1[8], vc2[8];
-    ld2(p.dq, q1, q2); ld2(p.dks, ks1, ks2); ld2(p.dkc, kc1, kc2); ld2(p.dvs, vs1, vs2); ld2(p.dvc, vc1, vc2);
-    float oq1[8], oq2[8], ok1[8], ok2[8], ob1[8], ob2[8], ov1[8], ov2[8];
+    const long col0 = (long)h * 128 + c * 4, col1 = col0 + 64;
+    u32x4 wk[2][4], wv[2][4];
+    int cur_mod = -1;
+    const long n0 = (long)blockIdx.x * ROPE_BWD_TOK;
+    for (int j = 0; j < ROPE_BWD_TOK; ++j) {
+        const long n = n0 + j;
+        if (n >= p.N) break;                                  // uniform over the workgroup
+        const int s = (int)(n % p.S);
+        float acc[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        oq1[e] = q1[e] * cs[e] + q2[e] * sn[e];
-        oq2[e] = q2[e] * cs[e] - q1[e] * sn[e];
-        ob1[e] = kc1[e] * cs[e] + kc2[e] * sn[e];
-        ob2[e] = kc2[e] * cs[e] - kc1[e] * sn[e];
-        const float t1 = ks1[e] + kc1[e], t2 = ks2[e] + kc2[e];
-        ok1[e] = t1 * cs[e] + t2 * sn[e];
-        ok2[e] = t2 * cs[e] - t1 * sn[e];
-        ov1[e] = vs1[e] + vc1[e];
-        ov2[e] = vs2[e] + vc2[e];
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if (on) {
+            const int vis = p.dtb ? p.flag[n] != 0 : 0;             // (flag may be null without the bridge operands)
+            if (p.dtb && vis != cur_mod) {
+                const bf16_t* bk = vis ? p.bk_v : p.bk_l;
+                const bf16_t* bv = vis ? p.bv_v : p.bv_l;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long col = (hf ? col1 : col0) + e;
+                        wk[hf][e] = *(const u32x4*)(bk + col * 8);
+                        wv[hf][e] = *(const u32x4*)(bv + col * 8);
+                    }
+                cur_mod = vis;
+            }
+            float cs[4], sn[4];
+            unpack4b(*(const u32x2*)(p.cos + (long)s * 128 + c * 4), cs);
+            unpack4b(*(const u32x2*)(p.sin + (long)s * 128 + c * 4), sn);
+            auto ld2 = [&](const bf16_t* t, float* a, float* b) {
+                unpack4b(*(const u32x2*)(t + n * p.ld + col0), a);
+                unpack4b(*(const u32x2*)(t + n * p.ld + col1), b);
+            };
+            float q1[4], q2[4], ks1[4], ks2[4], kc1[4], kc2[4], vs1[4], vs2[4], vc1[4], vc2[4];
+            ld2(p.dq, q1, q2); ld2(p.dks, ks1, ks2); ld2(p.dkc, kc1, kc2); ld2(p.dvs, vs1, vs2); ld2(p.dvc, vc1, vc2);
+            float oq1[4], oq2[4], ok1[4], ok2[4], ob1[4], ob2[4], ov1[4], ov2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                oq1[e] = q1[e] * cs[e] + q2[e] * sn[e];
+                oq2[e] = q2[e] * cs[e] - q1[e] * sn[e];
+                ob1[e] = kc1[e] * cs[e] + kc2[e] * sn[e];
+                ob2[e] = kc2[e] * cs[e] - kc1[e] * sn[e];
+                const float t1 = ks1[e] + kc1[e], t2 = ks2[e] + kc2[e];
+                ok1[e] = t1 * cs[e] + t2 * sn[e];
+                ok2[e] = t2 * cs[e] - t1 * sn[e];
+                ov1[e] = vs1[e] + vc1[e];
+                ov2[e] = vs2[e] + vc2[e];
+            }
+            const u32x2 b1 = pack4b(ob1), b2 = pack4b(ob2);
+            *(u32x2*)(p.dqkv + n * p.ldo + col0) = pack4b(oq1);
+            *(u32x2*)(p.dqkv + n * p.ldo + col1) = pack4b(oq2);
+            *(u32x2*)(p.dqkv + n * p.ldo + HD + col0) = pack4b(ok1);
+            *(u32x2*)(p.dqkv + n * p.ldo + HD + col1) = pack4b(ok2);
+            *(u32x2*)(p.dqkv + n * p.ldo + 2 * HD + col0) = pack4b(ov1);
+            *(u32x2*)(p.dqkv + n * p.ldo + 2 * HD + col1) = pack4b(ov2);
+            *(u32x2*)(p.dkb + n * p.ldb + col0) = b1;
+            *(u32x2*)(p.dkb + n * p.ldb + col1) = b2;
+            if (p.dtb) {
+                // dt_k[j] += dkb[c] B_k[c][j] with dkb as stored (bf16), dt_v[j] += dvb[c] B_v[c][j] with dvb = dV_cross
+                float kb1[4], kb2[4];
+                unpack4b(b1, kb1); unpack4b(b2, kb2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w0[8], w1[8], x0[8], x1[8];
+                    unpack8(wk[0][e], w0); unpack8(wk[1][e], w1); unpack8(wv[0][e], x0); unpack8(wv[1][e], x1);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        acc[r] = fmaf(kb1[e], w0[r], fmaf(kb2[e], w1[r], acc[r]));
+                        acc[8 + r] = fmaf(vc1[e], x0[r], fmaf(vc2[e], x1[r], acc[8 + r]));
+                    }
+                }
+            }
+        }
+        if (p.dtb) {
+            // workgroup reduction of the 16 sums of this token: wave sums, then 16 threads add the waves
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = wave_sum(acc[e]);
+            if (lane == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) part[j & 1][wave][e] = acc[e];
+            }
+            __syncthreads();                                  // (double-buffered by token parity: one barrier per token)
+            if (threadIdx.x < 16) {
+                float t = 0.f;
+                for (int w = 0; w < nwaves; ++w) t += part[j & 1][w][threadIdx.x];
+                p.dtb[n * p.ldt + threadIdx.x] = f2bf(t);
+            }
+        }
     }
-    *(u32x4*)(p.dqkv + n * p.ldo + col0) = pack8(oq1);
-    *(u32x4*)(p.dqkv + n * p.ldo + col1) = pack8(oq2);
-    *(u32x4*)(p.dqkv + n * p.ldo + HD + col0) = pack8(ok1);
-    *(u32x4*)(p.dqkv + n * p.ldo + HD + col1) = pack8(ok2);
-    *(u32x4*)(p.dqkv + n * p.ldo + 2 * HD + col0) = pack8(ov1);
-    *(u32x4*)(p.dqkv + n * p.ldo + 2 * HD + col1) = pack8(ov2);
-    *(u32x4*)(p.dkb + n * p.ldb + col0) = pack8(ob1);
-    *(u32x4*)(p.dkb + n * p.ldb + col1) = pack8(ob2);
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -293,18 +367,25 @@ extern "C" int libra_swiglu_bwd(const void* dy, int64_t lddy, const void* gate, 
 
 extern "C" int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const void* dk_cross, const void* dv_same,
                                      const void* dv_cross, int64_t ld, const void* cos, const void* sin, int64_t max_pos,
-                                     void* dqkv, int64_t ldo, void* dkb, int64_t ldb, int64_t N, int64_t S, int64_t H,
-                                     void* stream) {
+                                     void* dqkv, int64_t ldo, void* dkb, int64_t ldb, const void* bk_l, const void* bk_v,
+                                     const void* bv_l, const void* bv_v, const uint8_t* flag, void* dtb, int64_t ldt,
+                                     int64_t N, int64_t S, int64_t H, void* stream) {
     if (N <= 0) return LIBRA_OK;
-    if (H <= 0 || S <= 0 || S > max_pos || ld < H * 128 || ldo < 3 * H * 128 || ldb < H * 128) return LIBRA_ERR_SHAPE;
+    if (H <= 0 || H > 32 || S <= 0 || S > max_pos || ld < H * 128 || ldo < 3 * H * 128 || ldb < H * 128) return LIBRA_ERR_SHAPE;
     if ((ld % 8) || (ldo % 8) || (ldb % 8)) return LIBRA_ERR_ALIGN;
     if (!dq || !dk_same || !dk_cross || !dv_same || !dv_cross || !cos || !sin || !dqkv || !dkb) return LIBRA_ERR_ALIGN;
     if (!al16(dq) || !al16(dk_same) || !al16(dk_cross) || !al16(dv_same) || !al16(dv_cross) || !al16(dqkv) || !al16(dkb)) return LIBRA_ERR_ALIGN;
+    if (dtb && (!bk_l || !bk_v || !bv_l || !bv_v || !flag || ldt < 16 || !al16(bk_l) || !al16(bk_v) || !al16(bv_l) || !al16(bv_v)))
+        return LIBRA_ERR_ALIGN;
     RopeBwdArgs a;
     a.dq = (const bf16_t*)dq; a.dks = (const bf16_t*)dk_same; a.dkc = (const bf16_t*)dk_cross; a.dvs = (const bf16_t*)dv_same;
     a.dvc = (const bf16_t*)dv_cross; a.ld = ld; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
-    a.dqkv = (bf16_t*)dqkv; a.ldo = ldo; a.dkb = (bf16_t*)dkb; a.ldb = ldb; a.N = N; a.S = (int)S; a.H = (int)H;
-    const long total = N * H * 8;
-    hipLaunchKernelGGL(rope_bridge_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    a.dqkv = (bf16_t*)dqkv; a.ldo = ldo; a.dkb = (bf16_t*)dkb; a.ldb = ldb;
+    a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
+    a.flag = flag; a.dtb = (bf16_t*)dtb; a.ldt = ldt; a.N = N; a.S = (int)S; a.H = (int)H;
+    const int threads = (int)((H * 16 + 63) / 64 * 64);
+    const long grid = (N + ROPE_BWD_TOK - 1) / ROPE_BWD_TOK;
+    if (grid > 0x7fffffffL) return LIBRA_ERR_SHAPE;
+    hipLaunchKernelGGL(rope_bridge_bwd_kernel, dim3((unsigned)grid), dim3(threads), 0, (hipStream_t)stream, a);
     return launched();
 }

@@ -459,15 +459,15 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     dqkv, dtb = dqkvt[:, :3 * H], dqkvt[:, 3 * H:]
     dtb.zero_()
     dkb = torch.empty((N, H), dtype=BF16, device=dev)
-    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb)
+    # (dt_k = B_k^T dkb, dt_v = B_v^T dvb land in dtb[:, 0:16] from the same kernel: no skinny GEMMs re-reading dkb / dvb)
+    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb,
+                      bridge_b=(pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"]), flag=flag, dtb=dtb)
     dvb = dvc
     # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
     h = sv["h"]
     for idx, which, bk, bv in ((lang_idx, "language", pk["bk_l"], pk["bv_l"]), (vis_idx, "vision", pk["bk_v"], pk["bv_v"])):
         if idx.numel() == 0:
             continue
-        K.gemm_nt(dkb, bk, b_t=True, a_rows=idx, c_rows=idx, out=dtb[:, 0:8])
-        K.gemm_nt(dvb, bv, b_t=True, a_rows=idx, c_rows=idx, out=dtb[:, 8:16])
         nk, nv = a + f"vision_k_bridge_on_{which}.weight_B", a + f"vision_v_bridge_on_{which}.weight_B"
         if w(nk) or w(nv):
             tbc = _compact(tb, idx)

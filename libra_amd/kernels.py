@@ -530,9 +530,16 @@ def swiglu_bwd(dy, gate, up, dgate, dup):
     _lib.check(rc, "swiglu_bwd")
 
 
-def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb):
+def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb, *, bridge_b=None, flag=None, dtb=None):
+    """bridge_b = (bk_l, bk_v, bv_l, bv_v) + flag + dtb [N, >=16]: also writes the rank-8 bridge activation gradients."""
     N = dq.shape[0]
+    if dtb is not None:
+        _chk2d(dtb, "dtb")
+        bk_l, bk_v, bv_l, bv_v = bridge_b
+        extra = (bk_l.data_ptr(), bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), dtb.data_ptr(), dtb.stride(0))
+    else:
+        extra = (None, None, None, None, None, None, 0)
     rc = _lib.lib().libra_rope_bridge_bwd(dq.data_ptr(), dks.data_ptr(), dkc.data_ptr(), dvs.data_ptr(), dvc.data_ptr(),
                                           dq.stride(0), cos.data_ptr(), sin.data_ptr(), cos.shape[0], dqkv.data_ptr(),
-                                          dqkv.stride(0), dkb.data_ptr(), dkb.stride(0), N, S, H, _stream())
+                                          dqkv.stride(0), dkb.data_ptr(), dkb.stride(0), *extra, N, S, H, _stream())
     _lib.check(rc, "rope_bridge_bwd")

@@ -187,6 +187,44 @@ def test_rope_bridge(K):
     assert torch.equal(qkv[:, 2 * D:], q0[:, 2 * D:])
 
 
+def test_rope_bridge_bwd(K):
+    """dq/dk/dv through the rope transpose, dkb, and the fused rank-8 gradients dtb = [B_k[m]^T dkb, B_v[m]^T dvb]."""
+    from oracle import libra_oracle as LO
+    B, S, H = 2, 37, 32          # H = 32: the kernel's full 512-thread token group (Libra-7B/11B), ragged token tail
+    N, D = B * S, H * 128
+    dq, dks, dkc, dvs, dvc = [rnd(N, D, seed=10 + i) for i in range(5)]
+    bkl, bkv, bvl, bvv = [rnd(D, 8, seed=3 + i, scale=0.3) for i in range(4)]
+    flag = _flags(N, 9, "span")
+    cosf, sinf = LO.rope_tables(128, 64)
+    cos, sin = cosf.to(BF).cuda(), sinf.to(BF).cuda()
+    dqkvt = torch.full((N, 3 * D + 64), 7.0, dtype=BF, device="cuda")
+    dqkv, dtb = dqkvt[:, :3 * D], dqkvt[:, 3 * D:]
+    dkb = torch.empty(N, D, dtype=BF, device="cuda")
+    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, H, dqkv, dkb, bridge_b=(bkl, bkv, bvl, bvv), flag=flag.cuda(), dtb=dtb)
+    pos = torch.arange(S).repeat(B)
+    c, s_ = cos.float().cpu()[pos][:, None], sin.float().cpu()[pos][:, None]
+
+    def rope_t(t):               # transpose of x -> x cos + rotate_half(x) sin
+        t = t.float().cpu().reshape(N, H, 128)
+        t1, t2 = t[..., :64], t[..., 64:]
+        return torch.cat([t1 * c[..., :64] + t2 * s_[..., 64:], t2 * c[..., 64:] - t1 * s_[..., :64]], -1).reshape(N, D)
+    close(dqkv[:, :D], rope_t(dq), rel=4e-3, what="dq")
+    close(dqkv[:, D:2 * D], rope_t(dks.float() + dkc.float()), rel=4e-3, what="dk")
+    close(dqkv[:, 2 * D:], dvs.float() + dvc.float(), rel=4e-3, what="dv")
+    close(dkb, rope_t(dkc), rel=4e-3, what="dkb")
+    f = flag.bool()[:, None]
+    kbf, dvf = dkb.float().cpu(), dvc.float().cpu()
+    tk = torch.where(f, kbf @ bkv.float().cpu(), kbf @ bkl.float().cpu())
+    tv = torch.where(f, dvf @ bvv.float().cpu(), dvf @ bvl.float().cpu())
+    close(dtb[:, 0:8], tk, rel=6e-3, what="dt_k")
+    close(dtb[:, 8:16], tv, rel=6e-3, what="dt_v")
+    assert torch.equal(dtb[:, 16:], torch.full((N, 48), 7.0, dtype=BF, device="cuda"))     # untouched columns
+    # without the bridge operands the kernel leaves dtb alone
+    dtb.fill_(3.0)
+    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, H, dqkv, dkb)
+    assert torch.equal(dtb, torch.full((N, 64), 3.0, dtype=BF, device="cuda"))
+
+
 def test_swiglu_gather_ce(K):
     rows, I = 77, 512
     gu = rnd(rows, 2 * I, seed=1)

@@ -23,3 +23,21 @@ for _ in range(10): run()
 e.record(); torch.cuda.synchronize()
 us = s.elapsed_time(e) * 100
 print(f"rope_bridge: {us:.1f} us  ({(qkv.numel() * 2 * (1 + 2 / 3) + 2 * N * D * 2) / us / 1e6:.2f} TB/s algorithmic)")
+
+
+def timeit(fn, what, nbytes):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); s.record()
+    for _ in range(10): fn()
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 100
+    print(f"{what}: {us:.1f} us  ({nbytes / us / 1e6:.2f} TB/s algorithmic)")
+
+
+g = [torch.randn(N, D, device="cuda").to(bf) for _ in range(5)]
+dqkvt = torch.empty(N, 3 * D + 64, device="cuda", dtype=bf)
+dqkv, dtb = dqkvt[:, :3 * D], dqkvt[:, 3 * D:]
+dkb = torch.empty(N, D, device="cuda", dtype=bf)
+nb = 9 * N * D * 2
+timeit(lambda: K.rope_bridge_bwd(*g, cos, sin, S, H, dqkv, dkb), "rope_bridge_bwd (no dtb)", nb)
+timeit(lambda: K.rope_bridge_bwd(*g, cos, sin, S, H, dqkv, dkb, bridge_b=tuple(w), flag=flag, dtb=dtb), "rope_bridge_bwd (+dtb)", nb)
