@@ -62,26 +62,26 @@ def build(device, batch, embed_dim=512):
 
 def make_step(clip, tok, pixel, cot, world):
     from libra_amd.dp import BucketedGradReducer
-    params = [p for p in clip.parameters()]
+    named = list(clip.named_parameters())
 
     def step():
-        for p in params:
+        for _, p in named:
             p.grad = None
         feat, h2d, idx, ids, _, _ = tok.model.encode_flat(pixel, offset=32000, boi=32512, eoi=32513, want_ids=True,
                                                          want_quant=False)
-        feat.backward(cot)
         if world > 1:
-            red = BucketedGradReducer(bucket_bytes=64 << 20)
-            red.add({str(i): p.grad for i, p in enumerate(params) if p.grad is not None})
-            out = red.finish()
-            for i, p in enumerate(params):
-                if p.grad is not None:
-                    p.grad = out[str(i)]
+            # each layer's gradients enter their RCCL all-reduce while the layers below are still in backward
+            red = BucketedGradReducer(bucket_bytes=48 << 20)
+            with red.capture():
+                feat.backward(cot)
+            red.finish_into(named)
+        else:
+            feat.backward(cot)
         return ids
     return step
 
 
-def build_libra(device, batch, seq=2048):
+def build_libra(device, batch, seq=2048, world=1):
     """BASELINE configs[2]/[3] shape: the reference's real pretraining step — frozen CLIP ViT + VQ encode under no_grad
     (clip_encoder.py:53, image_tokenizer.py:70) -> tensor assembly -> Libra-11B routed decoder fwd+bwd with the language
     stream frozen (modeling_libra.py:1342-1346: 4.27 B trainable "vision" parameters)."""
@@ -106,7 +106,10 @@ def build_libra(device, batch, seq=2048):
     text = text.to(device)
     am = torch.ones(batch, seq, dtype=torch.long, device=device)
     spans = [[(1 + L, 2 + L)] for _ in range(batch)]
-    params = [p for p in dec.parameters() if p.requires_grad]
+    from libra_amd.dp import BucketedGradReducer
+    named = [(n, p) for n, p in dec.named_parameters() if p.requires_grad]
+    params = [p for _, p in named]
+    trainable = {n for n, _ in named}
 
     def step():
         for p in params:
@@ -118,7 +121,14 @@ def build_libra(device, batch, seq=2048):
         labels = get_labels(inp, spans, boi_token_id=tok.boi_token_id, bos_token_id=1)
         out = dec(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], vision_indices=inp["vision_indices"],
                   contiguous_signal=inp["coninous_signal"], labels=labels)
-        out.loss.backward()
+        if world > 1:
+            # 8.5 GB of bf16 gradients per step: each decoder layer's ~267 MB goes out while the layers below are in backward
+            red = BucketedGradReducer(bucket_bytes=256 << 20, only=trainable)
+            with red.capture():
+                out.loss.backward()
+            red.finish_into(named)
+        else:
+            out.loss.backward()
         return out.loss.detach()
     return step, params
 
@@ -186,11 +196,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL over xGMI.  (LIBRA_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box.)
+        backend = os.environ.get("LIBRA_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
     if args.batch is None:
         args.batch = 32 if args.workload == "vit" else 8
@@ -198,19 +211,7 @@ def main():
         clip, tok, pixel, cot = build(device, args.batch)
         step = make_step(clip, tok, pixel, cot, world)
     else:
-        from libra_amd.dp import BucketedGradReducer
-        inner, dparams = build_libra(device, args.batch)
-
-        def step():
-            loss = inner()
-            if world > 1:
-                red = BucketedGradReducer(bucket_bytes=256 << 20)
-                red.add({str(i): p.grad for i, p in enumerate(dparams) if p.grad is not None})
-                outg = red.finish()
-                for i, p in enumerate(dparams):
-                    if p.grad is not None:
-                        p.grad = outg[str(i)]
-            return loss
+        step, _ = build_libra(device, args.batch, world=world)
 
     def note(msg):
         if rank == 0:

@@ -15,6 +15,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import dp
 from . import kernels as K
 
 BF16 = torch.bfloat16
@@ -352,8 +353,11 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         K.rmsnorm_routed_wgrad(dhid, sv["x_last"], sv["rstd_f"], flag, dl, dv)
         g["model.norm.weight"], g["model.vision_norm.weight"] = K.f32_to_bf16(dl), K.f32_to_bf16(dv)
 
+    emitted: set = set()
+    dp.emit_new(g, emitted)                    # heads + final norm
     for i in range(d.layers - 1, -1, -1):
         dx = layer_backward(sd, packed[i], i, d, sv["layers"][i], dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w)
+        dp.emit_new(g, emitted)                # data parallel: this layer's gradients start their all-reduce now
 
     # ---- embeddings (modeling_libra.py:625-661)
     e = sv["emb"]
@@ -381,6 +385,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         tok = sv["input_ids"][0].reshape(-1).index_select(0, lang_idx.long())
         acc.index_add_(0, tok, dx.index_select(0, lang_idx.long()).float())
         g["model.embed_tokens.weight"] = acc.to(BF16)
+    dp.emit_new(g, emitted)
     return g
 
 

@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from . import dp
 from . import kernels as K
 
 BF16 = torch.bfloat16
@@ -179,6 +180,7 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
         if bslice is not None:
             K.colsum(dy, bslice)
 
+    emitted: set = set()
     dx_sum = None          # fp32 column sum of dx when the LayerNorm backward that produced dx already took it
     for i in range(min(top, L) - 1, -1, -1):
         pre = f"{P}encoder.layers.{i}."
@@ -212,6 +214,7 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
                              dgamma=dg1, dbeta=dbt1, dxsum=dx_sum, out=dx_ring[1] if dx is dx_ring[0] else dx_ring[0])
         if dhs[i] is not None:
             K.add_(dx, dhs[i].reshape(M, D).to(BF16).contiguous())
+        dp.emit_new(grads, emitted)            # data parallel: this layer's weight gradients start their all-reduce now
     # ---- embeddings: hs0 = LN(emb); emb = [cls ; patches] + pos
     dg0, db0 = f32(D, P + "pre_layrnorm.weight"), f32(D, P + "pre_layrnorm.bias")
     demb = K.layernorm_bwd(dx, saved["emb"], params[P + "pre_layrnorm.weight"], saved["mean0"], saved["rstd0"],
@@ -240,4 +243,5 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
     if need_pixel_grad:
         dcols = K.gemm_nt(dpatch, packed["wpe"], b_t=True)                               # [Np, kpe]
         dpixel = K.patch_col2im(dcols, B, dims.channels, dims.image, dims.image, dims.patch)
+    dp.emit_new(grads, emitted)                # the bias / LayerNorm arena and the embedding gradients
     return dpixel, grads

@@ -137,3 +137,32 @@ def test_libra_full_width_single_layer_vs_oracle():
     ours, theirs = rel_err(y.float().cpu()[valid], ref[valid]), rel_err(refb.float()[valid], ref[valid])
     print(f"full-width layer: ours {ours:.3e}, reference-style bf16 {theirs:.3e}")
     assert ours < max(1.5 * theirs, 3e-3), (ours, theirs)
+
+
+def test_libra_backward_emits_trainable_gradients_to_a_capturing_reducer():
+    """Same contract as the ViT test for the decoder under the pretraining freeze policy: only the trainable
+    ("vision") gradients are exchanged, all of them leave during the backward, results equal the plain backward."""
+    from libra_amd.dp import BucketedGradReducer
+    from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy
+    t, meta = load_golden("libra_tiny.safetensors")
+    m = LibraForCausalLM(LibraConfig(**meta["cfg"]))
+    m.load_state_dict(sub(t, "w."), strict=True)
+    m = m.to(BF).cuda()
+    apply_freeze_policy(m, frozen_language=True)
+    kw = dict(input_ids=t["in.input_ids"].cuda(), attention_mask=t["in.attention_mask"].cuda(),
+              vision_indices=t["in.vision_indices"].cuda(), contiguous_signal=t["in.signal"].to(BF).cuda(),
+              labels=t["in.labels"].cuda())
+    m(**kw).loss.backward()
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    plain = {n: p.grad.clone() for n, p in named if p.grad is not None}
+    assert plain and all("vision" in n for n in plain)
+    m.zero_grad(set_to_none=True)
+    red = BucketedGradReducer(bucket_bytes=1 << 14, only={n for n, _ in named})
+    with red.capture():
+        m(**kw).loss.backward()
+    captured = set(red.seen)
+    red.finish_into(named)
+    assert captured == set(plain), set(plain) ^ captured
+    for n, p in named:
+        if n in plain:
+            assert torch.equal(p.grad, plain[n]), n

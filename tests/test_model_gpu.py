@@ -194,3 +194,33 @@ def test_vq_full_size_roundtrip_properties(vit_l):
     assert torch.equal(packed, idx)
     assert torch.equal(body.permute(1, 2, 0).reshape(32 * 576, 2), idx)
     assert len(torch.unique(idx)) > 8          # random-init features are highly correlated; just not degenerate
+
+
+def test_vit_backward_emits_every_gradient_to_a_capturing_reducer():
+    """Data-parallel overlap hook (libra_amd/dp.py): under `reducer.capture()` the ViT backward must hand every
+    parameter gradient to the reducer layer by layer (nothing left for the exposed tail), each exactly once, and the
+    gradients installed afterwards must be the ones a plain backward produces (world size 1 = identity exchange)."""
+    from libra_amd.dp import BucketedGradReducer
+    t, meta = load_golden("vit_tiny.safetensors")
+    m = _build_clip(meta, sub(t, "w."))
+    m.requires_grad_(True)
+    x = t["in.pixel_values"].to(BF).cuda()
+    ct = t["in.cotangent"].cuda()
+
+    def loss():
+        hs = m(x, output_hidden_states=True).hidden_states
+        return (torch.cat([hs[-2], hs[-3]], -1)[:, 1:].float() * ct).sum()
+    loss().backward()
+    plain = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    red = BucketedGradReducer(bucket_bytes=1 << 14)
+    with red.capture():
+        loss().backward()
+    captured = set(red.seen)
+    launches_during_backward = red.launches
+    red.finish_into(m.named_parameters())
+    assert captured == set(plain), set(plain) ^ captured
+    assert launches_during_backward >= meta["cfg"]["num_hidden_layers"] - 2      # buckets left while backward was running
+    for n, p in m.named_parameters():
+        if n in plain:
+            assert torch.equal(p.grad, plain[n]), n
