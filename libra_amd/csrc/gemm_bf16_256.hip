@@ -17,6 +17,7 @@
 //     B_hi(t+2) and the only wait is a counted `s_waitcnt vmcnt(4)` once per K tile (phase 4), i.e. two
 //     half-tiles stay in flight across every barrier.  A buffer is re-staged only after the reads of it
 //     were retired before a barrier every wave has passed (B: lgkmcnt(0) before phase 2's barrier).
+#include <type_traits>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
@@ -202,102 +203,112 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     __syncthreads();
 
     // ---- epilogue: each wave round-trips its own 32x64 fp32 slabs through a private 8 KiB LDS region ----
+    // Two instantiations of the same code: INTERIOR (the whole 256x256 tile lies inside C and N is a multiple of 8 - every
+    // per-lane bound test and every scalar tail path folds away; > 98 % of the tiles of the hot shapes) and the generic
+    // edge version.  The choice is wave-uniform (m0 / n0 come from blockIdx).
     float* ct = (float*)(smem + wave * 8192);
     const int cg = lane & 7;                                   // 8-column group within the wave's 64 columns
     const int gn = n0 + wc * 64 + cg * 8;
-    const bool ncol_ok = gn < p.N;
-    const bool full8 = gn + 8 <= p.N;
-    float bias[8], cs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { bias[e] = 0.f; cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f; }
-    if ((p.flags & LIBRA_GEMM_BIAS) && ncol_ok) {
-        if (full8) unpack8(*(const u32x4*)(p.bias + gn), bias);
-        else for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
-    }
-    // The fused operands (row map, aux, residual) of 32-row slab i+1 are fetched before slab i is processed: the
-    // epilogue was a chain of 16 dependent global-load round trips per wave (a third of the launch at K = 1024).
     const bool want_aux = (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) && !p.slab, want_res = (p.flags & LIBRA_GEMM_RESIDUAL) && !p.slab;
-    struct Extras { int om[4]; u32x4 aux[4], res[4]; };
-    auto fetch = [&](const int i, Extras& x) {
+    // one prefetched fused operand per slab: aux when MUL_QGELU_GRAD is on, else the residual (both at once - no caller
+    // does that - loads the residual late); keeping both in flight spilled registers
+    struct Extras { int om[4]; u32x4 ext[4]; };
+    auto run = [&](auto interior) {
+        constexpr bool IN = decltype(interior)::value;
+        const bool ncol_ok = IN || gn < p.N;
+        const bool full8 = IN || gn + 8 <= p.N;
+        float bias[8], cs[8];
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int gm = m0 + wr * 128 + i * 32 + pass * 8 + (lane >> 3);
-            const bool ok = gm < p.M && ncol_ok;
-            x.om[pass] = (ok && p.c_rows) ? p.c_rows[gm] : gm;
+        for (int e = 0; e < 8; ++e) { bias[e] = 0.f; cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f; }
+        if ((p.flags & LIBRA_GEMM_BIAS) && ncol_ok) {
+            if (full8) unpack8(*(const u32x4*)(p.bias + gn), bias);
+            else for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
         }
+        // The fused operands (row map, aux, residual) of 32-row slab i+1 are fetched before slab i is processed: the
+        // epilogue was a chain of 16 dependent global-load round trips per wave (a third of the launch at K = 1024).
+        auto fetch = [&](const int i, Extras& x) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int gm = m0 + wr * 128 + i * 32 + pass * 8 + (lane >> 3);
-            const bool ok = gm < p.M && full8;
-            x.aux[pass] = u32x4{0, 0, 0, 0}; x.res[pass] = u32x4{0, 0, 0, 0};
-            if (want_aux && ok) x.aux[pass] = *(const u32x4*)(p.aux + (long)x.om[pass] * p.ldaux + gn);
-            if (want_res && ok) x.res[pass] = *(const u32x4*)(p.resid + (long)x.om[pass] * p.ldr + gn);
-        }
-    };
-    auto epi = [&](const f32x16& c0, const f32x16& c1, const int i, const Extras& ex) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ct[((r & 3) + 8 * (r >> 2) + 4 * fk) * 64 + j * 32 + l31] = (j == 0 ? c0 : c1)[r];
-        // same-wave LDS write -> read (in-order per wave)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3);
-            const int gm = m0 + wr * 128 + i * 32 + row;
-            if (gm < p.M && ncol_ok) {
-                const int om = ex.om[pass];
-                float v[8];
-                const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
-                const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
-                if (p.slab) {
-                    float* sd = p.slab + ((long)blockIdx.y * p.M + gm) * p.N + gn;   // slabs are never row-mapped
-                    if (full8) { *(f32x4*)sd = lo; *(f32x4*)(sd + 4) = hi; }
-                    else for (int e = 0; e < 8 && gn + e < p.N; ++e) sd[e] = e < 4 ? lo[e] : hi[e - 4];
-                    continue;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
-                if (p.flags & LIBRA_GEMM_STORE_PREACT) {
-                    bf16_t* pd = p.preact + (long)om * p.ldpre + gn;
-                    if (full8) *(u32x4*)pd = pack8(v);
-                    else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
-                }
-                if (p.flags & LIBRA_GEMM_QUICK_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = qgelu(bf2f(f2bf(v[e])));
-                }
-                if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
-                    float x[8];
-                    if (full8) unpack8(ex.aux[pass], x);
-                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad(x[e]);
-                }
-                if (p.flags & LIBRA_GEMM_RESIDUAL) {
-                    float x[8];
-                    if (full8) unpack8(ex.res[pass], x);
-                    else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += x[e];
-                }
-                bf16_t* dst = Cp + (long)om * p.ldc + gn;
-                if (full8) *(u32x4*)dst = pack8(v);
-                else for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
+            for (int pass = 0; pass < 4; ++pass) {
+                const int gm = m0 + wr * 128 + i * 32 + pass * 8 + (lane >> 3);
+                const bool ok = IN || (gm < p.M && ncol_ok);
+                x.om[pass] = (ok && p.c_rows) ? p.c_rows[gm] : gm;
             }
-        }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int gm = m0 + wr * 128 + i * 32 + pass * 8 + (lane >> 3);
+                const bool ok = IN || (gm < p.M && full8);
+                x.ext[pass] = u32x4{0, 0, 0, 0};
+                if (want_aux && ok) x.ext[pass] = *(const u32x4*)(p.aux + (long)x.om[pass] * p.ldaux + gn);
+                else if (want_res && ok) x.ext[pass] = *(const u32x4*)(p.resid + (long)x.om[pass] * p.ldr + gn);
+            }
+        };
+        auto epi = [&](const f32x16& c0, const f32x16& c1, const int i, const Extras& ex) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[((r & 3) + 8 * (r >> 2) + 4 * fk) * 64 + j * 32 + l31] = (j == 0 ? c0 : c1)[r];
+            // same-wave LDS write -> read (in-order per wave)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3);
+                const int gm = m0 + wr * 128 + i * 32 + row;
+                if (IN || (gm < p.M && ncol_ok)) {
+                    const int om = ex.om[pass];
+                    float v[8];
+                    const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
+                    const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
+                    if (p.slab) {
+                        float* sd = p.slab + ((long)blockIdx.y * p.M + gm) * p.N + gn;   // slabs are never row-mapped
+                        if (full8) { *(f32x4*)sd = lo; *(f32x4*)(sd + 4) = hi; }
+                        else for (int e = 0; e < 8 && gn + e < p.N; ++e) sd[e] = e < 4 ? lo[e] : hi[e - 4];
+                        continue;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
+                    if (p.flags & LIBRA_GEMM_STORE_PREACT) {
+                        bf16_t* pd = p.preact + (long)om * p.ldpre + gn;
+                        if (full8) *(u32x4*)pd = pack8(v);
+                        else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
+                    }
+                    if (p.flags & LIBRA_GEMM_QUICK_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = qgelu(bf2f(f2bf(v[e])));
+                    }
+                    if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
+                        float x[8];
+                        if (full8) unpack8(ex.ext[pass], x);
+                        else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad(x[e]);
+                    }
+                    if (p.flags & LIBRA_GEMM_RESIDUAL) {
+                        float x[8];
+                        if (full8) unpack8(want_aux ? *(const u32x4*)(p.resid + (long)om * p.ldr + gn) : ex.ext[pass], x);
+                        else for (int e = 0; e < 8; ++e) x[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += x[e];
+                    }
+                    bf16_t* dst = Cp + (long)om * p.ldc + gn;
+                    if (full8) *(u32x4*)dst = pack8(v);
+                    else for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
+                }
+            }
+        };
+        Extras e0, e1;
+        fetch(0, e0);
+        fetch(1, e1);
+        epi(acc[0][0], acc[0][1], 0, e0);
+        fetch(2, e0);
+        epi(acc[1][0], acc[1][1], 1, e1);
+        fetch(3, e1);
+        epi(acc[2][0], acc[2][1], 2, e0);
+        epi(acc[3][0], acc[3][1], 3, e1);
     };
-    Extras e0, e1;
-    fetch(0, e0);
-    fetch(1, e1);
-    epi(acc[0][0], acc[0][1], 0, e0);
-    fetch(2, e0);
-    epi(acc[1][0], acc[1][1], 1, e1);
-    fetch(3, e1);
-    epi(acc[2][0], acc[2][1], 2, e0);
-    epi(acc[3][0], acc[3][1], 3, e1);
+    if (m0 + 256 <= p.M && n0 + 256 <= p.N) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 // out[m][n] = bf16( sum_s slab[s][m][n] ), 8 elements per thread (deterministic split-K second stage)

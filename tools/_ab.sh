@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of two builds of the library inside one box visit (box-to-box variance is larger than most effects)
+L=libra_amd/lib
+for shape in "16384 4096 1024 0 0" "16384 1024 1024 0 0" "18464 4096 1024 0 1" "18464 1024 4096 0 0" "16384 4096 4096 0 0"; do
+  for rep in 1 2; do
+    for v in base exp; do
+      cp $L/$v.so.tmp $L/liblibra_hip.so
+      echo -n "$v "; python tools/gemm_one.py $shape 30 2>&1 | tail -1
+    done
+  done
+done
+cp $L/exp.so.tmp $L/liblibra_hip.so
+python -m pytest tests/test_kernels_gpu.py -m gpu -q -k gemm 2>&1 | tail -3
+for rep in 1 2; do for v in base exp; do cp $L/$v.so.tmp $L/liblibra_hip.so; echo -n "$v "; python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c100-200; done; done
