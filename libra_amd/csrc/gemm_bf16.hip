@@ -23,6 +23,7 @@
 // 16-byte aligned.  M and N are arbitrary (tail rows are clamped on load and masked on store).
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
@@ -148,85 +149,92 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
             }
     __syncthreads();
 
-    const int cgrp = tid & 15;               // 8-column group owned by this thread (fixed across rows)
-    const int gn = n0 + cgrp * 8;
-    if (gn >= p.N) return;
-    const bool full8 = (gn + 8 <= p.N);
-    float bias[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-    if (p.flags & LIBRA_GEMM_BIAS) {
-        if (full8) {
-            unpack8(*(const u32x4*)(p.bias + gn), bias);
-        } else {
-            for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
+    // Two instantiations of the same epilogue code: INTERIOR (the whole 128x128 tile lies inside C: every per-lane bound test
+    // and scalar tail path folds away) and the generic edge version; the choice is wave-uniform.
+    auto run = [&](auto interior) {
+        constexpr bool IN = decltype(interior)::value;
+        const int cgrp = tid & 15;               // 8-column group owned by this thread (fixed across rows)
+        const int gn = n0 + cgrp * 8;
+        if (!IN && gn >= p.N) return;
+        const bool full8 = IN || (gn + 8 <= p.N);
+        float bias[8];
+    #pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+        if (p.flags & LIBRA_GEMM_BIAS) {
+            if (full8) {
+                unpack8(*(const u32x4*)(p.bias + gn), bias);
+            } else {
+                for (int e = 0; e < 8 && gn + e < p.N; ++e) bias[e] = bf2f(p.bias[gn + e]);
+            }
         }
-    }
-    float cs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f;
+        float cs[8];
+    #pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = (gn + e < p.alpha_cols) ? p.alpha : 1.0f;
 
-    // fused operands (row map, aux, residual) of all 8 row passes are fetched up front: one round trip, not eight
-    const bool want_aux = (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) != 0, want_res = (p.flags & LIBRA_GEMM_RESIDUAL) != 0;
-    int oms[8];
-    u32x4 xaux[8], xres[8];
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int gm = m0 + pass * 16 + (tid >> 4);
-        oms[pass] = (gm < p.M && p.c_rows) ? p.c_rows[gm] : gm;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int gm = m0 + pass * 16 + (tid >> 4);
-        const bool ok = gm < p.M && full8;
-        xaux[pass] = u32x4{0, 0, 0, 0}; xres[pass] = u32x4{0, 0, 0, 0};
-        if (want_aux && ok) xaux[pass] = *(const u32x4*)(p.aux + (long)oms[pass] * p.ldaux + gn);
-        if (want_res && ok) xres[pass] = *(const u32x4*)(p.resid + (long)oms[pass] * p.ldr + gn);
-    }
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 16 + (tid >> 4);
-        const int gm = m0 + row;
-        if (gm >= p.M) break;
-        const int om = oms[pass];
-        float v[8];
-        const f32x4 lo = *(const f32x4*)(ct + row * BN + cgrp * 8);
-        const f32x4 hi = *(const f32x4*)(ct + row * BN + cgrp * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
-        if (p.flags & LIBRA_GEMM_STORE_PREACT) {
-            // the reference rounds the Linear output to bf16 before the activation sees it
-            bf16_t* pd = p.preact + (long)om * p.ldpre + gn;
-            if (full8) *(u32x4*)pd = pack8(v);
-            else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
+        // fused operands (row map, aux, residual) of all 8 row passes are fetched up front: one round trip, not eight
+        const bool want_aux = (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) != 0, want_res = (p.flags & LIBRA_GEMM_RESIDUAL) != 0;
+        int oms[8];
+        u32x4 xaux[8], xres[8];
+    #pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int gm = m0 + pass * 16 + (tid >> 4);
+            oms[pass] = ((IN || gm < p.M) && p.c_rows) ? p.c_rows[gm] : gm;
         }
-        if (p.flags & LIBRA_GEMM_QUICK_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(bf2f(f2bf(v[e])));
+    #pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int gm = m0 + pass * 16 + (tid >> 4);
+            const bool ok = IN || (gm < p.M && full8);
+            xaux[pass] = u32x4{0, 0, 0, 0}; xres[pass] = u32x4{0, 0, 0, 0};
+            if (want_aux && ok) xaux[pass] = *(const u32x4*)(p.aux + (long)oms[pass] * p.ldaux + gn);
+            if (want_res && ok) xres[pass] = *(const u32x4*)(p.resid + (long)oms[pass] * p.ldr + gn);
         }
-        if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
-            float a[8];
-            if (full8) unpack8(xaux[pass], a);
-            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f(a[e]);
+    #pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            const int gm = m0 + row;
+            if (!IN && gm >= p.M) break;
+            const int om = oms[pass];
+            float v[8];
+            const f32x4 lo = *(const f32x4*)(ct + row * BN + cgrp * 8);
+            const f32x4 hi = *(const f32x4*)(ct + row * BN + cgrp * 8 + 4);
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias[e]) * cs[e];
+            if (p.flags & LIBRA_GEMM_STORE_PREACT) {
+                // the reference rounds the Linear output to bf16 before the activation sees it
+                bf16_t* pd = p.preact + (long)om * p.ldpre + gn;
+                if (full8) *(u32x4*)pd = pack8(v);
+                else for (int e = 0; e < 8 && gn + e < p.N; ++e) pd[e] = f2bf(v[e]);
+            }
+            if (p.flags & LIBRA_GEMM_QUICK_GELU) {
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = quick_gelu_f(bf2f(f2bf(v[e])));
+            }
+            if (p.flags & LIBRA_GEMM_MUL_QGELU_GRAD) {
+                float a[8];
+                if (full8) unpack8(xaux[pass], a);
+                else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.aux[(long)om * p.ldaux + gn + e]) : 0.f;
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= quick_gelu_grad_f(a[e]);
+            }
+            if (p.flags & LIBRA_GEMM_RESIDUAL) {
+                float a[8];
+                if (full8) unpack8(xres[pass], a);
+                else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += a[e];
+            }
+            bf16_t* dst = Cp + (long)om * p.ldc + gn;
+            if (full8) {
+                *(u32x4*)dst = pack8(v);
+            } else {
+                for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
+            }
         }
-        if (p.flags & LIBRA_GEMM_RESIDUAL) {
-            float a[8];
-            if (full8) unpack8(xres[pass], a);
-            else for (int e = 0; e < 8; ++e) a[e] = (gn + e < p.N) ? bf2f(p.resid[(long)om * p.ldr + gn + e]) : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += a[e];
-        }
-        bf16_t* dst = Cp + (long)om * p.ldc + gn;
-        if (full8) {
-            *(u32x4*)dst = pack8(v);
-        } else {
-            for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = f2bf(v[e]);
-        }
-    }
+    };
+    if (m0 + BM <= p.M && n0 + BN <= p.N) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 }  // namespace libra

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of the library inside one box visit (box-to-box variance is larger than most effects)
 L=libra_amd/lib
-for shape in "16384 4096 1024 0 0" "16384 1024 1024 0 0" "18464 4096 1024 0 1" "18464 1024 4096 0 0" "16384 4096 4096 0 0"; do
+for shape in "2048 4096 1024 0 0" "2048 1024 4096 0 1" "18464 1024 1024 0 0" "4624 1024 1024 0 0"; do
   for rep in 1 2; do
     for v in base exp; do
       cp $L/$v.so.tmp $L/liblibra_hip.so
