@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B of two builds of the library inside one box visit (box-to-box variance is larger than most effects)
+# A/B of two builds of the library inside ONE box visit (box-to-box variance, 3-15 %, is larger than most effects):
+# build the variants into libra_amd/lib/{base,exp}.so.tmp (git-ignored, they travel with the gpurun snapshot), then
+#   gpurun -- ./tools/ab_builds.sh
+# alternates them under the same shapes, runs the GEMM parity tests on `exp`, and the bench on both.
 L=libra_amd/lib
 for shape in "2048 4096 1024 0 0" "2048 1024 4096 0 1" "18464 1024 1024 0 0" "4624 1024 1024 0 0"; do
   for rep in 1 2; do
