@@ -13,3 +13,8 @@ timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1; e
 find gpurun_out/prof -name "*stats*" | head
 # HBM traffic of the GEMM launches (PMC)
 ./tools/hbm_traffic.sh vit > gpurun_out/hbm_vit.log 2>&1; tail -2 gpurun_out/hbm_vit.log | cut -c1-400
+# full pretraining step (ViT+VQ -> Libra-11B decoder fwd+bwd): bench line + kernel stats, when asked for
+if [ "${1:-}" = "libra" ]; then
+  timeout 600 python bench.py --workload libra --steps 6 --warmup 2 > gpurun_out/bench_libra.log 2>&1; echo "bench libra rc=$?"; tail -1 gpurun_out/bench_libra.log | cut -c1-300
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_libra -- python $GRAFT_REPO_ROOT/bench.py --workload libra --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_libra.log 2>&1 ); echo "prof libra rc=$?"
+fi
