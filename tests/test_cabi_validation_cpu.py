@@ -1,0 +1,76 @@
+"""Host-side behaviour of the C ABI that needs no GPU: every entry point validates its arguments BEFORE anything
+is enqueued (bad shapes -> LIBRA_ERR_SHAPE, null / misaligned pointers -> LIBRA_ERR_ALIGN, empty problems -> LIBRA_OK),
+and the pure planning / workspace functions answer for the BASELINE shapes.  The pointers handed in are never
+dereferenced on the host; no kernel is launched by any call below."""
+import ctypes as C
+
+import pytest
+
+OK, ERR_SHAPE, ERR_ALIGN = 0, -1, -2
+P = C.c_void_p
+FAKE = P(0x10000)            # 16-byte aligned, non-null, never dereferenced
+
+
+@pytest.fixture(scope="module")
+def L():
+    from libra_amd import _lib
+    return _lib.lib()
+
+
+def _gemm(L, *, A=FAKE, lda=128, B=FAKE, ldb=128, Cp=FAKE, ldc=128, M=128, N=128, K=128, flags=0, bias=None):
+    return L.libra_gemm_bf16_nt(A, lda, B, ldb, Cp, ldc, M, N, K, bias, None, 0, None, 0, None, 0, 1.0, 0, flags, None)
+
+
+def test_gemm_argument_validation(L):
+    assert _gemm(L, K=100) == ERR_SHAPE                   # reduction length must be a multiple of 64
+    assert _gemm(L, lda=64) == ERR_SHAPE                  # leading dimension shorter than the row
+    assert _gemm(L, A=None) != OK                         # null operand
+    assert _gemm(L, A=P(0x10002)) == ERR_ALIGN            # 16-byte alignment of the LDS-DMA source
+    assert _gemm(L, flags=1) != OK                        # LIBRA_GEMM_BIAS without a bias pointer
+    assert _gemm(L, M=0) == OK                            # empty problem: nothing to do, nothing launched
+
+
+def test_row_kernels_argument_validation(L):
+    assert L.libra_layernorm_fwd(FAKE, FAKE, FAKE, FAKE, None, None, 4, 1001, 1e-5, None) == ERR_SHAPE      # D % 8
+    assert L.libra_layernorm_fwd(FAKE, FAKE, FAKE, FAKE, None, None, 0, 1024, 1e-5, None) == OK
+    assert L.libra_vit_attn_fwd(FAKE, 3072, FAKE, 1024, None, 1, 577, 0, 0.125, None) == ERR_SHAPE          # no heads
+    # rope_bridge_bwd: the 512-thread token group covers H <= 32 heads (Libra-7B / 11B); more is refused, not mis-computed
+    args = [FAKE] * 5 + [8192, FAKE, FAKE, 4096, FAKE, 3 * 8192, FAKE, 8192] + [None] * 6 + [0, 10, 10]
+    assert L.libra_rope_bridge_bwd(*args, 64, None) == ERR_SHAPE
+    # with the bridge-gradient output requested, its operands are mandatory
+    args2 = [FAKE] * 5 + [4096, FAKE, FAKE, 4096, FAKE, 3 * 4096, FAKE, 4096, None, None, None, None, None, FAKE, 64, 10, 10]
+    assert L.libra_rope_bridge_bwd(*args2, 32, None) == ERR_ALIGN
+
+
+def test_splitk_plan_for_the_baseline_shapes(L):
+    # weight gradients of the ViT step (reduction over 32 x 577 tokens, padded to 18496): few tiles, long K -> sliced
+    for M, N in [(1024, 4096), (4096, 1024), (3072, 1024), (1024, 1024)]:
+        s = L.libra_gemm_splitk_plan(M, N, 18496)
+        assert 2 <= s <= 64, (M, N, s)
+        assert L.libra_gemm_splitk_workspace_bytes(M, N, s) == s * M * N * 4
+    # forward / dgrad GEMMs of the same step fill the chip on their own
+    for M, N, K in [(18464, 4096, 1024), (18464, 1024, 4096), (18464, 3072, 1024), (16384, 11008, 4096)]:
+        assert L.libra_gemm_splitk_plan(M, N, K) == 1, (M, N, K)
+    # skinny weight gradients of the rank-8 bridges (M = 8 or 16 output rows, thousands of tokens)
+    assert L.libra_gemm_splitk_plan(16, 4096, 16384) > 1
+    assert L.libra_gemm_splitk_plan(8, 8, 64) == 1        # too small to be worth slicing
+
+
+def test_workspace_sizes_are_positive_and_scale(L):
+    a = L.libra_layernorm_bwd_workspace_bytes(18464, 1024)
+    b = L.libra_layernorm_bwd_workspace_bytes(18464, 2048)
+    assert 0 < a < b
+    assert L.libra_colsum_workspace_bytes(18464, 4096) > 0
+    assert L.libra_rmsnorm_wgrad_workspace_bytes(16384, 4096) > 0
+    assert L.libra_rmsnorm_wgrad_workspace_bytes(0, 4096) == 0
+
+
+def test_error_codes_map_to_the_reference_exception_types():
+    from libra_amd import _lib
+    _lib.check(OK, "x")
+    with pytest.raises(ValueError):            # shape mismatches are ValueError upstream (modeling_libra.py:374-403)
+        _lib.check(ERR_SHAPE, "x")
+    with pytest.raises(ValueError):
+        _lib.check(ERR_ALIGN, "x")
+    with pytest.raises(_lib.LibraHipError):
+        _lib.check(-3, "x")
