@@ -219,8 +219,10 @@ int libra_swiglu_bwd(const void* dy, int64_t lddy, const void* gate, const void*
                      void* dup, int64_t ldd, int64_t rows, int64_t I, void* stream);
 /* backward of libra_rope_bridge: dqkv [N,3*H*128] = (R^T dq', R^T (dK_same + dK_cross), dV_same + dV_cross),
  * dkb [N,H*128] = R^T dK_cross  (dvb = dV_cross itself), and - when dtb is not NULL - the gradient of the rank-8 bridge
- * activations dtb[n, 0:8] = B_k[m_n]^T dkb[n], dtb[n, 8:16] = B_v[m_n]^T dvb[n] (weight_B [H*128, 8] per modality as in
- * libra_rope_bridge; LibraAttention.forward, modeling_libra.py:318-340), taken while dkb / dvb are in registers.  H <= 32. */
+ * activations dtb[n, 0:8] = B_k[m_n]^T dkb[n], dtb[n, 8:16] = B_v[m_n]^T dvb[n] (LibraAttention.forward,
+ * modeling_libra.py:318-340), taken while dkb / dvb are in registers.  The four bridge operands are given TRANSPOSED here,
+ * bk_* / bv_* = weight_B^T, [8, H*128] row-major bf16: a dword then holds the weights of two adjacent channels for one rank,
+ * the operand shape of v_dot2_f32_bf16 against the packed gradient.  H <= 32. */
 int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const void* dk_cross, const void* dv_same,
                           const void* dv_cross, int64_t ld, const void* cos, const void* sin, int64_t max_pos,
                           void* dqkv, int64_t ldo, void* dkb, int64_t ldb, const void* bk_l, const void* bk_v,

@@ -60,7 +60,7 @@ SIGNATURES = {
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LibraHipError(RuntimeError):

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const bf16_t* __restri
 // ---------------------------------------------------------------------------------------------------
 // Routed RMSNorm backward, dx part:  y = w_m * (x * rstd)  =>  dx = rstd * (g - xh * mean(g * xh)),  g = dy * w_m, xh = x * rstd
 template <int NC>
-__global__ __launch_bounds__(256) void rmsnorm_routed_bwd_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, NC <= 8 ? 3 : 1) void rmsnorm_routed_bwd_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
                                                                  long ldx, const bf16_t* __restrict__ w_lang,
                                                                  const bf16_t* __restrict__ w_vis,
                                                                  const unsigned char* __restrict__ flag,
@@ -54,38 +54,39 @@ __global__ __launch_bounds__(256) void rmsnorm_routed_bwd_kernel(const bf16_t* _
     if (row >= rows) return;
     const int nch = D >> 3;
     const bf16_t* w = (flag && flag[row]) ? w_vis : w_lang;
+    // Every load of the row - dy, x, the weight and the residual gradient - is issued before the first use, and the row
+    // is kept as it arrived (packed bf16: 4 registers per 8 elements and operand) and unpacked again for the second
+    // sweep: one exposed memory latency per row instead of two, at the register footprint of three waves per SIMD.
+    u32x4 ra[NC], rb[NC], rw[NC], rr[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        const bool on = c < nch;
+        ra[i] = on ? *(const u32x4*)(dy + row * lddy + c * 8) : u32x4{0, 0, 0, 0};
+        rb[i] = on ? *(const u32x4*)(x + row * ldx + c * 8) : u32x4{0, 0, 0, 0};
+        rw[i] = on ? *(const u32x4*)(w + c * 8) : u32x4{0, 0, 0, 0};
+        rr[i] = (on && dres) ? *(const u32x4*)(dres + row * lddr + c * 8) : u32x4{0, 0, 0, 0};
+    }
     const float rstd = rstd_i[row];
-    float g[NC][8], xh[NC][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            float a[8], b[8], ww[8];
-            unpack8(*(const u32x4*)(dy + row * lddy + c * 8), a);
-            unpack8(*(const u32x4*)(x + row * ldx + c * 8), b);
-            unpack8(*(const u32x4*)(w + c * 8), ww);
+        float a[8], b[8], ww[8];
+        unpack8(ra[i], a); unpack8(rb[i], b); unpack8(rw[i], ww);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { g[i][e] = a[e] * ww[e]; xh[i][e] = b[e] * rstd; s += g[i][e] * xh[i][e]; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { g[i][e] = 0.f; xh[i][e] = 0.f; }
-        }
+        for (int e = 0; e < 8; ++e) s += (a[e] * ww[e]) * (b[e] * rstd);
     }
     s = wave_sum(s) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { pin(ra[i]); pin(rb[i]); pin(rw[i]); }      // (opaque: unpack again, do not keep 3 fp32 copies)
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
-            float o[8];
+            float a[8], b[8], ww[8], r[8], o[8];
+            unpack8(ra[i], a); unpack8(rb[i], b); unpack8(rw[i], ww); unpack8(rr[i], r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - xh[i][e] * s);
-            if (dres) {
-                float r[8];
-                unpack8(*(const u32x4*)(dres + row * lddr + c * 8), r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += r[e];
-            }
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (a[e] * ww[e] - (b[e] * rstd) * s) + r[e];
             *(u32x4*)(dx + row * lddx + c * 8) = pack8(o);
         }
     }
@@ -186,6 +187,11 @@ struct RopeBwdArgs {
 };
 constexpr int ROPE_BWD_TOK = 16;
 
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2_f32_bf16, fp32 accumulate)
+__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a), __builtin_bit_cast(bf16x2_hw, b), c, false);
+}
 __device__ __forceinline__ void unpack4b(const u32x2 v, float* f) {
     f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
     f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
@@ -204,7 +210,9 @@ __global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs 
     const int nwaves = (blockDim.x + 63) >> 6;
     const int HD = p.H * 128;
     const long col0 = (long)h * 128 + c * 4, col1 = col0 + 64;
-    u32x4 wk[2][4], wv[2][4];
+    // bridge weights of this thread's 4 + 4 channels for all 8 ranks, as bf16 channel PAIRS (the operands are B^T [8, D]):
+    // one v_dot2_f32_bf16 consumes two channels of a packed gradient dword against them
+    u32x2 wk[8][2], wv[8][2];
     int cur_mod = -1;
     const long n0 = (long)blockIdx.x * ROPE_BWD_TOK;
     for (int j = 0; j < ROPE_BWD_TOK; ++j) {
@@ -220,12 +228,11 @@ __global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs 
                 const bf16_t* bk = vis ? p.bk_v : p.bk_l;
                 const bf16_t* bv = vis ? p.bv_v : p.bv_l;
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+                for (int r = 0; r < 8; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const long col = (hf ? col1 : col0) + e;
-                        wk[hf][e] = *(const u32x4*)(bk + col * 8);
-                        wv[hf][e] = *(const u32x4*)(bv + col * 8);
+                    for (int hf = 0; hf < 2; ++hf) {
+                        wk[r][hf] = *(const u32x2*)(bk + (long)r * HD + (hf ? col1 : col0));
+                        wv[r][hf] = *(const u32x2*)(bv + (long)r * HD + (hf ? col1 : col0));
                     }
                 cur_mod = vis;
             }
@@ -237,7 +244,9 @@ __global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs 
                 unpack4b(*(const u32x2*)(t + n * p.ld + col1), b);
             };
             float q1[4], q2[4], ks1[4], ks2[4], kc1[4], kc2[4], vs1[4], vs2[4], vc1[4], vc2[4];
-            ld2(p.dq, q1, q2); ld2(p.dks, ks1, ks2); ld2(p.dkc, kc1, kc2); ld2(p.dvs, vs1, vs2); ld2(p.dvc, vc1, vc2);
+            const u32x2 rvc1 = *(const u32x2*)(p.dvc + n * p.ld + col0), rvc2 = *(const u32x2*)(p.dvc + n * p.ld + col1);
+            ld2(p.dq, q1, q2); ld2(p.dks, ks1, ks2); ld2(p.dkc, kc1, kc2); ld2(p.dvs, vs1, vs2);
+            unpack4b(rvc1, vc1); unpack4b(rvc2, vc2);
             float oq1[4], oq2[4], ok1[4], ok2[4], ob1[4], ob2[4], ov1[4], ov2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -261,28 +270,22 @@ __global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs 
             *(u32x2*)(p.dkb + n * p.ldb + col0) = b1;
             *(u32x2*)(p.dkb + n * p.ldb + col1) = b2;
             if (p.dtb) {
-                // dt_k[j] += dkb[c] B_k[c][j] with dkb as stored (bf16), dt_v[j] += dvb[c] B_v[c][j] with dvb = dV_cross
-                float kb1[4], kb2[4];
-                unpack4b(b1, kb1); unpack4b(b2, kb2);
+                // dt_k[r] += dkb[c] B_k[c][r] with dkb as stored (bf16), dt_v[r] += dvb[c] B_v[c][r] with dvb = dV_cross:
+                // both gradients are already packed channel pairs
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float w0[8], w1[8], x0[8], x1[8];
-                    unpack8(wk[0][e], w0); unpack8(wk[1][e], w1); unpack8(wv[0][e], x0); unpack8(wv[1][e], x1);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        acc[r] = fmaf(kb1[e], w0[r], fmaf(kb2[e], w1[r], acc[r]));
-                        acc[8 + r] = fmaf(vc1[e], x0[r], fmaf(vc2[e], x1[r], acc[8 + r]));
-                    }
+                for (int r = 0; r < 8; ++r) {
+                    acc[r] = dot2bf(b1[0], wk[r][0][0], dot2bf(b1[1], wk[r][0][1], dot2bf(b2[0], wk[r][1][0], dot2bf(b2[1], wk[r][1][1], acc[r]))));
+                    acc[8 + r] = dot2bf(rvc1[0], wv[r][0][0], dot2bf(rvc1[1], wv[r][0][1], dot2bf(rvc2[0], wv[r][1][0], dot2bf(rvc2[1], wv[r][1][1], acc[8 + r]))));
                 }
             }
         }
         if (p.dtb) {
-            // workgroup reduction of the 16 sums of this token: wave sums, then 16 threads add the waves
+            // workgroup reduction of the 16 sums of this token: wave sums (registers only), then 16 threads add the waves
+            float rs[4];
+            wave_sum16(acc, rs);                              // rs[e] in row rho = total of acc[e + 4 rho]
+            if ((lane & 15) == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = wave_sum(acc[e]);
-            if (lane == 0) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) part[j & 1][wave][e] = acc[e];
+                for (int e = 0; e < 4; ++e) part[j & 1][wave][e + 4 * (lane >> 4)] = rs[e];
             }
             __syncthreads();                                  // (double-buffered by token parity: one barrier per token)
             if (threadIdx.x < 16) {

@@ -84,6 +84,9 @@ def pack(sd: Dict[str, torch.Tensor], d: DecDims):
                                bridge_a("vision")], 0),
             bk_l=bridge_b("vision_k_bridge_on_language"), bk_v=bridge_b("vision_k_bridge_on_vision"),
             bv_l=bridge_b("vision_v_bridge_on_language"), bv_v=bridge_b("vision_v_bridge_on_vision"),
+            # the same four, transposed [8, H]: the backward takes B^T dkb / B^T dvb with v_dot2 over channel pairs
+            bkT_l=bridge_b("vision_k_bridge_on_language").t().contiguous(), bkT_v=bridge_b("vision_k_bridge_on_vision").t().contiguous(),
+            bvT_l=bridge_b("vision_v_bridge_on_language").t().contiguous(), bvT_v=bridge_b("vision_v_bridge_on_vision").t().contiguous(),
             wgu=cat([m + "gate_proj.weight", m + "up_proj.weight"]),
             agu=cat([m + "vision_gate_proj.weight_A", m + "vision_up_proj.weight_A"]),
         ))
@@ -466,7 +469,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     dkb = torch.empty((N, H), dtype=BF16, device=dev)
     # (dt_k = B_k^T dkb, dt_v = B_v^T dvb land in dtb[:, 0:16] from the same kernel: no skinny GEMMs re-reading dkb / dvb)
     K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb,
-                      bridge_b=(pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"]), flag=flag, dtb=dtb)
+                      bridge_b=(pk["bkT_l"], pk["bkT_v"], pk["bvT_l"], pk["bvT_v"]), flag=flag, dtb=dtb)
     dvb = dvc
     # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
     h = sv["h"]

@@ -531,11 +531,15 @@ def swiglu_bwd(dy, gate, up, dgate, dup):
 
 
 def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb, *, bridge_b=None, flag=None, dtb=None):
-    """bridge_b = (bk_l, bk_v, bv_l, bv_v) + flag + dtb [N, >=16]: also writes the rank-8 bridge activation gradients."""
+    """bridge_b = (bk_l, bk_v, bv_l, bv_v) as weight_B^T [8, H*128] + flag + dtb [N, >=16]: also writes the rank-8 bridge
+    activation gradients."""
     N = dq.shape[0]
     if dtb is not None:
         _chk2d(dtb, "dtb")
         bk_l, bk_v, bv_l, bv_v = bridge_b
+        for t in bridge_b:
+            if tuple(t.shape) != (8, H * 128) or not t.is_contiguous():
+                raise ValueError(f"rope_bridge_bwd: bridge operands are weight_B^T [8, {H * 128}] contiguous, got {tuple(t.shape)}")
         extra = (bk_l.data_ptr(), bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), dtb.data_ptr(), dtb.stride(0))
     else:
         extra = (None, None, None, None, None, None, 0)

@@ -203,7 +203,8 @@ def test_rope_bridge_bwd(K):
     dqkvt = torch.full((N, 3 * D + 64), 7.0, dtype=BF, device="cuda")
     dqkv, dtb = dqkvt[:, :3 * D], dqkvt[:, 3 * D:]
     dkb = torch.empty(N, D, dtype=BF, device="cuda")
-    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, H, dqkv, dkb, bridge_b=(bkl, bkv, bvl, bvv), flag=flag.cuda(), dtb=dtb)
+    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, H, dqkv, dkb, bridge_b=tuple(t.t().contiguous() for t in (bkl, bkv, bvl, bvv)),
+                      flag=flag.cuda(), dtb=dtb)
     pos = torch.arange(S).repeat(B)
     c, s_ = cos.float().cpu()[pos][:, None], sin.float().cpu()[pos][:, None]
 

@@ -40,4 +40,13 @@ dqkv, dtb = dqkvt[:, :3 * D], dqkvt[:, 3 * D:]
 dkb = torch.empty(N, D, device="cuda", dtype=bf)
 nb = 9 * N * D * 2
 timeit(lambda: K.rope_bridge_bwd(*g, cos, sin, S, H, dqkv, dkb), "rope_bridge_bwd (no dtb)", nb)
-timeit(lambda: K.rope_bridge_bwd(*g, cos, sin, S, H, dqkv, dkb, bridge_b=tuple(w), flag=flag, dtb=dtb), "rope_bridge_bwd (+dtb)", nb)
+timeit(lambda: K.rope_bridge_bwd(*g, cos, sin, S, H, dqkv, dkb, bridge_b=tuple(t.t().contiguous() for t in w), flag=flag, dtb=dtb), "rope_bridge_bwd (+dtb)", nb)
+
+# routed RMSNorm backward at the same token count (H = 4096 channels, residual gradient fused)
+Dm = 4096
+dy, x, dres = [torch.randn(N, Dm, device="cuda").to(bf) for _ in range(3)]
+wl, wv = torch.randn(Dm, device="cuda").to(bf), torch.randn(Dm, device="cuda").to(bf)
+rstd = torch.rand(N, device="cuda") + 0.5
+dx = torch.empty(N, Dm, device="cuda", dtype=bf)
+timeit(lambda: K.rmsnorm_routed_bwd(dy, x, wl, wv, flag, rstd, dres=dres, out=dx), "rmsnorm_routed_bwd (+dres)", 4 * N * Dm * 2)
+timeit(lambda: K.rmsnorm_routed_bwd(dy, x, wl, wv, flag, rstd, out=dx), "rmsnorm_routed_bwd", 3 * N * Dm * 2)
