@@ -65,6 +65,11 @@ struct RopeArgs {
 };
 
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2_f32_bf16, fp32 accumulate)
+__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a), __builtin_bit_cast(bf16x2_hw, b), c, false);
+}
 
 // One thread = 4 channels d in [4c, 4c+4) and their RoPE partners d + 64.  It keeps those 8 channels' rows of B_k / B_v
 // (64 dwords) in registers across ROPE_TOK consecutive tokens and reloads them only when the modality flips: read per
@@ -90,10 +95,11 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
     const long n_first = (long)blockIdx.x * ROPE_TOK * tpb + slot;
     u32x4 wk[2][4], wv[2][4];
     int cur_mod = -1;
-    for (int j = 0; j < ROPE_TOK; ++j) {
+    int s = (int)(n_first % p.S);                             // position of the token in its sequence: one division per
+    for (int j = 0; j < ROPE_TOK; ++j, s += tpb) {            // thread, then stepped (a 64-bit modulo per token was ~100 VALU ops)
         const long n = n_first + (long)j * tpb;
         if (n >= p.N) break;
-        const int s = (int)(n % p.S);
+        while (s >= p.S) s -= p.S;
         const int vis = p.flag[n] != 0;
         if (vis != cur_mod) {
             const bf16_t* bk = vis ? p.bk_v : p.bk_l;
@@ -108,9 +114,8 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
                 }
             cur_mod = vis;
         }
-        float tk[8], tv[8];
-        unpack8(*(const u32x4*)(p.tb + n * p.ldt), tk);
-        unpack8(*(const u32x4*)(p.tb + n * p.ldt + 8), tv);
+        // t_k, t_v stay packed: (rank 2i, 2i+1) pairs are exactly the operand shape of v_dot2_f32_bf16 against weight_B rows
+        const u32x4 tk = *(const u32x4*)(p.tb + n * p.ldt), tv = *(const u32x4*)(p.tb + n * p.ldt + 8);
         float cs[2][4], sn[2][4];
         float q[2][4], k[2][4], v[2][4], kb[2][4], vb[2][4];
 #pragma unroll
@@ -124,12 +129,9 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
             unpack4(*(const u32x2*)(p.qkv + n * p.ld + 2 * HD + col), v[hf]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float wkf[8], wvf[8];
-                unpack8(wk[hf][e], wkf);
-                unpack8(wv[hf][e], wvf);
                 float a = 0.f, b2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { a = fmaf(tk[r], wkf[r], a); b2 = fmaf(tv[r], wvf[r], b2); }
+                for (int r = 0; r < 4; ++r) { a = dot2bf(tk[r], wk[hf][e][r], a); b2 = dot2bf(tv[r], wv[hf][e][r], b2); }
                 kb[hf][e] = rbf(a);
                 vb[hf][e] = rbf(b2);
             }

@@ -215,10 +215,11 @@ __global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs 
     u32x2 wk[8][2], wv[8][2];
     int cur_mod = -1;
     const long n0 = (long)blockIdx.x * ROPE_BWD_TOK;
-    for (int j = 0; j < ROPE_BWD_TOK; ++j) {
+    int s = (int)(n0 % p.S);                                  // one division per thread, then stepped
+    for (int j = 0; j < ROPE_BWD_TOK; ++j, ++s) {
         const long n = n0 + j;
         if (n >= p.N) break;                                  // uniform over the workgroup
-        const int s = (int)(n % p.S);
+        if (s >= p.S) s -= p.S;
         float acc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
