@@ -20,26 +20,31 @@ __global__ __launch_bounds__(256) void rmsnorm_routed_kernel(const bf16_t* __res
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = D >> 3;
+    // the weight row is requested together with x (its modality flag first): one exposed memory latency per row, not two
+    const bf16_t* w = (flag && flag[row]) ? w_vis : w_lang;
+    u32x4 rx[NC], rw[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        rx[i] = c < nch ? *(const u32x4*)(x + row * ldx + c * 8) : u32x4{0, 0, 0, 0};
+        rw[i] = c < nch ? *(const u32x4*)(w + c * 8) : u32x4{0, 0, 0, 0};
+    }
     float v[NC][8];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            unpack8(*(const u32x4*)(x + row * ldx + c * 8), v[i]);
+        unpack8(rx[i], v[i]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-        }
+        for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
     }
     const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
     if (rstd_o && lane == 0) rstd_o[row] = rstd;
-    const bf16_t* w = (flag && flag[row]) ? w_vis : w_lang;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
             float g[8], o[8];
-            unpack8(*(const u32x4*)(w + c * 8), g);
+            unpack8(rw[i], g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(v[i][e] * rstd));
             *(u32x4*)(y + row * ldy + c * 8) = pack8(o);

@@ -106,19 +106,32 @@ __global__ __launch_bounds__(256) void rmsnorm_wgrad_partial_kernel(const bf16_t
     float sl[8], sv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sl[e] = 0.f; sv[e] = 0.f; }
-    for (long r = r0; r < r1; ++r) {
+    auto add_row = [&](const u32x4 ra, const u32x4 rb, const float rs, const bool vis) {
         float a[8], b[8];
-        unpack8(*(const u32x4*)(dy + r * lddy + c8), a);
-        unpack8(*(const u32x4*)(x + r * ldx + c8), b);
-        const float rs = rstd[r];
-        const bool vis = flag && flag[r];
+        unpack8(ra, a); unpack8(rb, b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float t = a[e] * b[e] * rs;
             sl[e] += vis ? 0.f : t;
             sv[e] += vis ? t : 0.f;
         }
+    };
+    // four rows (eight 16-byte loads) in flight per thread; rows are accumulated in order, so the sums do not depend on it
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        u32x4 ra[4], rb[4]; float rs[4]; bool vis[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ra[u] = *(const u32x4*)(dy + (r + u) * lddy + c8);
+            rb[u] = *(const u32x4*)(x + (r + u) * ldx + c8);
+            rs[u] = rstd[r + u];
+            vis[u] = flag && flag[r + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add_row(ra[u], rb[u], rs[u], vis[u]);
     }
+    for (; r < r1; ++r)
+        add_row(*(const u32x4*)(dy + r * lddy + c8), *(const u32x4*)(x + r * ldx + c8), rstd[r], flag && flag[r]);
     float* d0 = part + ((long)blockIdx.y * 2) * D + c8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { d0[e] = sl[e]; d0[D + e] = sv[e]; }

@@ -50,3 +50,7 @@ rstd = torch.rand(N, device="cuda") + 0.5
 dx = torch.empty(N, Dm, device="cuda", dtype=bf)
 timeit(lambda: K.rmsnorm_routed_bwd(dy, x, wl, wv, flag, rstd, dres=dres, out=dx), "rmsnorm_routed_bwd (+dres)", 4 * N * Dm * 2)
 timeit(lambda: K.rmsnorm_routed_bwd(dy, x, wl, wv, flag, rstd, out=dx), "rmsnorm_routed_bwd", 3 * N * Dm * 2)
+dl, dv = torch.zeros(Dm, device="cuda"), torch.zeros(Dm, device="cuda")
+timeit(lambda: K.rmsnorm_routed_wgrad(dy, x, rstd, flag, dl, dv), "rmsnorm_routed_wgrad", 2 * N * Dm * 2)
+y = torch.empty(N, Dm, device="cuda", dtype=bf)
+timeit(lambda: K.rmsnorm_routed(x, wl, wv, flag, 1e-6, out=y), "rmsnorm_routed fwd", 2 * N * Dm * 2)
