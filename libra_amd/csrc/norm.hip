@@ -158,8 +158,45 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_bwd_kernel(
         if (more) cur = nxt;
     }
     if (part) {
-        // per-wave partial rows [part][NP][D] (deterministic second stage: ln_param_reduce_kernel) — no atomics
-        float* pg = part + ((long)(blockIdx.x * ROWS_PER_BLOCK + wave) * NP) * D;
+        // Deterministic parameter-gradient partials, no atomics.  For D <= 2048 the four waves of the workgroup are first
+        // summed through LDS in wave order (one wave's rows at a time: NP * D floats), so ONE partial row set per workgroup
+        // reaches HBM - a quarter of the bytes written here and read again by ln_param_reduce_kernel; wider rows keep one
+        // set per wave (the LDS slab would not fit).
+        constexpr bool WG_SUM = NC <= 4;
+        if constexpr (WG_SUM) {
+            __shared__ __attribute__((aligned(16))) float comb[NP * NC * 512];
+            for (int w = 1; w < ROWS_PER_BLOCK; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        float* q = comb + (lane + 64 * i) * 8;
+                        *(f32x4*)(q) = f32x4{ag[i][0], ag[i][1], ag[i][2], ag[i][3]};
+                        *(f32x4*)(q + 4) = f32x4{ag[i][4], ag[i][5], ag[i][6], ag[i][7]};
+                        *(f32x4*)(q + NC * 512) = f32x4{ab[i][0], ab[i][1], ab[i][2], ab[i][3]};
+                        *(f32x4*)(q + NC * 512 + 4) = f32x4{ab[i][4], ab[i][5], ab[i][6], ab[i][7]};
+                        if (DXSUM) {
+                            *(f32x4*)(q + 2 * NC * 512) = f32x4{ad[i][0], ad[i][1], ad[i][2], ad[i][3]};
+                            *(f32x4*)(q + 2 * NC * 512 + 4) = f32x4{ad[i][4], ad[i][5], ad[i][6], ad[i][7]};
+                        }
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        const float* q = comb + (lane + 64 * i) * 8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            ag[i][e] += q[e]; ab[i][e] += q[NC * 512 + e];
+                            if (DXSUM) ad[i][e] += q[2 * NC * 512 + e];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (wave != 0) return;
+        }
+        float* pg = part + ((long)(WG_SUM ? blockIdx.x : blockIdx.x * ROWS_PER_BLOCK + wave) * NP) * D;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
@@ -318,8 +355,9 @@ extern "C" int libra_layernorm_bwd(const void* dy, const void* x, const void* ga
     });
     if (rc != LIBRA_OK || !dgamma) return rc;
     const int np = dxsum ? 3 : 2;
+    const int nparts = (int)(D <= 2048 ? grid : grid * ROWS_PER_BLOCK);       // (rows of D <= 2048 are summed per workgroup first)
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)np), dim3(1024), 0, (hipStream_t)stream,
-                       part, (int)(grid * ROWS_PER_BLOCK), np, (int)D, dgamma, dbeta, dxsum);
+                       part, nparts, np, (int)D, dgamma, dbeta, dxsum);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
 
