@@ -96,6 +96,10 @@ class _VitFunction(torch.autograd.Function):
         B = pixel_values.shape[0]
         ctx.model, ctx.saved, ctx.pd, ctx.packed = model, saved, pd, packed
         ctx.pixel_needs_grad = pixel_values.requires_grad
+        # hidden states nobody differentiated arrive as None, not as zero tensors: the engine then starts the backward at the
+        # last layer that has a cotangent (select_layer = [-2, -3] never reaches the last encoder layer), adds nothing for
+        # the others and keeps the fused bias-gradient path
+        ctx.set_materialize_grads(False)
         return tuple(h.view(B, dims.tokens, dims.hidden) for h in hs)
 
     @staticmethod
