@@ -473,7 +473,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     dvb = dvc
     # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
     h = sv["h"]
-    for idx, which, bk, bv in ((lang_idx, "language", pk["bk_l"], pk["bv_l"]), (vis_idx, "vision", pk["bk_v"], pk["bv_v"])):
+    for idx, which in ((lang_idx, "language"), (vis_idx, "vision")):
         if idx.numel() == 0:
             continue
         nk, nv = a + f"vision_k_bridge_on_{which}.weight_B", a + f"vision_v_bridge_on_{which}.weight_B"
