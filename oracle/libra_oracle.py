@@ -188,6 +188,88 @@ def vl_logits(sd, hidden, flag, Q: int):
     return torch.stack(outs)
 
 
+# ---- KV-cache decode path ------------------------------------------------------------------------------
+# LibraAttention.forward with past_key_value (modeling_libra.py:344-361), LibraForCausalLM.forward's cached branch
+# (:1139-1144) and prepare_inputs_for_generation's conventions (:1190-1231): the per-layer cache is
+# ([K_for_vision, K_for_language] (roped), V, V_bridge, vision_flag).  Here it is kept in the closed-form operands
+# k_same = rope(k), k_cross = rope(k + kb), v, vb with  K_for_vision[j] = flag_j ? k_same : k_cross  and
+# K_for_language[j] = flag_j ? k_cross : k_same;  `as_reference_cache` converts for comparison with the fixture.
+# Pinned by tests/test_oracle_libra_golden.py against tests/golden/libra_tiny_decode.safetensors
+# (tests/golden/make_golden_libra_decode.py runs the reference's own cached forward).
+
+def attention_step(sd, pre, x, flag, cache: Optional[dict], position_ids, key_valid, heads: int, cos, sin):
+    """x [B,q,H] = the NEW tokens (q = prompt length at prefill, 1 afterwards), flag [B,q], position_ids [B,q],
+    key_valid [B, past + q] bool (the attention_mask).  -> (out [B,q,H], new cache)."""
+    B, q_len, Hd = x.shape
+    d = Hd // heads
+    lin = lambda name: (lambda t: F.linear(t, sd[pre + name + ".weight"]))
+    low = lambda name: (lambda t: libra_linear(t, sd, pre + name + "."))
+    q = routed(x, flag, lin("q_proj"), low("vision_q_proj"))
+    k = routed(x, flag, lin("k_proj"), low("vision_k_proj"))
+    v = routed(x, flag, lin("v_proj"), low("vision_v_proj"))
+    kb = routed(x, flag, low("vision_k_bridge_on_language"), low("vision_k_bridge_on_vision"))
+    vb = routed(x, flag, low("vision_v_bridge_on_language"), low("vision_v_bridge_on_vision"))
+    hd = lambda t: t.view(B, q_len, heads, d).transpose(1, 2)
+    q, k_same, k_cross, v, vb = hd(q), hd(k), hd(k + kb), hd(v), hd(vb)
+    q = apply_rope(q, cos, sin, position_ids)
+    k_same = apply_rope(k_same, cos, sin, position_ids)
+    k_cross = apply_rope(k_cross, cos, sin, position_ids)
+    new = dict(k_same=k_same, k_cross=k_cross, v=v, vb=vb, flag=flag, pos=position_ids)
+    if cache is not None:
+        new = {n: torch.cat([cache[n], new[n]], dim=(1 if n in ("flag", "pos") else 2)) for n in new}
+    kf, kpos = new["flag"], new["pos"]                                       # [B, L]
+    cross = (flag[:, :, None] != kf[:, None, :]).unsqueeze(1)                 # [B,1,q,L]: m_i != m_j
+    s = torch.where(cross, q @ new["k_cross"].transpose(-1, -2), q @ new["k_same"].transpose(-1, -2)) / (d ** 0.5)
+    mn = torch.finfo(s.dtype).min
+    allowed = (kpos[:, None, :] <= position_ids[:, :, None]) & key_valid[:, None, :]      # causal by position + padding
+    s = torch.max(s + torch.where(allowed, 0.0, mn).to(s.dtype).unsqueeze(1), torch.tensor(mn, dtype=s.dtype))
+    p = torch.softmax(s, dim=-1, dtype=torch.float32 if s.dtype != torch.float64 else torch.float64).to(q.dtype)
+    o = p @ new["v"] + (p * cross.to(p.dtype)) @ new["vb"]
+    o = o.transpose(1, 2).reshape(B, q_len, Hd)
+    return routed(o, flag, lin("o_proj"), low("vision_o_proj")), new
+
+
+def model_step(sd, input_ids, vision_indices, signal, caches: Optional[list], position_ids, key_valid, *, layers: int, heads: int,
+               vocab: int, max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048):
+    """One cached forward over the NEW tokens input_ids [Q,B,q]: -> (hidden [B,q,H], flag [B,q], caches)."""
+    flag = vision_indices < max_vision_token_length
+    assert torch.equal(flag, input_ids[0] >= vocab)
+    x = input_embeds(sd, input_ids, flag, signal, vocab, eps)               # signal None -> zeros (:646-653)
+    cos, sin = rope_tables(x.shape[-1] // heads, max(max_pos, int(position_ids.max()) + 1), dtype=x.dtype)
+    out_caches = []
+    for i in range(layers):
+        pre = f"model.layers.{i}."
+        h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "input_layernorm.weight"], eps),
+                   lambda t: rms_norm(t, sd[pre + "vision_input_layernorm.weight"], eps))
+        a, c = attention_step(sd, pre + "self_attn.", h, flag, None if caches is None else caches[i], position_ids, key_valid,
+                              heads, cos, sin)
+        out_caches.append(c)
+        x = x + a
+        h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "post_attention_layernorm.weight"], eps),
+                   lambda t: rms_norm(t, sd[pre + "vision_post_attention_layernorm.weight"], eps))
+        x = x + mlp(sd, pre + "mlp.", h, flag)
+    x = routed(x, flag, lambda t: rms_norm(t, sd["model.norm.weight"], eps), lambda t: rms_norm(t, sd["model.vision_norm.weight"], eps))
+    return x, flag, out_caches
+
+
+def cached_logits(sd, hidden, flag, vision_indices, Q: int, *, had_past: bool, max_vision_token_length: int, newline_token_id: int):
+    """cal_vl_logits + the cached branch's EOI rule: when the step's last input token is EOI (vision index L-1) its logits
+    are replaced by "append a newline" (+inf at newline_token_id, -inf elsewhere; :1141-1144)."""
+    z = vl_logits(sd, hidden, flag, Q)
+    if had_past:
+        eoi = vision_indices[:, -1] == max_vision_token_length - 1
+        forced = torch.full((z.shape[-1],), float("-inf"), dtype=z.dtype)
+        forced[newline_token_id] = float("inf")
+        z[:, eoi, -1, :] = forced
+    return z
+
+
+def as_reference_cache(c: dict):
+    """-> (K_for_vision, K_for_language, V, V_bridge, flag) in the reference's cache layout [B, heads, L, d]."""
+    f = c["flag"][:, None, :, None]
+    return (torch.where(f, c["k_same"], c["k_cross"]), torch.where(f, c["k_cross"], c["k_same"]), c["v"], c["vb"], c["flag"])
+
+
 def causal_lm_loss(logits_q: torch.Tensor, labels_q: torch.Tensor) -> torch.Tensor:
     """mean over codebooks of shift-by-one CE with ignore_index -100 (:1160-1174)."""
     Q = logits_q.shape[0]

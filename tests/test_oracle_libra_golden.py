@@ -82,3 +82,45 @@ def test_tokenizer_tensor_assembly_matches_reference():
     assert torch.equal(am, t["out.attention_mask"])
     assert torch.equal(vi, t["out.vision_indices"])
     assert torch.equal(sig, t["out.signal"])
+
+
+def test_kv_cache_decode_matches_reference():
+    """§8f-1 groundwork: the oracle's cached step (prefill, then one token per call) against the reference's own
+    past_key_values run - per-step logits incl. the EOI -> newline rule, the layer-0 cache in the reference's layout,
+    and consistency with the oracle's uncached forward."""
+    t, meta = load_golden("libra_tiny_decode.safetensors")
+    w = sub(load_golden("libra_tiny.safetensors")[0], "w.")
+    c = meta["cfg"]
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+              max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    Q, L = c["vision_codebook_num"], c["max_vision_token_length"]
+    for name, info in meta["cases"].items():
+        ids, vi, sig = t[f"{name}.input_ids"], t[f"{name}.vision_indices"], t[f"{name}.signal"]
+        P, S = info["prefill"], info["length"]
+        valid = torch.ones(1, S, dtype=torch.bool)
+        pos = torch.arange(S).unsqueeze(0)
+        hid, flag, caches = LO.model_step(w, ids[:, :, :P], vi[:, :P], sig[:, :P], None, pos[:, :P], valid[:, :P], **kw)
+        steps = [LO.cached_logits(w, hid, flag, vi[:, :P], Q, had_past=False, max_vision_token_length=L,
+                                  newline_token_id=meta["newline_token_id"])]
+        for s in range(P, S):
+            hid, flag, caches = LO.model_step(w, ids[:, :, s:s + 1], vi[:, s:s + 1], None, caches, pos[:, s:s + 1], valid[:, :s + 1], **kw)
+            steps.append(LO.cached_logits(w, hid, flag, vi[:, s:s + 1], Q, had_past=True, max_vision_token_length=L,
+                                          newline_token_id=meta["newline_token_id"]))
+        inc = torch.cat(steps, dim=2)
+        ref = t[f"{name}.logits_incremental"]
+        assert torch.equal(torch.isfinite(inc), torch.isfinite(ref)), name
+        assert torch.equal(torch.isposinf(inc), torch.isposinf(ref)), name            # the forced newline
+        fin = torch.isfinite(ref)
+        assert rel_err(inc[fin], ref[fin]) < 2e-5, (name, rel_err(inc[fin], ref[fin]))
+        assert info["eoi_forced_steps"] == ([S - 1] if name == "B" else [])
+        kv, kl, v, vb, fl = LO.as_reference_cache(caches[0])
+        for got, key in ((kv, "k_for_vision"), (kl, "k_for_language"), (v, "v"), (vb, "v_bridge")):
+            assert rel_err(got, t[f"{name}.cache0.{key}"]) < 2e-5, (name, key)
+        assert torch.equal(fl.to(torch.uint8), t[f"{name}.cache0.flag"])
+        # and the cached path agrees with the oracle's own uncached forward (signal zero at the decoded positions)
+        full, fflag = LO.model_forward(w, ids, torch.ones(1, S, dtype=torch.long), vi, sig, **kw)
+        zf = LO.vl_logits(w, full, fflag, Q)
+        keep = torch.ones(S, dtype=torch.bool); keep[info["eoi_forced_steps"]] = False
+        a, b = inc[:, :, keep], zf[:, :, keep]
+        m = torch.isfinite(b)
+        assert rel_err(a[m], b[m]) < 2e-5, name
