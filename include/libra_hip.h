@@ -166,6 +166,22 @@ int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const 
                       const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                       int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S, int64_t H,
                       void* stream);
+/* The same with an explicit RoPE position per token (positions [N] int32, each < max_pos) instead of n % S: the cached
+ * decode step, where the N = B new tokens sit at position_ids[b] (prepare_inputs_for_generation, modeling_libra.py:1196-1209). */
+int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                          const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                          int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, const int* positions,
+                          int64_t H, void* stream);
+/* Routed-bridge attention of ONE new query token per sequence against the KV cache (LibraAttention.forward with
+ * past_key_value, modeling_libra.py:344-391, at q_len = 1).  The reference's cache ([K_for_vision, K_for_language], V,
+ * V_bridge, flag) is held as the four row buffers the training path produces - K_same, K_cross, V_same, V_cross
+ * [B, Lmax, H*128] bf16 (row stride ldc, batch stride batch_stride elements) - plus key_flag [B, Lmax] (row stride
+ * flag_stride): key j uses the *_cross buffers iff key_flag[b][j] != query_flag[b].  q, out [B, H*128]; kv_len[b] = number
+ * of valid cached tokens including the new one; scale = 1/sqrt(128).                                                       */
+int libra_bridge_attn_decode(const void* q, int64_t ldq, const void* k_same, const void* k_cross, const void* v_same,
+                             const void* v_cross, int64_t ldc, int64_t batch_stride, const uint8_t* key_flag,
+                             int64_t flag_stride, const uint8_t* query_flag, const int* kv_len, void* out, int64_t ldo,
+                             int64_t B, int64_t H, float scale, void* stream);
 /* Fused routed-bridge causal flash attention, forward (LibraAttention.forward + attn_with_bridge,
  * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right-padding via
  * kv_len[b]), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row

@@ -67,6 +67,7 @@ struct RopeArgs {
     const bf16_t* cos; const bf16_t* sin;         // [max_pos, 128] bf16 (the reference casts its fp32 cache to x.dtype)
     bf16_t* k_cross; bf16_t* v_cross; long ldc;   // [N, H*128]
     long N; int S;
+    const int* positions;                         // optional [N]: RoPE position of token n (NULL: n % S)
 };
 
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
         const long n = n_first + (long)j * tpb;
         if (n >= p.N) break;
         while (s >= p.S) s -= p.S;
+        const int pos = p.positions ? p.positions[n] : s;
         const int vis = p.flag[n] != 0;
         if (vis != cur_mod) {
             const bf16_t* bk = vis ? p.bk_v : p.bk_l;
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
         for (int hf = 0; hf < 2; ++hf) {
             const int d = hf * 64 + c * 4;
             const long col = (long)h * 128 + d;
-            unpack4(*(const u32x2*)(p.cos + (long)s * 128 + d), cs[hf]);
-            unpack4(*(const u32x2*)(p.sin + (long)s * 128 + d), sn[hf]);
+            unpack4(*(const u32x2*)(p.cos + (long)pos * 128 + d), cs[hf]);
+            unpack4(*(const u32x2*)(p.sin + (long)pos * 128 + d), sn[hf]);
             unpack4(*(const u32x2*)(p.qkv + n * p.ld + col), q[hf]);
             unpack4(*(const u32x2*)(p.qkv + n * p.ld + HD + col), k[hf]);
             unpack4(*(const u32x2*)(p.qkv + n * p.ld + 2 * HD + col), v[hf]);
@@ -281,10 +283,10 @@ extern "C" int libra_rmsnorm_routed_fwd(const void* x, int64_t ldx, const void* 
     return launched();
 }
 
-extern "C" int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
-                                 const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
-                                 int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
-                                 int64_t H, void* stream) {
+static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                           const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                           int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
+                           int64_t H, const int* positions, void* stream) {
     if (N <= 0) return LIBRA_OK;
     if (H <= 0 || S <= 0 || S > max_pos || ld < 3 * H * 128 || ldt < 16 || ldc < H * 128) return LIBRA_ERR_SHAPE;
     if ((ld % 8) || (ldt % 8) || (ldc % 8)) return LIBRA_ERR_ALIGN;
@@ -296,11 +298,29 @@ extern "C" int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t 
     a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
     a.flag = flag; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
     a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
+    a.positions = positions;
     const long LT = H * 16, tpb = LT >= 256 ? 1 : 256 / LT;
     const long gx = (N + ROPE_TOK * tpb - 1) / (ROPE_TOK * tpb), gy = LT >= 256 ? (LT + 255) / 256 : 1;
     if (gx > 0x7fffffffL || gy > 65535) return LIBRA_ERR_SHAPE;
     hipLaunchKernelGGL(rope_bridge_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, a);
     return launched();
+}
+
+extern "C" int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                                 const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                                 int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
+                                 int64_t H, void* stream) {
+    return rope_bridge_run(qkv, ld, tb, ldt, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, max_pos, k_cross, v_cross, ldc, N, S, H,
+                           nullptr, stream);
+}
+
+extern "C" int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                                     const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                                     int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N,
+                                     const int* positions, int64_t H, void* stream) {
+    if (!positions) return LIBRA_ERR_ALIGN;
+    return rope_bridge_run(qkv, ld, tb, ldt, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, max_pos, k_cross, v_cross, ldc, N, max_pos,
+                           H, positions, stream);
 }
 
 extern "C" int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows,

@@ -143,8 +143,27 @@ def _rows(n: int, c: int, dev, save: bool):
     return K.alloc_rows(n, c, dev)[:n] if save else torch.empty((n, c), dtype=BF16, device=dev)
 
 
-def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None):
-    """One LibraDecoderLayer (modeling_libra.py:437-491).  `sv` (dict) collects what the backward needs."""
+class KVCache:
+    """Per-layer key / value cache of the generation path (the reference's 4-tuple ([K_for_vision, K_for_language], V,
+    V_bridge, vision_flag), modeling_libra.py:344-361), held as the four row buffers the kernels produce anyway:
+    K_same = rope(k), K_cross = rope(k + kb), V_same = v, V_cross = v + vb, each [B, capacity, H] bf16, plus the modality
+    flag [B, capacity] of every cached token.  `length` tokens are valid in every sequence (no padding inside the cache)."""
+
+    def __init__(self, layers: int, B: int, capacity: int, H: int, device):
+        self.B, self.capacity, self.length = B, capacity, 0
+        self.layers = [tuple(torch.empty((B, capacity, H), dtype=BF16, device=device) for _ in range(4)) for _ in range(layers)]
+        self.flag = torch.zeros((B, capacity), dtype=torch.uint8, device=device)
+
+    def get_seq_length(self) -> int:
+        return self.length
+
+
+def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None, *,
+                  cache: Optional[KVCache] = None, positions: Optional[torch.Tensor] = None):
+    """One LibraDecoderLayer (modeling_libra.py:437-491).  `sv` (dict) collects what the backward needs.
+    With `cache`: positions None = prefill (the S prompt tokens' K/V rows are stored at slots [0, S)); positions int32 [B] =
+    one cached decode step (S == 1): RoPE at positions[b], the new rows appended at slot cache.length, attention of the
+    single query over the cache_len + 1 cached tokens (bridge_attn_decode)."""
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S
     dev = x.device
@@ -168,9 +187,21 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
         K.gemm_nt_grouped([t[:, j * r:(j + 1) * r] for j in range(3)],
                           [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
                           [qkv[:, j * H:(j + 1) * H] for j in range(3)], c_rows=vis_idx)
-    kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
-    o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
-                               (H // d.heads) ** -0.5, need_lse=save)
+    if positions is None:
+        kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
+    else:
+        kc, vc = K.rope_bridge_pos(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, positions, d.heads)
+    if cache is not None:                                   # plumbing copies into the cache slots
+        slot = 0 if positions is None else cache.length
+        for buf, rows in zip(cache.layers[i], (qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc)):
+            buf[:, slot:slot + S].copy_(rows.view(B, S, H))
+    if positions is None:
+        o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
+                                   (H // d.heads) ** -0.5, need_lse=save)
+    else:
+        ks_c, kc_c, vs_c, vc_c = cache.layers[i]
+        o, lse = K.bridge_attn_decode(qkv[:, :H], ks_c, kc_c, vs_c, vc_c, cache.flag, flag, lens, d.heads,
+                                      (H // d.heads) ** -0.5), None
     x_mid = torch.empty_like(x)
     to = None
     if n_l:
@@ -202,11 +233,18 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
 
 
 def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, signal, labels=None, *,
-            want_hidden_states: bool = False, save: bool = False):
-    """-> dict(hidden [B,S,H], flag, lang_idx, vis_idx, z_lang [n_l,V], z_vis list of [n_v,Vv], loss or None, saved)."""
+            want_hidden_states: bool = False, save: bool = False, cache: Optional[KVCache] = None):
+    """-> dict(hidden [B,S,H], flag, lang_idx, vis_idx, z_lang [n_l,V], z_vis list of [n_v,Vv], loss or None, saved).
+    `cache` (empty KVCache): prefill - every layer's K/V rows of the prompt are stored for decode_step."""
     Q, B, S = input_ids.shape
     dev = input_ids.device
     flag, lang_idx, vis_idx, lens = route(vision_indices, attention_mask, d)
+    if cache is not None:
+        if cache.length != 0 or S > cache.capacity or B != cache.B:
+            raise ValueError("prefill needs an empty KV cache of the batch size with capacity >= the prompt length")
+        if not bool((lens == S).all()):
+            raise NotImplementedError("cached generation handles unpadded prompts only (the decode kernel has one valid "
+                                      "length per sequence and no holes inside the cache)")
     if not torch.equal(flag.view(B, S).bool(), input_ids[0] >= d.vocab):
         raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
     cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, S), dev)
@@ -215,11 +253,14 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     hs = [x] if want_hidden_states else None
     for i in range(d.layers):
         sv = {} if save else None
-        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv)
+        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv, cache=cache)
         if save:
             saved["layers"].append(sv)
         if want_hidden_states:
             hs.append(x)
+    if cache is not None:
+        cache.flag[:, :S] = flag.view(B, S)
+        cache.length = S
     hidden, rstd_f = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
@@ -256,6 +297,47 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
                      Q=Q, input_ids=input_ids)
     return dict(hidden=hidden.view(B, S, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang,
                 z_vis=z_vis, loss=loss, hidden_states=hs, saved=saved)
+
+
+@torch.no_grad()
+def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indices, position_ids):
+    """One cached generation step (LibraForCausalLM.forward with past_key_values, modeling_libra.py:1118-1144): input_ids
+    [Q,B,1] are the NEW tokens, position_ids [B] their RoPE positions; decoded vision tokens have no encoder signal
+    (prepare_inputs_for_generation, :1216-1218 -> zeros, :646-653).  Appends to `cache`.  Same return dict as forward()."""
+    Q, B, S = input_ids.shape
+    if S != 1 or B != cache.B:
+        raise ValueError("decode_step takes exactly one new token per cached sequence")
+    if cache.length == 0 or cache.length >= cache.capacity:
+        raise ValueError("decode_step needs a prefilled KV cache with a free slot")
+    dev = input_ids.device
+    flagb = (vision_indices < d.max_vision_len).reshape(-1)
+    if not torch.equal(flagb, (input_ids[0] >= d.vocab).reshape(-1)):
+        raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
+    flag = flagb.to(torch.uint8).contiguous()
+    lang_idx = torch.nonzero(~flagb).squeeze(1).to(torch.int32).contiguous()
+    vis_idx = torch.nonzero(flagb).squeeze(1).to(torch.int32).contiguous()
+    positions = position_ids.reshape(B).to(torch.int32).contiguous()
+    cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, cache.capacity), dev)
+    cache.flag[:, cache.length] = flag
+    kv_len = torch.full((B,), cache.length + 1, dtype=torch.int32, device=dev)
+    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, None)
+    for i in range(d.layers):
+        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, kv_len, cos, sin, B, 1, None, cache=cache,
+                          positions=positions)
+    cache.length += 1
+    hidden, _ = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
+    n_l, n_v = lang_idx.numel(), vis_idx.numel()
+    z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
+    z_vis = []
+    vv_ld = K.round_up(d.vision_vocab, 8)
+    for q in range(Q):
+        if n_v:
+            buf = torch.empty((n_v, vv_ld), dtype=BF16, device=dev)
+            z_vis.append(K.gemm_nt(hidden, sd[f"vision_lm_head.heads.{q}.weight"], a_rows=vis_idx, out=buf[:, :d.vision_vocab]))
+        else:
+            z_vis.append(None)
+    return dict(hidden=hidden.view(B, 1, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang, z_vis=z_vis,
+                loss=None, hidden_states=None, saved=None)
 
 
 def dense_logits(out, d: DecDims, B: int, S: int):

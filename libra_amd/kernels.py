@@ -421,6 +421,44 @@ def rope_bridge(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, S: int, H: int)
     return kc, vc
 
 
+def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, H: int):
+    """rope_bridge with an explicit int32 position per token (the cached decode step)."""
+    _chk2d(qkv, "qkv"); _chk2d(tb, "tb")
+    N = qkv.shape[0]
+    if positions.dtype != torch.int32 or positions.numel() != N:
+        raise ValueError("rope_bridge_pos: positions must be int32 [N]")
+    kc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
+    vc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
+    rc = _lib.lib().libra_rope_bridge_pos(qkv.data_ptr(), qkv.stride(0), tb.data_ptr(), tb.stride(0), bk_l.data_ptr(),
+                                          bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), cos.data_ptr(),
+                                          sin.data_ptr(), cos.shape[0], kc.data_ptr(), vc.data_ptr(), kc.stride(0), N,
+                                          positions.data_ptr(), H, _stream())
+    _lib.check(rc, "rope_bridge_pos")
+    return kc, vc
+
+
+def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag, kv_len, H: int, scale: float):
+    """One new query token per sequence against the KV cache: q [B, H*128]; caches [B, Lmax, H*128] (same strides);
+    key_flag [B, Lmax] u8, query_flag [B] u8, kv_len [B] int32 (valid cached tokens incl. the new one) -> [B, H*128]."""
+    _chk2d(q, "q")
+    B = q.shape[0]
+    for t in (k_same, k_cross, v_same, v_cross):
+        if t.dim() != 3 or t.shape[0] != B or t.shape[2] != H * 128 or t.stride(2) != 1 or t.dtype != BF16 or \
+                t.stride() != k_same.stride():
+            raise ValueError("bridge_attn_decode: caches must be [B, Lmax, H*128] bf16 with identical strides")
+    if key_flag.dtype != torch.uint8 or query_flag.dtype != torch.uint8 or kv_len.dtype != torch.int32:
+        raise ValueError("bridge_attn_decode: flags are uint8, kv_len is int32")
+    if int(kv_len.max()) > k_same.shape[1]:
+        raise ValueError("bridge_attn_decode: kv_len exceeds the cache length")
+    out = torch.empty((B, H * 128), dtype=BF16, device=q.device)
+    rc = _lib.lib().libra_bridge_attn_decode(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_cross.data_ptr(), v_same.data_ptr(),
+                                             v_cross.data_ptr(), k_same.stride(1), k_same.stride(0), key_flag.data_ptr(),
+                                             key_flag.stride(0), query_flag.data_ptr(), kv_len.data_ptr(), out.data_ptr(),
+                                             out.stride(0), B, H, float(scale), _stream())
+    _lib.check(rc, "bridge_attn_decode")
+    return out
+
+
 def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S: int, H: int, scale: float, *,
                     need_lse: bool = False):
     for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross")):

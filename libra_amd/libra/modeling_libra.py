@@ -190,13 +190,19 @@ class LibraForCausalLM(PreTrainedModel):
                 past_hidden_states=None, past_vision_flag=None):
         if input_ids is None or vision_indices is None:
             raise ValueError("You have to specify input_ids [Q,B,S] and vision_indices [B,S]")
-        if inputs_embeds is not None or past_key_values is not None or use_cache:
-            raise NotImplementedError("incremental decoding with the bridge KV cache is SURVEY §8f item 1")
-        if position_ids is not None or output_attentions:
-            raise NotImplementedError("custom position_ids / attention maps are not produced by the fused kernels")
+        if inputs_embeds is not None:
+            raise NotImplementedError("inputs_embeds: the embedding gather is part of the fused path")
+        if output_attentions:
+            raise NotImplementedError("attention maps are not produced by the fused kernels")
         if not input_ids.is_cuda:
             raise RuntimeError("libra_amd LibraForCausalLM runs on MI355X only; got CPU tensors (no CPU fallback)")
         assert len(input_ids) == self.config.vision_codebook_num                      # :705
+        if past_key_values is not None or use_cache:
+            if labels is not None:
+                raise ValueError("labels with use_cache / past_key_values: the cached path is inference only (:1142)")
+            return self._forward_cached(input_ids, attention_mask, position_ids, past_key_values, contiguous_signal, vision_indices)
+        if position_ids is not None:
+            raise NotImplementedError("custom position_ids on the training path (positions are arange(S), :736-739)")
         Q, B, S = input_ids.shape
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.bool, device=input_ids.device)
@@ -217,10 +223,47 @@ class LibraForCausalLM(PreTrainedModel):
         object.__setattr__(res, "_engine_out", out)
         return res
 
+    @torch.no_grad()
+    def _forward_cached(self, input_ids, attention_mask, position_ids, past, signal, vision_indices):
+        """Generation path (LibraForCausalLM.forward with use_cache / past_key_values, modeling_libra.py:1118-1188):
+        `past` None = prefill of the prompt (returns a filled DE.KVCache as `.past_key_values`); otherwise one new token per
+        sequence.  `.logits` is materialised ([Q,B,q,V+Vv], q = the tokens of this call) with the cached branch's rule that an
+        EOI input token predicts nothing but a newline (:1141-1144)."""
+        Q, B, S = input_ids.shape
+        dims = self._dims
+        sd, packed = self._state()
+        dev = input_ids.device
+        if past is None:
+            if attention_mask is None:
+                attention_mask = torch.ones((B, S), dtype=torch.bool, device=dev)
+            if position_ids is not None and not torch.equal(position_ids.reshape(B, S).to(dev), torch.arange(S, device=dev).expand(B, S)):
+                raise NotImplementedError("prefill positions other than arange(S)")
+            cache = DE.KVCache(dims.layers, B, max(dims.max_pos, S), dims.hidden, dev)
+            out = DE.forward(sd, packed, dims, input_ids, attention_mask, vision_indices, signal, None, cache=cache)
+        else:
+            if not isinstance(past, DE.KVCache):
+                raise TypeError("past_key_values must be the KVCache returned by a previous call of this model")
+            if S != 1:
+                raise ValueError("only support generating token by token")             # cal_vision_logits_inference, :912
+            if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
+                raise NotImplementedError("cached generation handles unpadded sequences only")
+            cache = past
+            if position_ids is None:                                                    # attention_mask.cumsum(-1) - 1, :1207
+                position_ids = torch.full((B, 1), cache.length, dtype=torch.long, device=dev)
+            out = DE.decode_step(sd, packed, dims, cache, input_ids, vision_indices, position_ids)
+        logits = DE.dense_logits(out, dims, B, S)
+        if past is not None:
+            eoi = vision_indices[:, -1] == self.max_vision_token_length - 1
+            if bool(eoi.any()):
+                forced = torch.full((logits.shape[-1],), float("-inf"), dtype=logits.dtype, device=dev)
+                forced[self.config.newline_token_id] = float("inf")
+                logits[:, eoi, -1, :] = forced
+        return LibraCausalLMOutputWithPast(loss=None, logits=logits, past_key_values=cache, hidden_states=None, attentions=None)
+
     @staticmethod
     def materialize_logits(output) -> torch.Tensor:
         """[Q,B,S,V+Vv] exactly as the reference's `.logits` (text rows [lm_head | -inf], vision rows [-inf | head_q])."""
-        return output._lazy_logits.get()
+        return output.logits if output.logits is not None else output._lazy_logits.get()
 
 
 class _LibraFunction(torch.autograd.Function):

@@ -251,3 +251,48 @@ def test_swiglu_gather_ce(K):
     ref = F.cross_entropy(z[:, :V].float().cpu(), (tgt - 1000).clamp_min(0), reduction="none")
     ref[tgt < 0] = 0
     close(loss, ref, rel=1e-4, what="ce rows")
+
+
+def test_rope_bridge_with_explicit_positions(K):
+    """rope_bridge_pos on a shuffled subset of tokens with their positions == the rows rope_bridge produces in sequence order
+    (bit-exact: same kernel, the position operand replaces n % S)."""
+    from oracle import libra_oracle as LO
+    B, S, H = 2, 40, 2
+    N, D = B * S, H * 128
+    qkv = rnd(N, 3 * D, seed=1)
+    tb = torch.zeros(N, 64, dtype=BF, device="cuda"); tb[:, :16] = rnd(N, 16, seed=2)
+    w = [rnd(D, 8, seed=3 + i, scale=0.3) for i in range(4)]
+    flag = _flags(N, 9, "random").cuda()
+    cosf, sinf = LO.rope_tables(128, 64)
+    cos, sin = cosf.to(BF).cuda(), sinf.to(BF).cuda()
+    full = qkv.clone()
+    kc, vc = K.rope_bridge(full, tb, *w, flag, cos, sin, S, H)
+    pick = torch.randperm(N, generator=torch.Generator().manual_seed(4))[:23].cuda()
+    sub = qkv[pick].contiguous()
+    kc2, vc2 = K.rope_bridge_pos(sub, tb[pick].contiguous(), *w, flag[pick].contiguous(), cos, sin, (pick % S).to(torch.int32), H)
+    assert torch.equal(sub, full[pick]) and torch.equal(kc2, kc[pick]) and torch.equal(vc2, vc[pick])
+
+
+@pytest.mark.parametrize("B,H,Lmax,mode", [(1, 1, 16, "span"), (3, 2, 77, "random"), (2, 4, 300, "allvis"), (8, 32, 2048, "span")])
+def test_bridge_attention_decode(K, B, H, Lmax, mode):
+    """One query token per sequence against the KV cache == the last row of the training-path closed form."""
+    D = H * 128
+    g = torch.Generator().manual_seed(5)
+    caches = [rnd(B * Lmax, D, seed=30 + i).view(B, Lmax, D) for i in range(4)]          # K_same, K_cross, V_same, V_cross
+    q = rnd(B, D, seed=40)
+    kflag = _flags(B * Lmax, 11, mode).view(B, Lmax)
+    lens = torch.randint(1, Lmax + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = Lmax
+    if B > 1:
+        lens[1] = 1                                           # a sequence whose cache holds only the new token
+    qflag = (torch.rand(B, generator=g) < 0.5).to(torch.uint8)
+    out = K.bridge_attn_decode(q, *caches, kflag.cuda(), qflag.cuda(), lens.cuda(), H, 128 ** -0.5)
+    ks, kc, vs, vc = [c.float().cpu().view(B, Lmax, H, 128) for c in caches]
+    qh = q.float().cpu().view(B, H, 128)
+    cross = (kflag.bool() != qflag.bool()[:, None])[:, :, None, None]
+    kk, vv = torch.where(cross, kc, ks), torch.where(cross, vc, vs)
+    s = torch.einsum("bhd,blhd->bhl", qh, kk) * 128 ** -0.5
+    s = s.masked_fill(torch.arange(Lmax)[None, None, :] >= lens[:, None, None].long(), float("-inf"))
+    ref = torch.einsum("bhl,blhd->bhd", torch.softmax(s, -1), vv).reshape(B, D)
+    close(out, ref, rel=2e-3, what="bridge decode attention")
+    assert torch.isfinite(out.float()).all()

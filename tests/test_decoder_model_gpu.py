@@ -166,3 +166,77 @@ def test_libra_backward_emits_trainable_gradients_to_a_capturing_reducer():
     for n, p in named:
         if n in plain:
             assert torch.equal(p.grad, plain[n]), n
+
+
+def test_libra_tiny_cached_decode_vs_reference_fixture():
+    """Generation path: prefill with use_cache, then one token per call with past_key_values, against the
+    per-step logits of the reference's own cached run (fixture) and against the fp32 oracle's cached step on the bf16-rounded
+    weights; plus consistency with this model's own uncached forward."""
+    from libra_amd.libra import LibraConfig, LibraForCausalLM
+    from oracle import libra_oracle as LO
+    t, meta = load_golden("libra_tiny_decode.safetensors")
+    w = sub(load_golden("libra_tiny.safetensors")[0], "w.")
+    c = meta["cfg"]
+    m = LibraForCausalLM(LibraConfig(**c))
+    m.load_state_dict(w, strict=True)
+    m = m.to(BF).cuda().eval()
+    sdf = {k: v.to(BF).float() for k, v in w.items()}
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+              max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    Q, L = c["vision_codebook_num"], c["max_vision_token_length"]
+    for name, info in meta["cases"].items():
+        ids, vi, sig = t[f"{name}.input_ids"].cuda(), t[f"{name}.vision_indices"].cuda(), t[f"{name}.signal"].to(BF).cuda()
+        P, S = info["prefill"], info["length"]
+        with torch.no_grad():
+            out = m(input_ids=ids[:, :, :P], vision_indices=vi[:, :P], contiguous_signal=sig[:, :P], use_cache=True)
+            steps, past = [out.logits], out.past_key_values
+            assert past.get_seq_length() == P
+            for s in range(P, S):
+                out = m(input_ids=ids[:, :, s:s + 1], vision_indices=vi[:, s:s + 1], past_key_values=past, use_cache=True,
+                        position_ids=torch.tensor([[s]], device="cuda"))
+                past = out.past_key_values
+                steps.append(out.logits)
+            assert past.get_seq_length() == S
+            full = m(input_ids=ids, vision_indices=vi, contiguous_signal=sig)
+        inc = torch.cat(steps, dim=2).float().cpu()
+        ref = t[f"{name}.logits_incremental"]
+        assert inc.shape == ref.shape
+        assert torch.equal(torch.isfinite(inc), torch.isfinite(ref)), name             # -inf padding pattern
+        assert torch.equal(torch.isposinf(inc), torch.isposinf(ref)), name             # EOI -> newline
+        # fp32 oracle cached run on the bf16-rounded weights: only the arithmetic differs
+        valid = torch.ones(1, S, dtype=torch.bool)
+        pos = torch.arange(S).unsqueeze(0)
+        sgf = t[f"{name}.signal"].to(BF).float()
+        hid, flag, caches = LO.model_step(sdf, t[f"{name}.input_ids"][:, :, :P], t[f"{name}.vision_indices"][:, :P], sgf[:, :P], None,
+                                          pos[:, :P], valid[:, :P], **kw)
+        osteps = [LO.vl_logits(sdf, hid, flag, Q)]
+        for s in range(P, S):
+            hid, flag, caches = LO.model_step(sdf, t[f"{name}.input_ids"][:, :, s:s + 1], t[f"{name}.vision_indices"][:, s:s + 1], None,
+                                              caches, pos[:, s:s + 1], valid[:, :s + 1], **kw)
+            osteps.append(LO.vl_logits(sdf, hid, flag, Q))
+        oref = torch.cat(osteps, dim=2)
+        fin = torch.isfinite(ref)
+        # the same cached run in the reference's own op-by-op bf16 arithmetic: the yardstick for "bf16 noise" on these logits
+        sdb = {k: v.to(BF) for k, v in w.items()}
+        sgb = t[f"{name}.signal"].to(BF)
+        hb, fb, cb = LO.model_step(sdb, t[f"{name}.input_ids"][:, :, :P], t[f"{name}.vision_indices"][:, :P], sgb[:, :P], None,
+                                   pos[:, :P], valid[:, :P], **kw)
+        bsteps = [LO.vl_logits(sdb, hb, fb, Q)]
+        for s in range(P, S):
+            hb, fb, cb = LO.model_step(sdb, t[f"{name}.input_ids"][:, :, s:s + 1], t[f"{name}.vision_indices"][:, s:s + 1], None, cb,
+                                       pos[:, s:s + 1], valid[:, :s + 1], **kw)
+            bsteps.append(LO.vl_logits(sdb, hb, fb, Q))
+        theirs = rel_err(torch.cat(bsteps, dim=2).float()[fin], oref[fin])
+        # the cached and the uncached path of this model agree (same kernels except the attention / rope entry points)
+        fl = LibraForCausalLM.materialize_logits(full).float().cpu()
+        keep = torch.ones(S, dtype=torch.bool); keep[info["eoi_forced_steps"]] = False
+        a, b = inc[:, :, keep], fl[:, :, keep]
+        mfin = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), mfin)
+        e_self = rel_err(a[mfin], b[mfin])
+        e_oracle = rel_err(inc[fin], oref[fin])
+        e_fix = rel_err(inc[fin], ref[fin])
+        report = dict(case=name, cached_vs_uncached=e_self, vs_fp32_oracle=e_oracle, vs_reference_fixture=e_fix, reference_bf16=theirs)
+        assert e_self < max(1.5 * theirs, 6e-3), report
+        assert e_oracle < max(2.0 * theirs, 6e-3), report            # the forward test's criterion
+        assert e_fix < max(3.0 * theirs, 3e-2), report               # vs the reference's fp32-weight run: + weight rounding
