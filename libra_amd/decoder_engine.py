@@ -46,8 +46,19 @@ class DecDims:
         return self.inter // self.down_ratio
 
 
+_ROPE_TABLES: Dict[tuple, tuple] = {}
+
+
 def rope_tables(dim: int, n_pos: int, device, base: float = 10000.0):
-    """LlamaRotaryEmbedding cache (models/llama/modeling_llama.py:135-164): fp32 tables, cast to bf16 on use."""
+    """LlamaRotaryEmbedding cache (models/llama/modeling_llama.py:135-164): fp32 tables, cast to bf16 on use.
+    Built once per (dim, n_pos, device): the generation loop asks for them at every step."""
+    key = (dim, n_pos, str(device), base)
+    if key not in _ROPE_TABLES:
+        _ROPE_TABLES[key] = _rope_tables(dim, n_pos, device, base)
+    return _ROPE_TABLES[key]
+
+
+def _rope_tables(dim: int, n_pos: int, device, base: float):
     inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
     t = torch.arange(n_pos, dtype=torch.float32)
     freqs = torch.einsum("i,j->ij", t, inv)
@@ -153,17 +164,20 @@ class KVCache:
         self.B, self.capacity, self.length = B, capacity, 0
         self.layers = [tuple(torch.empty((B, capacity, H), dtype=BF16, device=device) for _ in range(4)) for _ in range(layers)]
         self.flag = torch.zeros((B, capacity), dtype=torch.uint8, device=device)
+        self.graphs: Dict[tuple, tuple] = {}               # routing pattern of a decode step -> (hipGraph, static buffers, outputs)
 
     def get_seq_length(self) -> int:
         return self.length
 
 
 def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None, *,
-                  cache: Optional[KVCache] = None, positions: Optional[torch.Tensor] = None):
+                  cache: Optional[KVCache] = None, positions: Optional[torch.Tensor] = None,
+                  slot: Optional[torch.Tensor] = None):
     """One LibraDecoderLayer (modeling_libra.py:437-491).  `sv` (dict) collects what the backward needs.
     With `cache`: positions None = prefill (the S prompt tokens' K/V rows are stored at slots [0, S)); positions int32 [B] =
     one cached decode step (S == 1): RoPE at positions[b], the new rows appended at slot cache.length, attention of the
-    single query over the cache_len + 1 cached tokens (bridge_attn_decode)."""
+    single query over the cache_len + 1 cached tokens (bridge_attn_decode); `slot` is the cache slot as a device tensor
+    [1] int64 so that the step contains no host-side shape or index and can be captured in a hipGraph."""
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S
     dev = x.device
@@ -192,9 +206,11 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     else:
         kc, vc = K.rope_bridge_pos(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, positions, d.heads)
     if cache is not None:                                   # plumbing copies into the cache slots
-        slot = 0 if positions is None else cache.length
         for buf, rows in zip(cache.layers[i], (qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc)):
-            buf[:, slot:slot + S].copy_(rows.view(B, S, H))
+            if positions is None:
+                buf[:, :S].copy_(rows.view(B, S, H))
+            else:
+                buf.index_copy_(1, slot, rows.view(B, 1, H))
     if positions is None:
         o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
                                    (H // d.heads) ** -0.5, need_lse=save)
@@ -299,32 +315,18 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
                 z_vis=z_vis, loss=loss, hidden_states=hs, saved=saved)
 
 
-@torch.no_grad()
-def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indices, position_ids):
-    """One cached generation step (LibraForCausalLM.forward with past_key_values, modeling_libra.py:1118-1144): input_ids
-    [Q,B,1] are the NEW tokens, position_ids [B] their RoPE positions; decoded vision tokens have no encoder signal
-    (prepare_inputs_for_generation, :1216-1218 -> zeros, :646-653).  Appends to `cache`.  Same return dict as forward()."""
-    Q, B, S = input_ids.shape
-    if S != 1 or B != cache.B:
-        raise ValueError("decode_step takes exactly one new token per cached sequence")
-    if cache.length == 0 or cache.length >= cache.capacity:
-        raise ValueError("decode_step needs a prefilled KV cache with a free slot")
-    dev = input_ids.device
-    flagb = (vision_indices < d.max_vision_len).reshape(-1)
-    if not torch.equal(flagb, (input_ids[0] >= d.vocab).reshape(-1)):
-        raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
-    flag = flagb.to(torch.uint8).contiguous()
-    lang_idx = torch.nonzero(~flagb).squeeze(1).to(torch.int32).contiguous()
-    vis_idx = torch.nonzero(flagb).squeeze(1).to(torch.int32).contiguous()
-    positions = position_ids.reshape(B).to(torch.int32).contiguous()
+def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
+    """The device work of one cached step on static buffers `st` (ids [Q,B,1], flag [B], lang_idx, vis_idx, positions [B]
+    int32, slot [1] int64, kv_len [B] int32): no host synchronisation, no host-side index - capturable."""
+    Q, B = st["ids"].shape[0], st["ids"].shape[1]
+    flag, lang_idx, vis_idx = st["flag"], st["lang_idx"], st["vis_idx"]
+    dev = flag.device
     cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, cache.capacity), dev)
-    cache.flag[:, cache.length] = flag
-    kv_len = torch.full((B,), cache.length + 1, dtype=torch.int32, device=dev)
-    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, None)
+    cache.flag.index_copy_(1, st["slot"], flag.view(B, 1))
+    x = embed(sd, d, st["ids"], flag, lang_idx, vis_idx, None)
     for i in range(d.layers):
-        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, kv_len, cos, sin, B, 1, None, cache=cache,
-                          positions=positions)
-    cache.length += 1
+        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, st["kv_len"], cos, sin, B, 1, None, cache=cache,
+                          positions=st["positions"], slot=st["slot"])
     hidden, _ = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
@@ -338,6 +340,59 @@ def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indice
             z_vis.append(None)
     return dict(hidden=hidden.view(B, 1, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang, z_vis=z_vis,
                 loss=None, hidden_states=None, saved=None)
+
+
+@torch.no_grad()
+def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indices, position_ids, *, use_graph: bool = True):
+    """One cached generation step (LibraForCausalLM.forward with past_key_values, modeling_libra.py:1118-1144): input_ids
+    [Q,B,1] are the NEW tokens, position_ids [B] their RoPE positions; decoded vision tokens have no encoder signal
+    (prepare_inputs_for_generation, :1216-1218 -> zeros, :646-653).  Appends to `cache`.  Same return dict as forward().
+
+    A step is ~40 small launches per layer on B rows - launch-bound by two orders of magnitude against its HBM floor - so it
+    is captured ONCE per routing pattern (which of the B new tokens are vision tokens) into a hipGraph over static buffers and
+    replayed; the pattern is the only host read of the step.  The outputs live in the graph's buffers: consume them before the
+    next step."""
+    Q, B, S = input_ids.shape
+    if S != 1 or B != cache.B:
+        raise ValueError("decode_step takes exactly one new token per cached sequence")
+    if cache.length == 0 or cache.length >= cache.capacity:
+        raise ValueError("decode_step needs a prefilled KV cache with a free slot")
+    dev = input_ids.device
+    flagb = (vision_indices < d.max_vision_len).reshape(-1)
+    pattern = tuple(torch.stack([flagb, (input_ids[0] >= d.vocab).reshape(-1)]).tolist())      # the one host read
+    if pattern[0] != pattern[1]:
+        raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
+    key = tuple(pattern[0])
+    entry = cache.graphs.get(key) if use_graph else None
+    if entry is None:
+        st = dict(ids=input_ids.clone(), flag=flagb.to(torch.uint8).contiguous(),
+                  lang_idx=torch.nonzero(~flagb).squeeze(1).to(torch.int32).contiguous(),
+                  vis_idx=torch.nonzero(flagb).squeeze(1).to(torch.int32).contiguous(),
+                  positions=torch.empty(B, dtype=torch.int32, device=dev), slot=torch.empty(1, dtype=torch.int64, device=dev),
+                  kv_len=torch.empty(B, dtype=torch.int32, device=dev))
+    else:
+        graph, st, out = entry
+        st["ids"].copy_(input_ids)
+    st["positions"].copy_(position_ids.reshape(B))
+    st["slot"].fill_(cache.length)
+    st["kv_len"].fill_(cache.length + 1)
+    if not use_graph:
+        out = _decode_core(sd, packed, d, cache, st)
+    elif entry is None:
+        side = torch.cuda.Stream(device=dev)                                            # warm-up off the capture (first-use
+        side.wait_stream(torch.cuda.current_stream(dev))                                # kernel attributes, allocator pools);
+        with torch.cuda.stream(side):                                                   # it writes the same slot the replay does
+            _decode_core(sd, packed, d, cache, st)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = _decode_core(sd, packed, d, cache, st)
+        cache.graphs[key] = (graph, st, out)
+        graph.replay()
+    else:
+        graph.replay()
+    cache.length += 1
+    return out
 
 
 def dense_logits(out, d: DecDims, B: int, S: int):

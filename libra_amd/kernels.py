@@ -439,7 +439,8 @@ def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, 
 
 def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag, kv_len, H: int, scale: float):
     """One new query token per sequence against the KV cache: q [B, H*128]; caches [B, Lmax, H*128] (same strides);
-    key_flag [B, Lmax] u8, query_flag [B] u8, kv_len [B] int32 (valid cached tokens incl. the new one) -> [B, H*128]."""
+    key_flag [B, Lmax] u8, query_flag [B] u8, kv_len [B] int32 (valid cached tokens incl. the new one, <= Lmax: the caller's
+    invariant - checking it here would be a host synchronisation inside a capturable step) -> [B, H*128]."""
     _chk2d(q, "q")
     B = q.shape[0]
     for t in (k_same, k_cross, v_same, v_cross):
@@ -448,8 +449,6 @@ def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag
             raise ValueError("bridge_attn_decode: caches must be [B, Lmax, H*128] bf16 with identical strides")
     if key_flag.dtype != torch.uint8 or query_flag.dtype != torch.uint8 or kv_len.dtype != torch.int32:
         raise ValueError("bridge_attn_decode: flags are uint8, kv_len is int32")
-    if int(kv_len.max()) > k_same.shape[1]:
-        raise ValueError("bridge_attn_decode: kv_len exceeds the cache length")
     out = torch.empty((B, H * 128), dtype=BF16, device=q.device)
     rc = _lib.lib().libra_bridge_attn_decode(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_cross.data_ptr(), v_same.data_ptr(),
                                              v_cross.data_ptr(), k_same.stride(1), k_same.stride(0), key_flag.data_ptr(),

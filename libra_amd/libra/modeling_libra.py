@@ -250,7 +250,8 @@ class LibraForCausalLM(PreTrainedModel):
             cache = past
             if position_ids is None:                                                    # attention_mask.cumsum(-1) - 1, :1207
                 position_ids = torch.full((B, 1), cache.length, dtype=torch.long, device=dev)
-            out = DE.decode_step(sd, packed, dims, cache, input_ids, vision_indices, position_ids)
+            out = DE.decode_step(sd, packed, dims, cache, input_ids, vision_indices, position_ids,
+                                 use_graph=getattr(self, "decode_graphs", True))      # (False: launch the step kernel by kernel)
         logits = DE.dense_logits(out, dims, B, S)
         if past is not None:
             eoi = vision_indices[:, -1] == self.max_vision_token_length - 1
@@ -259,6 +260,54 @@ class LibraForCausalLM(PreTrainedModel):
                 forced[self.config.newline_token_id] = float("inf")
                 logits[:, eoi, -1, :] = forced
         return LibraCausalLMOutputWithPast(loss=None, logits=logits, past_key_values=cache, hidden_states=None, attentions=None)
+
+    # ---- generation glue (the reference's custom greedy_search / sample call these, modeling_libra_utils.py:61,:330) ----
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
+                                      vision_indices=None, contiguous_signal=None, past_hidden_states=None, past_vision_flag=None,
+                                      **kwargs):
+        """modeling_libra.py:1190-1231: with a cache only the last token, its position (attention_mask.cumsum - 1) and its
+        vision index are fed, and no encoder signal."""
+        if inputs_embeds is not None:
+            raise NotImplementedError("inputs_embeds: the embedding gather is part of the fused path")
+        if past_key_values:
+            input_ids = input_ids[:, :, -1:]
+        position_ids = kwargs.get("position_ids", None)
+        if attention_mask is not None and position_ids is None:
+            position_ids = attention_mask.long().cumsum(-1) - 1
+            position_ids.masked_fill_(attention_mask == 0, 1)
+            if past_key_values:
+                position_ids = position_ids[:, -1].unsqueeze(-1)
+        if past_key_values:
+            vision_indices = vision_indices[:, -1].unsqueeze(-1)
+            contiguous_signal = None
+        return {"input_ids": input_ids, "position_ids": position_ids, "past_key_values": past_key_values,
+                "use_cache": kwargs.get("use_cache"), "attention_mask": attention_mask, "vision_indices": vision_indices,
+                "contiguous_signal": contiguous_signal, "past_hidden_states": past_hidden_states,
+                "past_vision_flag": past_vision_flag}
+
+    def _update_model_kwargs_for_generation(self, outputs, model_kwargs, is_encoder_decoder: bool = False,
+                                            standardize_cache_format: bool = False):
+        """modeling_libra.py:1233-1282: carry the cache, grow the attention mask by one, and advance the vision index - inside
+        an image it counts up, after EOI (or in text) it stays at max_vision_token_length."""
+        model_kwargs["past_hidden_states"] = getattr(outputs, "past_hidden_states", None)
+        model_kwargs["past_vision_flag"] = getattr(outputs, "past_vision_flag", None)
+        model_kwargs["past_key_values"] = outputs.past_key_values
+        if "attention_mask" in model_kwargs:
+            am = model_kwargs["attention_mask"]
+            model_kwargs["attention_mask"] = torch.cat([am, am.new_ones((am.shape[0], 1))], dim=-1)
+        if "vision_indices" in model_kwargs:
+            vi = model_kwargs["vision_indices"]
+            nxt = (vi[:, -1].clone() + 1).clamp_(max=self.max_vision_token_length)
+            model_kwargs["vision_indices"] = torch.cat([vi, nxt[..., None]], dim=-1)
+        return model_kwargs
+
+    @staticmethod
+    def _reorder_cache(past_key_values, beam_idx):
+        """modeling_libra.py:1284-1289 for the KVCache container (beam search re-gathers the batch dimension)."""
+        past_key_values.layers = [tuple(t.index_select(0, beam_idx) for t in layer) for layer in past_key_values.layers]
+        past_key_values.flag = past_key_values.flag.index_select(0, beam_idx)
+        past_key_values.B = int(beam_idx.numel())
+        return past_key_values
 
     @staticmethod
     def materialize_logits(output) -> torch.Tensor:

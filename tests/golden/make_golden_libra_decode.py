@@ -88,6 +88,27 @@ def main():
             meta["cases"][name] = dict(prefill=P, length=S, incremental_vs_full_forward_max_abs=gap,
                                        eoi_forced_steps=forced.nonzero().flatten().tolist())
             print(name, "incremental vs full:", gap)
+    # generation glue (pure tensor logic): the reference's own prepare_inputs_for_generation /
+    # _update_model_kwargs_for_generation on a toy state - mid-image, at EOI and in text
+    import types
+    vi0 = torch.tensor([[L, 0, 1, 2], [L, L, L, L], [L, 3, 4, 5]])
+    am0 = torch.ones(3, 4, dtype=torch.long)
+    ids0 = torch.arange(2 * 3 * 4).reshape(2, 3, 4)
+    fake_out = types.SimpleNamespace(past_hidden_states=None, past_vision_flag=None, past_key_values=("cache",))
+    model._extract_past_from_model_output = lambda outputs, standardize_cache_format=False: outputs.past_key_values
+    kw = model._update_model_kwargs_for_generation(fake_out, {"attention_mask": am0.clone(), "vision_indices": vi0.clone()})
+    kw2 = model._update_model_kwargs_for_generation(fake_out, {"attention_mask": kw["attention_mask"], "vision_indices": kw["vision_indices"]})
+    prep = model.prepare_inputs_for_generation(torch.cat([ids0, ids0[:, :, -1:] + 1], -1), past_key_values=("cache",),
+                                               attention_mask=kw["attention_mask"], vision_indices=kw["vision_indices"],
+                                               contiguous_signal=torch.zeros(3, 5, 4), use_cache=True)
+    assert prep["contiguous_signal"] is None
+    prep0 = model.prepare_inputs_for_generation(ids0, past_key_values=None, attention_mask=am0, vision_indices=vi0, use_cache=True)
+    t.update({"glue.vision_indices0": vi0, "glue.attention_mask0": am0, "glue.input_ids0": ids0,
+              "glue.vision_indices1": kw["vision_indices"], "glue.attention_mask1": kw["attention_mask"],
+              "glue.vision_indices2": kw2["vision_indices"],
+              "glue.prep.input_ids": prep["input_ids"], "glue.prep.position_ids": prep["position_ids"],
+              "glue.prep.vision_indices": prep["vision_indices"], "glue.prep0.position_ids": prep0["position_ids"],
+              "glue.prep0.input_ids": prep0["input_ids"]})
     _save("libra_tiny_decode.safetensors", t, meta)
 
 

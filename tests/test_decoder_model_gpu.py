@@ -198,6 +198,16 @@ def test_libra_tiny_cached_decode_vs_reference_fixture():
                 steps.append(out.logits)
             assert past.get_seq_length() == S
             full = m(input_ids=ids, vision_indices=vi, contiguous_signal=sig)
+            # the same steps launched kernel by kernel (no hipGraph capture): bit-identical
+            m.decode_graphs = False
+            out2 = m(input_ids=ids[:, :, :P], vision_indices=vi[:, :P], contiguous_signal=sig[:, :P], use_cache=True)
+            steps2, past2 = [out2.logits], out2.past_key_values
+            for s in range(P, S):
+                out2 = m(input_ids=ids[:, :, s:s + 1], vision_indices=vi[:, s:s + 1], past_key_values=past2, use_cache=True)
+                steps2.append(out2.logits)
+            m.decode_graphs = True
+            a2, b2 = torch.cat(steps2, dim=2), torch.cat(steps, dim=2)
+            assert torch.equal(torch.nan_to_num(a2.float(), posinf=1e30, neginf=-1e30), torch.nan_to_num(b2.float(), posinf=1e30, neginf=-1e30)), name
         inc = torch.cat(steps, dim=2).float().cpu()
         ref = t[f"{name}.logits_incremental"]
         assert inc.shape == ref.shape

@@ -39,3 +39,31 @@ def test_freeze_policy_counts_match_reference():
     trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
     assert abs(trainable / 1e9 - 4.269) < 0.001, trainable
     assert all(("vision" in n) == p.requires_grad for n, p in m.named_parameters())
+
+
+def test_generation_glue_matches_reference():
+    """prepare_inputs_for_generation / _update_model_kwargs_for_generation (pure tensor logic) against outputs of the
+    reference's own methods on a toy state (mid-image, at EOI, in text), stored by make_golden_libra_decode.py."""
+    import types
+    import torch
+    from helpers import load_golden
+    from libra_amd.libra.modeling_libra import LibraForCausalLM
+    t, meta = load_golden("libra_tiny_decode.safetensors")
+    me = types.SimpleNamespace(max_vision_token_length=meta["cfg"]["max_vision_token_length"])
+    out = types.SimpleNamespace(past_hidden_states=None, past_vision_flag=None, past_key_values=("cache",))
+    kw = LibraForCausalLM._update_model_kwargs_for_generation(
+        me, out, {"attention_mask": t["glue.attention_mask0"].clone(), "vision_indices": t["glue.vision_indices0"].clone()})
+    assert torch.equal(kw["vision_indices"], t["glue.vision_indices1"]) and torch.equal(kw["attention_mask"], t["glue.attention_mask1"])
+    assert kw["past_key_values"] == ("cache",)
+    kw2 = LibraForCausalLM._update_model_kwargs_for_generation(me, out, dict(kw))
+    assert torch.equal(kw2["vision_indices"], t["glue.vision_indices2"])
+    ids0 = t["glue.input_ids0"]
+    prep = LibraForCausalLM.prepare_inputs_for_generation(
+        me, torch.cat([ids0, ids0[:, :, -1:] + 1], -1), past_key_values=("cache",), attention_mask=kw["attention_mask"],
+        vision_indices=kw["vision_indices"], contiguous_signal=torch.zeros(3, 5, 4), use_cache=True)
+    assert prep["contiguous_signal"] is None and prep["use_cache"] is True
+    for k in ("input_ids", "position_ids", "vision_indices"):
+        assert torch.equal(prep[k], t[f"glue.prep.{k}"]), k
+    prep0 = LibraForCausalLM.prepare_inputs_for_generation(me, ids0, past_key_values=None, attention_mask=t["glue.attention_mask0"],
+                                                           vision_indices=t["glue.vision_indices0"], use_cache=True)
+    assert torch.equal(prep0["position_ids"], t["glue.prep0.position_ids"]) and torch.equal(prep0["input_ids"], t["glue.prep0.input_ids"])
