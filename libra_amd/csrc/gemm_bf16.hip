@@ -333,6 +333,10 @@ extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int
 
 // Shared body of the plain / routed / grouped entry points.  `groups` problems of identical shape, strides and row maps;
 // A/B/C = group 0, Ag/Bg/Cg = groups 1.. (fused epilogue operands only with groups == 1).
+extern "C" int libra_gemm_skinny_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                         int64_t N, int64_t K, const void* resid, int64_t ldr, const int32_t* a_rows,
+                                         const int32_t* c_rows, void* stream);
+
 static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                     int64_t K, const void* bias, const void* resid, int64_t ldr, const void* aux, int64_t ldaux, void* preact,
                     int64_t ldpre, float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
@@ -360,6 +364,11 @@ static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void
         Ag[g] = Ag_in[g]; Bg[g] = Bg_in[g]; Cg[g] = Cg_in[g];
         if (!Ag[g] || !Bg[g] || !Cg[g] || (((uintptr_t)Ag[g] | (uintptr_t)Bg[g] | (uintptr_t)Cg[g]) & 15)) return LIBRA_ERR_ALIGN;
     }
+
+    // ---- M <= 16 (the generation step: one token per sequence): weights are read once, HBM-bound -> the skinny kernel ----
+    if (groups == 1 && M <= 16 && !at && !bt && (flags & ~LIBRA_GEMM_RESIDUAL) == 0 && alpha_cols == 0 && (K % 8) == 0)
+        return libra_gemm_skinny_launch_(A, lda, B, ldb, C, ldc, M, N, K, (flags & LIBRA_GEMM_RESIDUAL) ? resid : nullptr, ldr,
+                                         a_rows, c_rows, stream);
 
     // ---- leading rows on the 256^2 kernel, the rest (if any) on the 128^2 kernel below ----
     const int64_t rows256 = plan_rows256(M, N, K, groups);

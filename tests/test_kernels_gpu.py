@@ -326,3 +326,27 @@ def test_gemm_splitk_skinny(K, M, N, K_):
     close(out, a.float().t() @ b.float(), rel=2e-3, what=f"skinny split-K {M}x{N}x{K_}")
     out2 = K.gemm_nt(a, b, a_t=True, b_t=True)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("M,N,K_", [(1, 8, 64), (3, 200, 256), (8, 4096, 4096), (8, 1024, 11008), (16, 520, 3136), (13, 64, 512)])
+def test_gemm_skinny_rows(K, M, N, K_):
+    """M <= 16 (the generation step) goes to the skinny HBM-bound kernel: plain, residual, row gather / scatter."""
+    a, b = rnd(M, K_, seed=41, scale=0.5), rnd(N, K_, seed=42, scale=0.1)
+    base = a.float() @ b.float().t()
+    close(K.gemm_nt(a, b), base, what="skinny plain")
+    res = rnd(M, N, seed=43)
+    close(K.gemm_nt(a, b, resid=res), base + res.float(), what="skinny resid")
+    # routed: A rows gathered from a taller buffer, C rows scattered into a taller buffer whose other rows stay untouched
+    phys = M + 5
+    rows = torch.randperm(phys, generator=torch.Generator().manual_seed(7))[:M].to(torch.int32).cuda()
+    abig, rbig = rnd(phys, K_, seed=44, scale=0.5), rnd(phys, N, seed=45)
+    cbig = torch.full((phys, N), 3.0, dtype=BF, device="cuda")
+    K.gemm_nt(abig, b, out=cbig, a_rows=rows, c_rows=rows, resid=rbig)
+    ref = abig[rows.long()].float() @ b.float().t() + rbig[rows.long()].float()
+    close(cbig[rows.long()], ref, what="skinny routed")
+    untouched = torch.ones(phys, dtype=torch.bool, device="cuda"); untouched[rows.long()] = False
+    assert torch.equal(cbig[untouched], torch.full((phys - M, N), 3.0, dtype=BF, device="cuda"))
+    # and it agrees with the tiled kernels on the same problem (M = 17 rows takes the MFMA path; compare the shared rows)
+    if M == 16:
+        a17 = torch.cat([a, rnd(1, K_, seed=46)], 0)
+        close(K.gemm_nt(a, b), K.gemm_nt(a17, b)[:16].float(), what="skinny vs tiled")
