@@ -42,6 +42,25 @@ def test_row_kernels_argument_validation(L):
     assert L.libra_rope_bridge_bwd(*args2, 32, None) == ERR_ALIGN
 
 
+def test_generation_entry_points_argument_validation(L):
+    # rope with explicit positions: the position operand is mandatory
+    args = [FAKE, 3 * 256, FAKE, 64, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, 64, FAKE, FAKE, 256, 4]
+    assert L.libra_rope_bridge_pos(*args, None, 2, None) == ERR_ALIGN
+    # decode attention: cache row stride shorter than H*128, batch stride shorter than a row, null cache
+    ok = dict(q=FAKE, ldq=256, ks=FAKE, kc=FAKE, vs=FAKE, vc=FAKE, ldc=256, bs=256 * 64, kf=FAKE, fs=64, qf=FAKE, kl=FAKE, out=FAKE,
+              ldo=256, B=2, H=2)
+
+    def call(**kw):
+        a = dict(ok, **kw)
+        return L.libra_bridge_attn_decode(a["q"], a["ldq"], a["ks"], a["kc"], a["vs"], a["vc"], a["ldc"], a["bs"], a["kf"], a["fs"],
+                                          a["qf"], a["kl"], a["out"], a["ldo"], a["B"], a["H"], 128 ** -0.5, None)
+    assert call(ldc=128) == ERR_SHAPE
+    assert call(bs=64) == ERR_SHAPE
+    assert call(kc=None) == ERR_ALIGN
+    assert call(ks=P(0x10008)) == ERR_ALIGN
+    assert call(B=0) == OK
+
+
 def test_splitk_plan_for_the_baseline_shapes(L):
     # weight gradients of the ViT step (reduction over 32 x 577 tokens, padded to 18496): few tiles, long K -> sliced
     for M, N in [(1024, 4096), (4096, 1024), (3072, 1024), (1024, 1024)]:
