@@ -165,6 +165,7 @@ class KVCache:
         self.layers = [tuple(torch.empty((B, capacity, H), dtype=BF16, device=device) for _ in range(4)) for _ in range(layers)]
         self.flag = torch.zeros((B, capacity), dtype=torch.uint8, device=device)
         self.graphs: Dict[tuple, tuple] = {}               # routing pattern of a decode step -> (hipGraph, static buffers, outputs)
+        self.pack_key = None                               # version of the packed weights the graphs were captured against
 
     def get_seq_length(self) -> int:
         return self.length

@@ -239,6 +239,7 @@ class LibraForCausalLM(PreTrainedModel):
             if position_ids is not None and not torch.equal(position_ids.reshape(B, S).to(dev), torch.arange(S, device=dev).expand(B, S)):
                 raise NotImplementedError("prefill positions other than arange(S)")
             cache = DE.KVCache(dims.layers, B, max(dims.max_pos, S), dims.hidden, dev)
+            cache.pack_key = self._pack_key
             out = DE.forward(sd, packed, dims, input_ids, attention_mask, vision_indices, signal, None, cache=cache)
         else:
             if not isinstance(past, DE.KVCache):
@@ -248,6 +249,9 @@ class LibraForCausalLM(PreTrainedModel):
             if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
                 raise NotImplementedError("cached generation handles unpadded sequences only")
             cache = past
+            if getattr(cache, "pack_key", None) != self._pack_key:      # parameters changed since the graphs were captured:
+                cache.graphs.clear()                                     # they hold the old packed operands' addresses
+                cache.pack_key = self._pack_key
             if position_ids is None:                                                    # attention_mask.cumsum(-1) - 1, :1207
                 position_ids = torch.full((B, 1), cache.length, dtype=torch.long, device=dev)
             out = DE.decode_step(sd, packed, dims, cache, input_ids, vision_indices, position_ids,
@@ -307,6 +311,7 @@ class LibraForCausalLM(PreTrainedModel):
         past_key_values.layers = [tuple(t.index_select(0, beam_idx) for t in layer) for layer in past_key_values.layers]
         past_key_values.flag = past_key_values.flag.index_select(0, beam_idx)
         past_key_values.B = int(beam_idx.numel())
+        past_key_values.graphs.clear()                                   # captured steps point at the buffers just replaced
         return past_key_values
 
     @staticmethod
