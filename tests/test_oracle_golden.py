@@ -74,3 +74,20 @@ def test_vq_encode_matches_reference(E):
     assert list(quant.shape[2:]) == meta["image_size"]
     # bits: MSB-first packing, range
     assert int(idx.min()) >= 0 and int(idx.max()) < 512
+
+
+def test_vq_image_decoder_matches_reference():
+    """§8f-2 groundwork: token ids -> LFQ codes -> post_quant_conv -> taming Decoder against the reference's own
+    ImageTokenizer.decode / VQModel.decode_code run (codes bit-exact; z and image to fp32 round-off)."""
+    from oracle import vq_decode_oracle as VD
+    t, meta = load_golden("vq_decode_tiny.safetensors")
+    sd = sub(t, "w.")
+    dd = meta["dd"]
+    idx = VD.token_ids_to_indices(t["in.token_ids"], offset=meta["offset"], boi_token_id=meta["boi"])
+    assert torch.equal(idx, t["in.indices"])
+    codes, z, img = VD.decode_code(sd, idx, codebook_size=meta["codebook_size"], ch_mult=dd["ch_mult"],
+                                   num_res_blocks=dd["num_res_blocks"], resolution=dd["resolution"])
+    assert rel_err(codes, t["out.codes"]) < 1e-6
+    assert rel_err(z, t["out.z"]) < 2e-6
+    assert img.shape == t["out.image"].shape
+    assert rel_err(img, t["out.image"]) < 2e-5
