@@ -67,3 +67,27 @@ def test_generation_glue_matches_reference():
     prep0 = LibraForCausalLM.prepare_inputs_for_generation(me, ids0, past_key_values=None, attention_mask=t["glue.attention_mask0"],
                                                            vision_indices=t["glue.vision_indices0"], use_cache=True)
     assert torch.equal(prep0["position_ids"], t["glue.prep0.position_ids"]) and torch.equal(prep0["input_ids"], t["glue.prep0.input_ids"])
+
+
+def test_kv_cache_container_and_reorder():
+    """KVCache bookkeeping that needs no GPU: buffer shapes, beam re-ordering of every buffer (modeling_libra.py:1284-1289) and
+    that captured decode graphs are dropped when the buffers they point at are replaced."""
+    import torch
+    from libra_amd import decoder_engine as DE
+    from libra_amd.libra.modeling_libra import LibraForCausalLM
+    c = DE.KVCache(layers=3, B=4, capacity=10, H=256, device="cpu")
+    assert len(c.layers) == 3 and all(len(l) == 4 and l[0].shape == (4, 10, 256) for l in c.layers)
+    assert c.flag.shape == (4, 10) and c.flag.dtype == torch.uint8 and c.get_seq_length() == 0
+    for li, layer in enumerate(c.layers):
+        for bi, buf in enumerate(layer):
+            buf.copy_(torch.arange(4, dtype=torch.float32)[:, None, None].expand(4, 10, 256) + 10 * li + 100 * bi)
+    c.flag.copy_(torch.arange(4, dtype=torch.uint8)[:, None].expand(4, 10))
+    c.length = 7
+    c.graphs[(False, True, False, False)] = ("graph", {}, {})
+    beam = torch.tensor([2, 2, 0, 3])
+    out = LibraForCausalLM._reorder_cache(c, beam)
+    assert out is c and c.graphs == {} and c.B == 4 and c.get_seq_length() == 7
+    for li, layer in enumerate(c.layers):
+        for bi, buf in enumerate(layer):
+            assert torch.equal(buf[:, 0, 0].float(), beam.float() + 10 * li + 100 * bi)
+    assert torch.equal(c.flag[:, 0], beam.to(torch.uint8))
