@@ -80,7 +80,7 @@ def test_kv_cache_container_and_reorder():
     assert c.flag.shape == (4, 10) and c.flag.dtype == torch.uint8 and c.get_seq_length() == 0
     for li, layer in enumerate(c.layers):
         for bi, buf in enumerate(layer):
-            buf.copy_(torch.arange(4, dtype=torch.float32)[:, None, None].expand(4, 10, 256) + 10 * li + 100 * bi)
+            buf.copy_(torch.arange(4, dtype=torch.float32)[:, None, None].expand(4, 10, 256) + 8 * li + 32 * bi)
     c.flag.copy_(torch.arange(4, dtype=torch.uint8)[:, None].expand(4, 10))
     c.length = 7
     c.graphs[(False, True, False, False)] = ("graph", {}, {})
@@ -89,5 +89,5 @@ def test_kv_cache_container_and_reorder():
     assert out is c and c.graphs == {} and c.B == 4 and c.get_seq_length() == 7
     for li, layer in enumerate(c.layers):
         for bi, buf in enumerate(layer):
-            assert torch.equal(buf[:, 0, 0].float(), beam.float() + 10 * li + 100 * bi)
+            assert torch.equal(buf[:, 0, 0].float(), beam.float() + 8 * li + 32 * bi)
     assert torch.equal(c.flag[:, 0], beam.to(torch.uint8))
