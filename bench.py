@@ -1,16 +1,21 @@
 #!/usr/bin/env python
-"""bench.py — images/sec of Libra's vision hot path on MI355X (BASELINE.json configs[1]).
+"""bench.py — images/sec of Libra's vision-to-LLM hot path on MI355X (BASELINE.json metric:
+"images/sec/GPU fwd+bwd (ViT+bridge, 336px, seq2048)").
 
-A "step" = one pass of the hot path over one synthetic batch resident in HBM:
-    ViT-L/14@336 forward (all 24 layers, 25 hidden states)  ->  feature select [-2,-3]
-    -> VQ encode (quant_conv GEMM + LFQ sign/pack -> token ids)
-    -> backward of a fixed cotangent on the 2048-d feature through the ViT (dgrad + wgrad of every
-       parameter that feeds it; bf16 grads), + RCCL gradient all-reduce when N > 1 (data parallel, weak scaling)
-bs = 32 images / GPU, bf16, random-init weights, synthetic N(0,1) pixels.
+HEADLINE (default, `--workload bridge`, BASELINE configs[2] shapes): one step =
+    CLIP ViT-L/14@336 forward + VQ encode (no grad: the reference freezes both, clip_encoder.py:53, image_tokenizer.py:70)
+    -> LibraTokenizer tensor assembly + get_labels
+    -> Libra-11B routed-bridge decoder forward + backward (32 layers, LLaMA-2-7B text stream frozen = the reference's
+       pretraining recipe, 4.27 B trainable "vision" parameters; loss = the dual-head CE)
+    [-> fused AdamW with --with-optimizer]  [+ RCCL gradient exchange overlapped with backward when N > 1]
+bs = 8 image-sequences / GPU (one 336 px image + 1 470 text tokens per 2 048-token sequence), bf16, random-init weights,
+synthetic inputs resident in HBM.  value = image-sequences / s, whole job.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the bf16 MFMA GEMM, per-launch
-times from events on the launch stream in a separate instrumented step) and "cpu_baseline" (the CPU oracle
-timed on this box's host cores, N=1 only).
+SECOND LEG (`--workload vit`, BASELINE configs[1]; at N=1 it also runs after the headline and is reported under "extra"):
+    ViT-L/14@336 forward -> feature select [-2,-3] -> VQ encode -> backward of a fixed feature cotangent through the ViT, bs 32.
+
+One JSON line on rank 0 with "roofline" (dominant kernel family = the bf16 MFMA GEMM; per-launch HIP-event times on the
+launch stream in one extra instrumented step) and "cpu_baseline" (the CPU oracle on this box's host cores, N=1 only).
 """
 import argparse
 import json
@@ -29,9 +34,10 @@ VIT_L = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num
 GFLOP_FWD_PER_IMG = 381.9
 GFLOP_LAYER = 15.884               # one encoder layer forward
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+METRIC = "images/sec/GPU fwd+bwd (ViT+bridge, 336px, seq2048) at 1/2/4/8 MI355X"
 
 
-def build(device, batch, embed_dim=512):
+def build_vit(device, batch, embed_dim=512):
     from transformers import CLIPVisionConfig
     from libra_amd.clip import CLIPVisionModel
     from libra_amd.libra import ImageTokenizer
@@ -51,52 +57,68 @@ def build(device, batch, embed_dim=512):
         tok.model.quant_conv.weight.normal_(0, 2048 ** -0.5, generator=None)
         tok.model.quant_conv.bias.normal_(0, 0.05)
     tok = tok.to(torch.bfloat16).to(device)
-    # fwd/bwd config: the ViT's parameters take gradients (extension over the reference)
-    clip.requires_grad_(True)
-    tok.model.encoder.allow_grad = True
     g = torch.Generator().manual_seed(42)
     pixel = torch.randn(batch, 3, 336, 336, generator=g).to(torch.bfloat16).to(device)
     cot = torch.randn(batch, 576, 2048, generator=g).to(torch.bfloat16).to(device)
     return clip, tok, pixel, cot
 
 
-def make_step(clip, tok, pixel, cot, world):
-    from libra_amd.dp import BucketedGradReducer
+class Workload:
+    """step() runs one step; `buckets` (dp.GradBuckets or None) and `exchange` toggle the data-parallel exchange."""
+    buckets = None
+    opt = None
+    exchange = True
+
+
+def make_vit(device, batch, world, mode):
+    """configs[1]: the ViT's parameters take gradients (extension over the reference)."""
+    from libra_amd import dp, vit_engine
+    clip, tok, pixel, cot = build_vit(device, batch)
+    clip.requires_grad_(True)
+    tok.model.encoder.allow_grad = True
     named = list(clip.named_parameters())
+    w = Workload()
+    if world > 1:
+        L = VIT_L["num_hidden_layers"]
+        w.buckets = dp.GradBuckets(named, bucket_bytes=48 << 20, group_fn=lambda n: vit_engine.emit_group(n, L), mode=mode)
 
     def step():
         for _, p in named:
             p.grad = None
         feat, h2d, idx, ids, _, _ = tok.model.encode_flat(pixel, offset=32000, boi=32512, eoi=32513, want_ids=True,
                                                          want_quant=False)
-        if world > 1:
-            # each layer's gradients enter their RCCL all-reduce while the layers below are still in backward
-            red = BucketedGradReducer(bucket_bytes=48 << 20)
-            with red.capture():
+        if w.buckets is not None and w.exchange:
+            # each layer's gradients enter their RCCL exchange while the layers below are still in backward
+            with w.buckets.capture():
                 feat.backward(cot)
-            red.finish_into(named)
+            w.buckets.finish_into(named)
         else:
             feat.backward(cot)
         return ids
-    return step
+    w.step = step
+    return w
 
 
-def build_libra(device, batch, seq=2048, world=1):
-    """BASELINE configs[2]/[3] shape: the reference's real pretraining step — frozen CLIP ViT + VQ encode under no_grad
-    (clip_encoder.py:53, image_tokenizer.py:70) -> tensor assembly -> Libra-11B routed decoder fwd+bwd with the language
-    stream frozen (modeling_libra.py:1342-1346: 4.27 B trainable "vision" parameters)."""
+def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recompute=False, accum=1):
+    """configs[2]/[3]: the reference's real pretraining step (see module docstring)."""
+    from libra_amd import decoder_engine as DE
+    from libra_amd import dp
     from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy, assemble_inputs, get_labels
-    clip, tok, pixel, _ = build(device, batch)
+    clip, tok, pixel, _ = build_vit(device, batch)
     clip.requires_grad_(False)
     tok.model.encoder.allow_grad = False
+    cfg = LibraConfig(max_position_embeddings=max(2048, seq))
     with torch.device(device):
-        dec = LibraForCausalLM(LibraConfig())
+        dec = LibraForCausalLM(cfg)
     dec = dec.to(torch.bfloat16)
     with torch.no_grad():
         for n, p in dec.named_parameters():
             if "bridge" in n and n.endswith("weight_B"):
                 p.normal_(0, 0.02)             # zero-initialised upstream; make the bridge path numerically live
     apply_freeze_policy(dec, frozen_language=True)
+    dec.train()
+    if recompute:
+        dec.gradient_checkpointing_enable()
     V, L = 32000, 578
     PH = V - 1
     g = torch.Generator().manual_seed(42)
@@ -106,125 +128,147 @@ def build_libra(device, batch, seq=2048, world=1):
     text = text.to(device)
     am = torch.ones(batch, seq, dtype=torch.long, device=device)
     spans = [[(1 + L, 2 + L)] for _ in range(batch)]
-    from libra_amd.dp import BucketedGradReducer
-    named = [(n, p) for n, p in dec.named_parameters() if p.requires_grad]
+    named = [(n, p) for n, p in dec.named_parameters() if p.requires_grad and n != "vision_hidden_placeholder"]
     params = [p for _, p in named]
-    trainable = {n for n, _ in named}
+    w = Workload()
+    if world > 1 or with_optimizer:
+        # 8.5 GB of bf16 gradients per step: one decoder layer's ~267 MB per bucket goes out while the layers below are in backward
+        nl = cfg.num_hidden_layers
+        w.buckets = dp.GradBuckets(named, bucket_bytes=256 << 20, group_fn=lambda n: DE.emit_group(n, nl), mode=mode)
+    if with_optimizer:
+        w.opt = dp.FlatAdamW(w.buckets, named, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)   # libra_pretrain.yaml:83-91
 
     def step():
-        for p in params:
-            p.grad = None
-        with torch.no_grad():
-            img = tok.encode(pixel)
-        inp = assemble_inputs(text, am, img, img_ph_token_id=PH, img_gen_token_id=V - 2, boi_token_id=tok.boi_token_id,
-                              num_codebook=2, max_vision_token_length=L)
-        labels = get_labels(inp, spans, boi_token_id=tok.boi_token_id, bos_token_id=1)
-        out = dec(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], vision_indices=inp["vision_indices"],
-                  contiguous_signal=inp["coninous_signal"], labels=labels)
-        if world > 1:
-            # 8.5 GB of bf16 gradients per step: each decoder layer's ~267 MB goes out while the layers below are in backward
-            red = BucketedGradReducer(bucket_bytes=256 << 20, only=trainable)
-            with red.capture():
-                out.loss.backward()
-            red.finish_into(named)
-        else:
-            out.loss.backward()
-        return out.loss.detach()
-    return step, params
+        loss = None
+        for k in range(accum):
+            if w.buckets is None:
+                for p in params:
+                    p.grad = None
+            with torch.no_grad():
+                img = tok.encode(pixel)
+            inp = assemble_inputs(text, am, img, img_ph_token_id=PH, img_gen_token_id=V - 2, boi_token_id=tok.boi_token_id,
+                                  num_codebook=2, max_vision_token_length=L)
+            labels = get_labels(inp, spans, boi_token_id=tok.boi_token_id, bos_token_id=1)
+            out = dec(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], vision_indices=inp["vision_indices"],
+                      contiguous_signal=inp["coninous_signal"], labels=labels)
+            loss = out.loss / accum if accum > 1 else out.loss
+            if w.buckets is not None and (w.exchange or w.opt is not None):
+                with w.buckets.capture(sync=(k == accum - 1)):
+                    loss.backward()
+                w.buckets.finish_into(named)
+            else:
+                loss.backward()
+        if w.opt is not None:
+            w.opt.step()
+        return loss.detach()
+    w.step = step
+    w.model = dec
+    return w
 
 
-def cpu_baseline(sample_iters=3):
-    """The CPU oracle (oracle/vit_oracle.py, proven equal to the reference's modules on the golden fixtures) timed on
-    this box's host cores: ViT-L/14@336 fwd+bwd, B=1, fp32."""
+def _threads(n):
+    torch.set_num_threads(max(1, n))
+    return torch.get_num_threads()
+
+
+def _median_time(fn, warm, iters):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(seq=2048, budget_s=60.0, workload="bridge"):
+    """the CPU oracle (oracle/*.py, proven equal to the reference's modules on the golden fixtures) on ALL
+    host cores of this box, same seeded synthetic inputs:
+      (i)  config 1 exactly - ViT-L/14@336 forward, bs 1, fp32 and bf16, median of >=5 iterations after 2 warm-ups;
+      (ii) one full-width routed decoder layer forward+backward at B=1, S=seq (578 vision tokens), fp32, x32 layers
+           (a full 11 B fwd+bwd does not fit a sensible CPU time budget).
+    value = image-sequences/s of the headline workload = 1 / (ViT fwd + 32 x layer fwd+bwd)."""
+    from oracle import libra_oracle as LO
     from oracle import vit_oracle as VO
     try:
         n = len(os.sched_getaffinity(0))          # cores this container may actually use
     except AttributeError:
         n = os.cpu_count() or 1
-    n = max(1, min(n, 64))                        # torch CPU GEMMs stop scaling (and oversubscribe) beyond this
-    torch.set_num_threads(n)
+    n = _threads(n)
+    t_start = time.perf_counter()
     sd = VO.random_vit_state_dict(hidden=1024, inter=4096, layers=24, patch=14, image=336, seed=42)
-    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
     g = torch.Generator().manual_seed(42)
     x = torch.randn(1, 3, 336, 336, generator=g)
-    ct = torch.randn(1, 576, 2048, generator=g)
 
-    def one():
-        for v in sd.values():
+    def vit(sd_, x_):
+        with torch.no_grad():
+            hs = VO.vit_hidden_states(sd_, x_, patch=14, heads=16, layers=24)
+            return VO.feature_select(hs, [-2, -3], square=False)
+    t_vit32 = _median_time(lambda: vit(sd, x), 2, 5)
+    sdb = VO.cast_sd(sd, torch.bfloat16)
+    xb = x.to(torch.bfloat16)
+    t_vit16 = _median_time(lambda: vit(sdb, xb), 2, 5)
+    del sdb
+    # (ii) decoder layer fwd+bwd, full width
+    H, heads, L = 4096, 32, 578
+    lsd = {k: v.float().requires_grad_(True) for k, v in LO.random_layer_state_dict(seed=5).items()}
+    xs = torch.randn(1, seq, H, generator=g)
+    vi = torch.full((1, seq), L, dtype=torch.long)
+    vi[0, 1:1 + L] = torch.arange(L)
+    flag = vi < L
+    am = torch.ones(1, seq, dtype=torch.long)
+    mask = LO.additive_mask(am, seq, torch.float32)
+    pos = torch.arange(seq).unsqueeze(0)
+    cos, sin = LO.rope_tables(128, max(2048, seq))
+    ct = torch.randn(1, seq, H, generator=g)
+
+    def layer():
+        for v in lsd.values():
             v.grad = None
-        hs = VO.vit_hidden_states(sd, x, patch=14, heads=16, layers=24)
-        f = VO.feature_select(hs, [-2, -3], square=False)
-        (f * ct).sum().backward()
+        xin = xs.clone().requires_grad_(True)
+        y = LO.decoder_layer(lsd, 0, xin, flag, mask, pos, heads, 1e-6, cos, sin)
+        (y * ct).sum().backward()
     t0 = time.perf_counter()
-    one()                                          # warm-up (also sizes the sample)
-    warm = time.perf_counter() - t0
-    iters = max(1, min(sample_iters, int(20.0 / max(warm, 1e-3))))     # ~20 s of CPU work
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
+    layer()
+    first = time.perf_counter() - t0
+    left = budget_s - (time.perf_counter() - t_start)
+    iters = 5 if first * 6 < left else max(1, int(left / max(first, 1e-3)) - 1)
+    t_layer = _median_time(layer, 1, iters)
+    per_seq = t_vit32 + 32 * t_layer
+    if workload == "vit":
+        per_seq = t_vit32                  # config 1 itself (forward only: the CPU leg BASELINE.md §3 defines for the ViT)
+    return {"value": round(1.0 / per_seq, 5), "unit": "images/s", "cores": n, "kind": "port",
             "host_cpus": os.cpu_count(),
-            "sample": f"ViT-L/14@336 fwd+bwd (feature cotangent), B=1, fp32, {iters} timed iters after 1 warm-up "
-                      f"({warm:.1f} s)"}
+            "vit_fwd_bs1_images_per_s": {"fp32": round(1.0 / t_vit32, 3), "bf16": round(1.0 / t_vit16, 3)},
+            "decoder_layer_fwd_bwd_s": round(t_layer, 3),
+            "sample": f"config 1 exactly (ViT-L/14@336 fwd, bs 1, fp32 + bf16, median of 5 after 2 warm-ups) + ONE full-width "
+                      f"routed decoder layer fwd+bwd at B=1, S={seq}, 578 vision tokens, fp32 (median of {iters} after 2 "
+                      f"warm-ups incl. the sizing run) x 32 layers; {n} threads"}
 
 
 def hbm_traffic(workload):
     """Mean HBM bytes per GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/); None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{workload}.json")
-    try:
-        with open(path) as f:
-            return round(json.load(f)["gemm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{workload}.json")
+        try:
+            with open(path) as f:
+                return round(json.load(f)["gemm_bytes_per_launch"]), os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--workload", choices=["vit", "libra"], default="vit",
-                    help="vit = BASELINE configs[1] (headline line); libra = full pretraining step, ViT+VQ (no grad) -> "
-                         "Libra-11B routed decoder fwd+bwd, bs 8, seq 2048")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", 0))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL over xGMI.  (LIBRA_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box.)
-        backend = os.environ.get("LIBRA_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
-
-    if args.batch is None:
-        args.batch = 32 if args.workload == "vit" else 8
-    if args.workload == "vit":
-        clip, tok, pixel, cot = build(device, args.batch)
-        step = make_step(clip, tok, pixel, cot, world)
-    else:
-        step, _ = build_libra(device, args.batch, world=world)
-
-    def note(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
-    note(f"built model; world={world} batch={args.batch}")
-    for _ in range(args.warmup):
-        step()
+def timed(w, steps, warmup, world, device):
+    for _ in range(warmup):
+        w.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        w.step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -234,51 +278,186 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt
 
-    ms = dt / args.steps * 1e3
-    ips = args.batch * world * args.steps / dt
-    note(f"timed {args.steps} steps: {ms:.2f} ms/step, {ips:.1f} images/s")
 
-    # ---- roofline leg: one instrumented step, HIP events around every GEMM launch on the launch stream (the whole step
-    # runs on one stream, so a bracket contains exactly its own launch) ----
+def roofline(w, workload, ips_per_gpu, gflop_step_img):
+    """One instrumented step: HIP events around every GEMM launch on the launch stream (the whole step runs on one stream,
+    so a bracket contains exactly its own launch)."""
     from libra_amd import kernels as K
     with K.LaunchProfile() as prof:
-        step()
+        w.step()
     recs = prof.finish()
-    gem = [(w[0], t) for k, w, t in recs if k == "gemm"]
-    gbytes = sum(w[1] for k, w, t in recs if k == "gemm") / max(len(gem), 1)
-    gflop = sum(w for w, _ in gem) / 1e9
+    gem = [(wk[0], t) for k, wk, t in recs if k == "gemm"]
+    gbytes = sum(wk[1] for k, wk, t in recs if k == "gemm") / max(len(gem), 1)
+    gflop = sum(f for f, _ in gem) / 1e9
     gms = sum(t for _, t in gem)
     achieved = gflop / gms if gms > 0 else 0.0        # GFLOP/ms == TFLOP/s
-    if args.workload == "vit":
-        gflop_step_img = GFLOP_FWD_PER_IMG + 2 * (GFLOP_FWD_PER_IMG - GFLOP_LAYER)   # bwd skips the unused last layer
-    else:
-        # ViT fwd + decoder fwd (25.44 T) + decoder bwd: dgrad everywhere, wgrad for the vision weights, attention bwd 2.5x
-        dec_bwd = 32 * (595.0 + 153.34 + 2.5 * 34.4 + 153.34) + 385.0 + 2 * 4.8
-        gflop_step_img = GFLOP_FWD_PER_IMG + 25440.0 + dec_bwd
-    roof = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(args.workload),
-            "traffic_unit": "HBM bytes / launch (PMC, profiles/)", "algorithmic_bytes_per_launch": round(gbytes),
+    traffic, src = hbm_traffic("libra" if workload == "bridge" else "vit")
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (256x256x64 tiles; + gemm_bf16_nt_kernel 128x128 tail rows, "
+                                       "split-K wgrad slabs): every launch made through libra_gemm_bf16_nt*",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": f"HBM bytes / launch (PMC, profiles/{src})" if src else None,
+            "algorithmic_bytes_per_launch": round(gbytes),
             "timing": "HIP events on the launch stream around every GEMM launch of one extra step",
-            "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1),
-            "gemm_ms_per_step": round(gms, 2),
-            "whole_step_frac": round(ips / world * gflop_step_img / 1e3 / PEAK_BF16_TFLOPS, 4)}
+            "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1), "gemm_ms_per_step": round(gms, 2),
+            "gemm_gflop_per_step": round(gflop, 1),
+            "whole_step_frac": round(ips_per_gpu * gflop_step_img / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
-    out = {"metric": "images/sec/GPU fwd+bwd (ViT+bridge, 336px, seq2048) at 1/2/4/8 MI355X", "value": round(ips, 2),
-           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+
+def gflop_per_image(workload, seq=2048):
+    if workload == "vit":
+        return GFLOP_FWD_PER_IMG + 2 * (GFLOP_FWD_PER_IMG - GFLOP_LAYER)   # bwd skips the unused last layer
+    # ViT fwd + decoder fwd (25.44 T at S=2048) + decoder bwd: dgrad everywhere, wgrad for the vision weights only (frozen
+    # language), attention bwd 2.5x.  Per layer (SURVEY §8d formulas, Nv = 578):
+    H, I, r, rg, Nv, V = 4096, 11008, 1024, 2752, 578, 32000
+    Nl = seq - Nv
+    text = 8 * Nl * H * H + 6 * Nl * H * I
+    vis = 16 * Nv * H * r + 4 * Nv * (H * rg + rg * I) + 2 * Nv * (I * r + r * H)
+    bridge = 8 * seq * H * 8
+    attn = 2 * seq * seq * H
+    heads = 2 * Nl * H * V + 4 * Nv * H * 514
+    fwd = 32 * (text + vis + bridge + attn) + heads
+    bwd = 32 * (text + 2 * vis + 2 * bridge + 2.5 * attn) + 2 * Nl * H * V + 2 * 4 * Nv * H * 514
+    return GFLOP_FWD_PER_IMG + (fwd + bwd) / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--workload", choices=["bridge", "vit", "libra"], default="bridge",
+                    help="bridge (= libra) = the headline, BASELINE configs[2]: ViT+VQ (no grad) -> Libra-11B routed decoder "
+                         "fwd+bwd, bs 8, seq 2048; vit = configs[1]: ViT+VQ fwd/bwd bs 32")
+    ap.add_argument("--with-optimizer", action="store_true", help="include the fused AdamW update in the step (configs[3])")
+    ap.add_argument("--recompute", action="store_true", help="gradient checkpointing per decoder layer (the recipes' setting)")
+    ap.add_argument("--accum", type=int, default=1, help="gradient-accumulation micro-steps per step")
+    ap.add_argument("--exchange", choices=["auto", "allreduce", "rs_ag", "zero1"], default="auto",
+                    help="N>1 gradient exchange; auto = probe allreduce and rs_ag during warm-up and keep the faster")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ViT leg, optimizer leg) at N=1")
+    args = ap.parse_args()
+    if args.workload == "libra":
+        args.workload = "bridge"
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    backend = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL over xGMI.  (LIBRA_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box.)
+        backend = os.environ.get("LIBRA_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    if args.batch is None:
+        args.batch = 32 if args.workload == "vit" else 8
+    mode = "allreduce" if args.exchange == "auto" else args.exchange
+    if args.with_optimizer and args.exchange == "auto" and world > 1:
+        mode = "zero1"                       # sharded optimizer state: the exchange IS reduce-scatter + parameter all-gather
+
+    def make(mode_):
+        if args.workload == "vit":
+            return make_vit(device, args.batch, world, mode_)
+        return make_bridge(device, args.batch, args.seq, world, mode_, with_optimizer=args.with_optimizer,
+                           recompute=args.recompute, accum=args.accum)
+    w = make(mode)
+    note(f"built {args.workload}; world={world} batch={args.batch} exchange={mode if world > 1 else None}")
+
+    extra = {}
+    if world > 1 and args.exchange == "auto" and not args.with_optimizer:
+        # probe both exchange algorithms on this node (xGMI full mesh: direct reduce-scatter + all-gather vs whatever RCCL's
+        # all-reduce picks) and keep the faster for the timed region; both numbers are reported
+        probe = {}
+        for m in ("allreduce", "rs_ag"):
+            w.buckets.mode = m
+            probe[m] = timed(w, 2, 1, world, device) / 2 * 1e3
+        mode = min(probe, key=probe.get)
+        w.buckets.mode = mode
+        extra["exchange_probe_ms_per_step"] = {k: round(v, 2) for k, v in probe.items()}
+        note(f"exchange probe {extra['exchange_probe_ms_per_step']} -> {mode}")
+
+    dt = timed(w, args.steps, args.warmup, world, device)
+    ms = dt / args.steps * 1e3
+    ips = args.batch * args.accum * world * args.steps / dt
+    note(f"timed {args.steps} steps: {ms:.2f} ms/step, {ips:.2f} images/s")
+
+    if world > 1:
+        # exposed communication = step time with the exchange minus step time without it (same process, same buffers)
+        w.exchange = False
+        dt0 = timed(w, max(2, args.steps // 2), 1, world, device)
+        w.exchange = True
+        ms0 = dt0 / max(2, args.steps // 2) * 1e3
+        extra.update(exchange=mode, backend=backend, dist_world_size=dist.get_world_size(),
+                     ms_per_step_without_exchange=round(ms0, 3), exposed_comm_ms=round(ms - ms0, 3),
+                     exchanged_bytes_per_step=int(w.buckets.bytes_exchanged // max(w.buckets.launches, 1)
+                                                  * len(w.buckets.buckets)),
+                     grad_bucket_bytes=w.buckets.total_bytes, buckets=len(w.buckets.buckets))
+
+    gpi = gflop_per_image(args.workload, args.seq)
+    roof = roofline(w, args.workload, ips / world, gpi)
+    names = {"bridge": f"configs[2]: ViT-L/14@336 + VQ encode (no grad) -> tensor assembly -> Libra-11B routed-bridge decoder "
+                       f"fwd+bwd, LLaMA-2-7B text stream frozen (4.27 B trainable), bs={args.batch}/GPU, seq {args.seq}, one "
+                       "336px image per sequence, random-init",
+             "vit": f"configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs={args.batch}/GPU (LLM frozen)"}
+    out = {"metric": METRIC, "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": ("configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs=32/GPU (LLM frozen)"
-                                   if args.workload == "vit" else
-                                   "configs[2]/[3]: ViT+VQ encode (no grad) -> Libra-11B routed decoder fwd+bwd, frozen language, "
-                                   "bs=8/GPU, seq 2048, one 336px image per sequence"),
-                      "global_batch": args.batch * world, "image": "3x336x336", "vit_tokens": 577,
-                      "parallelism": f"dp{world}", "algorithmic_gflop_per_image": round(gflop_step_img, 1),
-                      "value_per_gpu": round(ips / world, 2)},
+           "config": {"workload": names[args.workload], "global_batch": args.batch * args.accum * world, "image": "3x336x336",
+                      "seq_len": args.seq if args.workload == "bridge" else 577, "parallelism": f"dp{world}",
+                      "algorithmic_gflop_per_image": round(gpi, 1), "value_per_gpu": round(ips / world, 3),
+                      "optimizer_in_step": bool(args.with_optimizer), "recompute": bool(args.recompute),
+                      "grad_accum": args.accum},
            "roofline": roof}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.workload == "vit":
+
+    if world == 1 and rank == 0 and not args.no_extra and args.workload == "bridge" and not args.with_optimizer:
+        # ---- optimizer leg: the same step + fused AdamW on the 4.27 B trainable parameters (configs[3] names AdamW)
+        try:
+            del w
+            torch.cuda.empty_cache()
+            wo = make_bridge(device, args.batch, args.seq, 1, "allreduce", with_optimizer=True, recompute=args.recompute)
+            n_opt = max(3, args.steps // 2)
+            dto = timed(wo, n_opt, 2, 1, device)
+            extra["with_optimizer"] = {"ms_per_step": round(dto / n_opt * 1e3, 3),
+                                       "images_per_s": round(args.batch * n_opt / dto, 3),
+                                       "optimizer_state_bytes": wo.opt.state_bytes,
+                                       "note": "same step + libra_adamw_step over the flat gradient buckets (fp32 master, m, v)"}
+            note(f"optimizer leg: {extra['with_optimizer']}")
+            del wo
+            torch.cuda.empty_cache()
+        except Exception as e:                       # never lose the headline line to an extra leg
+            extra["with_optimizer"] = {"error": repr(e)[:200]}
+        # ---- second leg: configs[1]
+        try:
+            wv = make_vit(device, 32, 1, "allreduce")
+            dtv = timed(wv, 20, 3, 1, device)
+            ipsv = 32 * 20 / dtv
+            extra["vit_leg"] = {"workload": names["vit"].replace(f"bs={args.batch}", "bs=32"), "images_per_s": round(ipsv, 2),
+                                "ms_per_step": round(dtv / 20 * 1e3, 3),
+                                "roofline": roofline(wv, "vit", ipsv, gflop_per_image("vit"))}
+            note(f"vit leg: {ipsv:.1f} images/s")
+            del wv
+            torch.cuda.empty_cache()
+        except Exception as e:
+            extra["vit_leg"] = {"error": repr(e)[:200]}
+    if extra:
+        out["extra"] = extra
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
         note("timing the CPU oracle on the host cores ...")
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(seq=args.seq, workload=args.workload)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -251,6 +251,16 @@ int libra_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 /* y = a + b (bf16, n % 8 == 0 not required) */
 int libra_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 
+/* ---- optimizer -----------------------------------------------------------------------------------*/
+/* Fused AdamW on a flat range of n elements (the data-parallel optimizer step of the reference's recipes: AdamW via HF
+ * Trainer / DeepSpeed fused Adam with bf16 + fp32 master weights, libra/configs/libra_pretrain.yaml:83-91,
+ * libra/configs/deepspeed_configs/ZeRO-2.json).  g = grad_scale * grad;  master -= lr*wd*master;
+ * m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  master -= lr/bias_corr1 * m / (sqrt(v)/sqrt(bias_corr2) + eps);
+ * param = bf16(master).  master / m / v fp32, grad / param bf16; all pointers 16-byte aligned.  One HBM pass (28 B/element). */
+int libra_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

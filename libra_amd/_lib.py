@@ -60,9 +60,10 @@ SIGNATURES = {
                               _I64, _I64, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
+    "libra_adamw_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class LibraHipError(RuntimeError):

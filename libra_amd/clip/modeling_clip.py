@@ -111,8 +111,9 @@ class _VitFunction(torch.autograd.Function):
         dpixel, grads = E.backward(ctx.pd, ctx.packed, ctx.saved, dhs, model._dims,
                                    need_pixel_grad=ctx.pixel_needs_grad)
         out = []
+        from .. import dp
         for n, p in ctx.pd.items():
-            g = grads.get(n)
+            g = None if dp.is_captured(n) else grads.get(n)       # captured gradients live in the data-parallel buckets
             if g is not None and g.shape != p.shape:
                 g = g.reshape(p.shape)
             out.append(g if (g is not None and p.requires_grad) else None)
@@ -168,12 +169,9 @@ class CLIPVisionModel(PreTrainedModel):
     def get_input_embeddings(self) -> nn.Module:
         return self.vision_model.embeddings.patch_embedding
 
-    # ---- packed operand caches (invalidated by parameter version counters) ----
+    # ---- packed operand copies (refreshed in place every forward for trainable parameters: vit_engine._Packed) ----
     def _packed_forward(self, pd):
-        key = E._versions(pd)
-        if self._pack.key != key:
-            self._pack.key, self._pack.fwd = key, E.pack_forward(pd, self._dims)
-        return self._pack.fwd
+        return self._pack.get(pd, self._dims)
 
     def forward(self, pixel_values: Optional[torch.FloatTensor] = None, output_attentions: Optional[bool] = None,
                 output_hidden_states: Optional[bool] = None, return_dict: Optional[bool] = None,

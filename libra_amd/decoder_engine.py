@@ -11,7 +11,7 @@ accumulation is fp32 in the MFMA.  Reference file:line citations: include/libra_
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
@@ -66,42 +66,72 @@ def _rope_tables(dim: int, n_pos: int, device, base: float):
     return emb.cos().to(BF16).to(device).contiguous(), emb.sin().to(BF16).to(device).contiguous()
 
 
-def pack(sd: Dict[str, torch.Tensor], d: DecDims):
-    """Fused / padded operand copies derived from the parameters (one per layer):
-    [q;k;v] dense and low-rank-A stacks, [gate;up] stacks, rank-8 bridge A's padded to the GEMM's 64-wide K/N granule."""
-    dev = sd["model.embed_tokens.weight"].device
-    H = d.hidden
-    out = []
-    for i in range(d.layers):
-        a = f"model.layers.{i}.self_attn."
-        m = f"model.layers.{i}.mlp."
-        cat = lambda names: torch.cat([sd[n].detach() for n in names], 0).contiguous()
+class PackedOperands:
+    """Fused / padded operand copies derived from the parameters, one dict per layer:
+    [q;k;v | bridge A] dense and low-rank-A stacks, [gate;up] stacks, rank-8 bridge B's padded to 8 columns (+ transposes).
 
-        def bridge_a(which):
-            t = torch.zeros((64, H), dtype=BF16, device=dev)
-            t[0:d.rank] = sd[a + f"vision_k_bridge_on_{which}.weight_A"].detach()
-            t[8:8 + d.rank] = sd[a + f"vision_v_bridge_on_{which}.weight_A"].detach()
-            return t
+    The buffers are allocated once and REFRESHED IN PLACE (so hipGraphs captured against them stay valid and see new values).
+    A slice is re-copied from its source parameter when the parameter is *volatile* (``requires_grad`` - an optimizer may
+    have updated it through ``.data``, which bumps neither ``_version`` nor ``data_ptr``: DeepSpeed ZeRO, apex, any
+    master-weight optimizer) or when its (data_ptr, _version) key changed (load_state_dict, .to()).  Version counters alone
+    are never trusted for trainable parameters."""
 
-        def bridge_b(name):
-            t = torch.zeros((H, 8), dtype=BF16, device=dev)
-            t[:, :d.rank] = sd[a + name + ".weight_B"].detach()
-            return t
-        out.append(dict(
+    def __init__(self, sd: Dict[str, torch.Tensor], d: DecDims):
+        dev = sd["model.embed_tokens.weight"].device
+        H, r, rg, I = d.hidden, d.r, d.rg, d.inter
+        self.device = dev
+        self.layers: List[dict] = []
+        self._slices: List[tuple] = []          # (dest view, source name, transposed?)
+        self._keys: Dict[int, tuple] = {}
+        z = lambda *shape: torch.zeros(shape, dtype=BF16, device=dev)
+        for i in range(d.layers):
+            a = f"model.layers.{i}.self_attn."
+            m = f"model.layers.{i}.mlp."
+            L = dict(wqkv_ab=z(3 * H + 64, H), aqkv_ab=z(3 * r + 64, H), wgu=z(2 * I, H), agu=z(2 * rg, H))
+            for j, nm in enumerate(("q", "k", "v")):
+                self._slices.append((L["wqkv_ab"][j * H:(j + 1) * H], a + f"{nm}_proj.weight", False))
+                self._slices.append((L["aqkv_ab"][j * r:(j + 1) * r], a + f"vision_{nm}_proj.weight_A", False))
             # the rank-8 bridge A's ride along as 64 extra output rows of the q/k/v projection of their modality: one GEMM
             # produces [q | k | v | t_k t_v 0...] (and one dgrad / wgrad GEMM handles both in the backward)
-            wqkv_ab=torch.cat([cat([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]), bridge_a("language")], 0),
-            aqkv_ab=torch.cat([cat([a + "vision_q_proj.weight_A", a + "vision_k_proj.weight_A", a + "vision_v_proj.weight_A"]),
-                               bridge_a("vision")], 0),
-            bk_l=bridge_b("vision_k_bridge_on_language"), bk_v=bridge_b("vision_k_bridge_on_vision"),
-            bv_l=bridge_b("vision_v_bridge_on_language"), bv_v=bridge_b("vision_v_bridge_on_vision"),
-            # the same four, transposed [8, H]: the backward takes B^T dkb / B^T dvb with v_dot2 over channel pairs
-            bkT_l=bridge_b("vision_k_bridge_on_language").t().contiguous(), bkT_v=bridge_b("vision_k_bridge_on_vision").t().contiguous(),
-            bvT_l=bridge_b("vision_v_bridge_on_language").t().contiguous(), bvT_v=bridge_b("vision_v_bridge_on_vision").t().contiguous(),
-            wgu=cat([m + "gate_proj.weight", m + "up_proj.weight"]),
-            agu=cat([m + "vision_gate_proj.weight_A", m + "vision_up_proj.weight_A"]),
-        ))
-    return out
+            for key, which, base in (("wqkv_ab", "language", 3 * H), ("aqkv_ab", "vision", 3 * r)):
+                self._slices.append((L[key][base:base + d.rank], a + f"vision_k_bridge_on_{which}.weight_A", False))
+                self._slices.append((L[key][base + 8:base + 8 + d.rank], a + f"vision_v_bridge_on_{which}.weight_A", False))
+            for kv in ("k", "v"):
+                for which, tag in (("language", "l"), ("vision", "v")):
+                    b, bT = z(H, 8), z(8, H)      # B [H, rank] and the same transposed [8, H]: the backward takes
+                    L[f"b{kv}_{tag}"], L[f"b{kv}T_{tag}"] = b, bT       # B^T dkb / B^T dvb with v_dot2 over channel pairs
+                    src = a + f"vision_{kv}_bridge_on_{which}.weight_B"
+                    self._slices.append((b[:, :d.rank], src, False))
+                    self._slices.append((bT[:d.rank], src, True))
+            for j, nm in enumerate(("gate", "up")):
+                self._slices.append((L["wgu"][j * I:(j + 1) * I], m + f"{nm}_proj.weight", False))
+                self._slices.append((L["agu"][j * rg:(j + 1) * rg], m + f"vision_{nm}_proj.weight_A", False))
+            self.layers.append(L)
+        self.refresh(sd, force=True)
+
+    def refresh(self, sd: Dict[str, torch.Tensor], force: bool = False) -> int:
+        """Re-copy stale slices; returns the number of slices copied."""
+        n = 0
+        with torch.no_grad():
+            for k, (dst, name, tr) in enumerate(self._slices):
+                p = sd[name]
+                key = (p.data_ptr(), p._version)
+                if force or p.requires_grad or self._keys.get(k) != key:
+                    src = p.detach()
+                    dst.copy_(src.t() if tr else src)
+                    self._keys[k] = key
+                    n += 1
+        return n
+
+    def __getitem__(self, i: int) -> dict:
+        return self.layers[i]
+
+    def __len__(self) -> int:
+        return len(self.layers)
+
+
+def pack(sd: Dict[str, torch.Tensor], d: DecDims) -> PackedOperands:
+    return PackedOperands(sd, d)
 
 
 def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims):
@@ -173,7 +203,7 @@ class KVCache:
 
 def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None, *,
                   cache: Optional[KVCache] = None, positions: Optional[torch.Tensor] = None,
-                  slot: Optional[torch.Tensor] = None):
+                  slot: Optional[torch.Tensor] = None, need_out: bool = True):
     """One LibraDecoderLayer (modeling_libra.py:437-491).  `sv` (dict) collects what the backward needs.
     With `cache`: positions None = prefill (the S prompt tokens' K/V rows are stored at slots [0, S)); positions int32 [B] =
     one cached decode step (S == 1): RoPE at positions[b], the new rows appended at slot cache.length, attention of the
@@ -229,12 +259,13 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     # ---- MLP block
     h2, rstd2 = K.rmsnorm_routed(x_mid, sd[pre + "post_attention_layernorm.weight"],
                                  sd[pre + "vision_post_attention_layernorm.weight"], flag, d.eps, save_rstd=True)
-    x_out = torch.empty_like(x)
+    x_out = torch.empty_like(x) if need_out else None      # (a recompute pass stops before the last down projections)
     gu = act = tg = guv = actv = td = None
     if n_l:
         gu = K.gemm_nt(h2, pk["wgu"], a_rows=lang_idx)                                 # [n_l, 2I]
         act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save))
-        K.gemm_nt(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid)
+        if need_out:
+            K.gemm_nt(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid)
     if n_v:
         tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save))               # [n_v, 2 rg]
         guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
@@ -242,19 +273,46 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
                           [guv[:, :I], guv[:, I:]])
         actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save))
         td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save))
-        K.gemm_nt(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)
+        if need_out:
+            K.gemm_nt(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)
     if save:
         sv.update(x=x, rstd1=rstd1, h=h, qkv=qkv, tb=tb, kc=kc, vc=vc, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu,
                   act=act, t=t, to=to, tg=tg, guv=guv, actv=actv, td=td)
     return x_out
 
 
+def check_ids(input_ids, flag_bs, d: DecDims):
+    """One fused device-side validation + ONE host read: vision_flag == (ids[0] >= V) (modeling_libra.py:707-710), text ids
+    inside the text table and every codebook's vision id inside the vision table (nn.Embedding device-asserts upstream;
+    gather_rows itself does not bound-check)."""
+    if input_ids.dtype != torch.int64:
+        raise TypeError(f"input_ids must be int64 (torch.long), got {input_ids.dtype}")
+    V, Vv = d.vocab, d.vision_vocab
+    ids0 = input_ids[0]
+    bad_flag = (flag_bs != (ids0 >= V)).any()
+    bad_text = ((ids0 < 0) & ~flag_bs).any()
+    vis = input_ids[:, flag_bs]                                   # [Q, n_v]
+    bad_vis = ((vis < V) | (vis >= V + Vv)).any() if vis.numel() else torch.zeros((), dtype=torch.bool, device=ids0.device)
+    code = int((bad_flag.to(torch.int32) + 2 * bad_text.to(torch.int32) + 4 * bad_vis.to(torch.int32)).item())
+    if code & 1:
+        raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
+    if code & 2:
+        raise IndexError("negative token id in input_ids")
+    if code & 4:
+        raise IndexError(f"a vision token id lies outside [{V}, {V + Vv}) in one of the codebooks")
+
+
 def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, signal, labels=None, *,
-            want_hidden_states: bool = False, save: bool = False, cache: Optional[KVCache] = None):
+            want_hidden_states: bool = False, save: bool = False, cache: Optional[KVCache] = None,
+            recompute: bool = False):
     """-> dict(hidden [B,S,H], flag, lang_idx, vis_idx, z_lang [n_l,V], z_vis list of [n_v,Vv], loss or None, saved).
-    `cache` (empty KVCache): prefill - every layer's K/V rows of the prompt are stored for decode_step."""
+    `cache` (empty KVCache): prefill - every layer's K/V rows of the prompt are stored for decode_step.
+    `recompute` (with save): gradient checkpointing per decoder layer (modeling_libra.py:787-797) - only each layer's
+    INPUT is kept; backward() re-runs layer_forward before layer_backward (4.3 GB instead of 61 GB at B=8, S=2048)."""
     Q, B, S = input_ids.shape
     dev = input_ids.device
+    if labels is not None and labels.dtype != torch.int64:
+        raise TypeError(f"labels must be int64 (torch.long), got {labels.dtype}")
     flag, lang_idx, vis_idx, lens = route(vision_indices, attention_mask, d)
     if cache is not None:
         if cache.length != 0 or S > cache.capacity or B != cache.B:
@@ -262,17 +320,17 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         if not bool((lens == S).all()):
             raise NotImplementedError("cached generation handles unpadded prompts only (the decode kernel has one valid "
                                       "length per sequence and no holes inside the cache)")
-    if not torch.equal(flag.view(B, S).bool(), input_ids[0] >= d.vocab):
-        raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
+    check_ids(input_ids, flag.view(B, S).bool(), d)
     cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, S), dev)
-    saved = dict(layers=[], emb={}) if save else None
+    saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
     x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None)
     hs = [x] if want_hidden_states else None
     for i in range(d.layers):
-        sv = {} if save else None
+        sv = {} if save and not recompute else None
+        x_in = x
         x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv, cache=cache)
         if save:
-            saved["layers"].append(sv)
+            saved["layers"].append(sv if not recompute else {"x": x_in})
         if want_hidden_states:
             hs.append(x)
     if cache is not None:
@@ -427,11 +485,14 @@ def _compact(t2d: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return buf[:n]
 
 
-def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None):
+def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None, name: Optional[str] = None):
     """dW[out, in] = sum_tokens dy[t, out] x[t, in]; both operands token-major, padded (LIBRA_GEMM_A_T | _B_T).
+    `name`: the parameter this gradient belongs to as a whole - when a data-parallel gradient store is capturing, the GEMM
+    writes straight into the parameter's slot of the flat bucket (dp.grad_out), no re-packing copy afterwards.
     (Measured: running these on a second stream, as the ViT engine does, is 1.5-3 % SLOWER here - the decoder's
     memory-bound row kernels and the big dgrad GEMMs leave no idle CUs to fill - so everything stays on one stream.)"""
-    o = K.gemm_nt(_full(dy_c), _full(x_c), a_t=True, b_t=True)
+    out = dp.grad_out(name) if name is not None else None
+    o = K.gemm_nt(_full(dy_c), _full(x_c), a_t=True, b_t=True, out=out)
     return post(o) if post is not None else o
 
 
@@ -495,9 +556,18 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         g["model.norm.weight"], g["model.vision_norm.weight"] = K.f32_to_bf16(dl), K.f32_to_bf16(dv)
 
     emitted: set = set()
+    groups = want_groups(want, d.layers)
+    _zero_fill(g, groups[0], sd)               # a head whose modality is absent from this batch still gets a (zero) gradient
     dp.emit_new(g, emitted)                    # heads + final norm
     for i in range(d.layers - 1, -1, -1):
-        dx = layer_backward(sd, packed[i], i, d, sv["layers"][i], dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w)
+        svi = sv["layers"][i]
+        if sv["recompute"]:                    # gradient checkpointing: rebuild this layer's activations from its input
+            x_in, svi = svi["x"], {}
+            layer_forward(sd, packed[i], i, d, x_in, flag, lang_idx, vis_idx, lens, cos, sin, B, S, svi, need_out=False)
+        dx = layer_backward(sd, packed[i], i, d, svi, dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w)
+        svi.clear()
+        sv["layers"][i] = None
+        _zero_fill(g, groups[1 + (d.layers - 1 - i)], sd)
         dp.emit_new(g, emitted)                # data parallel: this layer's gradients start their all-reduce now
 
     # ---- embeddings (modeling_libra.py:625-661)
@@ -506,7 +576,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         proc = "model.vision_contiguous_signal_processor.weight"
         dven = K.gemm_nt(dx, sd[proc], b_t=True, a_rows=vis_idx)                                   # [n_v, H+Cs]
         if w(proc):
-            g[proc] = _wg(_compact(dx, vis_idx), e["ven"])
+            g[proc] = _wg(_compact(dx, vis_idx), e["ven"], name=proc)
         dve = K.rmsnorm_routed_bwd(dven, e["ve"], sd["model.vision_signal_norm.weight"], None, None, e["rstd_e"])
         if w("model.vision_signal_norm.weight"):
             dn = f32(H + d.signal)
@@ -526,8 +596,39 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         tok = sv["input_ids"][0].reshape(-1).index_select(0, lang_idx.long())
         acc.index_add_(0, tok, dx.index_select(0, lang_idx.long()).float())
         g["model.embed_tokens.weight"] = acc.to(BF16)
+    _zero_fill(g, groups[-1], sd)
     dp.emit_new(g, emitted)
     return g
+
+
+_NO_GRAD_NAMES = ("vision_hidden_placeholder",)       # only read by the 2d prediction mode: no gradient upstream either
+
+
+def emit_group(name: str, n_layers: int) -> int:
+    """Backward-order group of a parameter: 0 = heads + final norms, 1 + (L-1-i) = decoder layer i, L+1 = embedding stage.
+    Rank-independent: the data-parallel buckets (dp.GradBuckets) are laid out by it."""
+    if name.startswith("model.layers."):
+        return 1 + (n_layers - 1 - int(name.split(".")[2]))
+    if name in ("model.norm.weight", "model.vision_norm.weight") or name.startswith(("lm_head.", "vision_lm_head.")):
+        return 0
+    return n_layers + 1
+
+
+def want_groups(want, n_layers: int):
+    groups = [[] for _ in range(n_layers + 2)]
+    for n in sorted(want):
+        if n not in _NO_GRAD_NAMES:
+            groups[emit_group(n, n_layers)].append(n)
+    return groups
+
+
+def _zero_fill(g, names, sd):
+    """Parameters of a modality that has no token in this micro-batch: the reference runs the module on an empty tensor
+    and autograd yields ZERO gradients (not None) - and every data-parallel rank must emit the same gradient set."""
+    for n in names:
+        if n not in g:
+            buf = dp.grad_out(n)
+            g[n] = buf.zero_() if buf is not None else torch.zeros_like(sd[n], dtype=BF16)
 
 
 def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w):
@@ -547,7 +648,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         gu = sv["gu"]
         dact = K.gemm_nt(dx_out, sd[m + "down_proj.weight"], b_t=True, a_rows=lang_idx)                 # [n_l, I]
         if w(m + "down_proj.weight"):
-            g[m + "down_proj.weight"] = _wg(_compact(dx_out, lang_idx), sv["act"])
+            g[m + "down_proj.weight"] = _wg(_compact(dx_out, lang_idx), sv["act"], name=m + "down_proj.weight")
         dgu = K.alloc_rows(n_l, 2 * I, dev)[:n_l]
         K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         K.gemm_nt(dgu, pk["wgu"], b_t=True, out=dh2, c_rows=lang_idx)
@@ -559,19 +660,19 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         dxo_v = _compact(dx_out, vis_idx)
         dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=K.alloc_rows(n_v, r, dev)[:n_v])
         if w(m + "vision_down_proj.weight_B"):
-            g[m + "vision_down_proj.weight_B"] = _wg(dxo_v, td)
+            g[m + "vision_down_proj.weight_B"] = _wg(dxo_v, td, name=m + "vision_down_proj.weight_B")
         dactv = K.gemm_nt(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True)                            # [n_v, I]
         if w(m + "vision_down_proj.weight_A"):
-            g[m + "vision_down_proj.weight_A"] = _wg(dtd, actv)
+            g[m + "vision_down_proj.weight_A"] = _wg(dtd, actv, name=m + "vision_down_proj.weight_A")
         dguv = K.alloc_rows(n_v, 2 * I, dev)[:n_v]
         K.swiglu_bwd(dactv, guv[:, :I], guv[:, I:], dguv[:, :I], dguv[:, I:])
         dtg = K.alloc_rows(n_v, 2 * rg, dev)[:n_v]
         K.gemm_nt_grouped([dguv[:, :I], dguv[:, I:]], [sd[m + "vision_gate_proj.weight_B"], sd[m + "vision_up_proj.weight_B"]],
                           [dtg[:, :rg], dtg[:, rg:]], b_t=True)
         if w(m + "vision_gate_proj.weight_B"):
-            g[m + "vision_gate_proj.weight_B"] = _wg(dguv[:, :I], tg[:, :rg])
+            g[m + "vision_gate_proj.weight_B"] = _wg(dguv[:, :I], tg[:, :rg], name=m + "vision_gate_proj.weight_B")
         if w(m + "vision_up_proj.weight_B"):
-            g[m + "vision_up_proj.weight_B"] = _wg(dguv[:, I:], tg[:, rg:])
+            g[m + "vision_up_proj.weight_B"] = _wg(dguv[:, I:], tg[:, rg:], name=m + "vision_up_proj.weight_B")
         K.gemm_nt(dtg, pk["agu"], b_t=True, out=dh2, c_rows=vis_idx)
         if any_l([m + "vision_gate_proj.weight_A", m + "vision_up_proj.weight_A"]):
             dagu = _wg(dtg, _compact(h2, vis_idx))
@@ -589,15 +690,15 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     if n_l:
         K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do)
         if w(a + "o_proj.weight"):
-            g[a + "o_proj.weight"] = _wg(_compact(dx_mid, lang_idx), _compact(o, lang_idx))
+            g[a + "o_proj.weight"] = _wg(_compact(dx_mid, lang_idx), _compact(o, lang_idx), name=a + "o_proj.weight")
     if n_v:
         dxm_v = _compact(dx_mid, vis_idx)
         dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=K.alloc_rows(n_v, r, dev)[:n_v])
         if w(a + "vision_o_proj.weight_B"):
-            g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"])
+            g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"], name=a + "vision_o_proj.weight_B")
         K.gemm_nt(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx)
         if w(a + "vision_o_proj.weight_A"):
-            g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx))
+            g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx), name=a + "vision_o_proj.weight_A")
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
     dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
                                                sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5)
@@ -648,7 +749,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
                           [dt[:, j * r:(j + 1) * r] for j in range(3)], b_t=True)
         for j, nm in enumerate(("q", "k", "v")):
             if w(a + f"vision_{nm}_proj.weight_B"):
-                g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r])
+                g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r], name=a + f"vision_{nm}_proj.weight_B")
         K.copy_rows(dtb, vis_idx, n_v, dt_buf, 3 * r)                # the vision rows' 64 bridge columns
         K.gemm_nt(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx)                   # K = 3r + 64
         nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"

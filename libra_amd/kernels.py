@@ -342,6 +342,21 @@ def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return a
 
 
+def adamw_step(master, m, v, grad, param, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+               bias_corr1: float, bias_corr2: float, grad_scale: float = 1.0):
+    """One fused AdamW update of a flat range: master / m / v fp32 [n], grad / param bf16 [n] (param = bf16(master))."""
+    n = master.numel()
+    for t, dt, nm in ((master, torch.float32, "master"), (m, torch.float32, "m"), (v, torch.float32, "v"),
+                      (grad, BF16, "grad"), (param, BF16, "param")):
+        if t.dtype != dt or t.numel() != n or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"adamw_step: {nm} must be a contiguous cuda {dt} tensor of {n} elements "
+                             f"(got {t.dtype} {tuple(t.shape)} {t.device}); there is no CPU optimizer path")
+    rc = _lib.lib().libra_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), n,
+                                     float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                     float(bias_corr1), float(bias_corr2), float(grad_scale), _stream())
+    _lib.check(rc, "adamw_step")
+
+
 # ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
 class LaunchProfile:
     """Context manager: while active, every gemm_nt / vit_attn_* call is bracketed by events on the current

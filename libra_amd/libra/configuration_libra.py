@@ -1,9 +1,9 @@
 """LibraConfig — mirror of /root/reference/libra/models/libra/configuration_libra.py:3-58 (the 18 Libra fields on top of
 LlamaConfig, /root/reference/libra/models/llama/configuration_llama.py:84-117).  Defaults = Libra-11B."""
-from transformers import PretrainedConfig
+from ..llama.configuration_llama import LlamaConfig
 
 
-class LibraConfig(PretrainedConfig):
+class LibraConfig(LlamaConfig):
     model_type = "libra"
     keys_to_ignore_at_inference = ["past_key_values"]
 
@@ -38,15 +38,9 @@ class LibraConfig(PretrainedConfig):
         self.resid_pdrop = resid_pdrop
         self.attn_pdrop = attn_pdrop
         self.embd_pdrop = embd_pdrop
-        self.vocab_size = vocab_size
-        self.max_position_embeddings = max_position_embeddings
-        self.hidden_size = hidden_size
-        self.intermediate_size = intermediate_size
-        self.num_hidden_layers = num_hidden_layers
-        self.num_attention_heads = num_attention_heads
-        self.hidden_act = hidden_act
-        self.initializer_range = initializer_range
-        self.rms_norm_eps = rms_norm_eps
-        self.use_cache = use_cache
-        super().__init__(pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id,
-                         tie_word_embeddings=tie_word_embeddings, **kwargs)
+        super().__init__(vocab_size=vocab_size, hidden_size=hidden_size, intermediate_size=intermediate_size,
+                         num_hidden_layers=num_hidden_layers, num_attention_heads=num_attention_heads, hidden_act=hidden_act,
+                         max_position_embeddings=max_position_embeddings, initializer_range=initializer_range,
+                         rms_norm_eps=rms_norm_eps, use_cache=use_cache, pad_token_id=pad_token_id,
+                         bos_token_id=bos_token_id, eos_token_id=eos_token_id, tie_word_embeddings=tie_word_embeddings,
+                         **kwargs)

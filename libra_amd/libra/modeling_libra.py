@@ -20,17 +20,21 @@ from transformers import PreTrainedModel
 from transformers.modeling_outputs import CausalLMOutputWithPast
 
 from .. import decoder_engine as DE
+from ..common.registry import registry
+from ..llama.modeling_llama import LlamaRMSNorm          # noqa: F401  (re-exported: trainer.py:3 imports the name)
 from .configuration_libra import LibraConfig
 
 
-class LlamaRMSNorm(nn.Module):          # models/llama/modeling_llama.py:118-132 (weight holder; trainer.py:3 imports the name)
-    def __init__(self, hidden_size, eps=1e-6):
-        super().__init__()
-        self.weight = nn.Parameter(torch.ones(hidden_size))
-        self.variance_epsilon = eps
+class _EngineOwned(nn.Module):
+    """Base of the parameter-holder sub-modules: their arithmetic is the fused kernel schedule of
+    ``libra_amd/decoder_engine.py`` driven by ``LibraForCausalLM.forward`` - calling one on its own has no fused equivalent."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError(f"{type(self).__name__} only owns parameters in libra_amd: the routed decoder runs as one fused "
+                           "schedule - call LibraForCausalLM(...) (or libra_amd.decoder_engine.layer_forward) instead")
 
 
-class LibraLinear(nn.Module):           # modeling_libra.py:150-206
+class LibraLinear(_EngineOwned):           # modeling_libra.py:150-206
     def __init__(self, in_features: int, out_features: int, bias: bool = False, down_ratio=4, rank=None):
         super().__init__()
         assert in_features % down_ratio == 0
@@ -47,7 +51,7 @@ class LibraLinear(nn.Module):           # modeling_libra.py:150-206
             nn.init.kaiming_uniform_(self.weight_B, a=math.sqrt(5))
 
 
-class LibraAttention(nn.Module):        # modeling_libra.py:245-265 (+ LlamaAttention.__init__ modeling_llama.py:207-228)
+class LibraAttention(_EngineOwned):        # modeling_libra.py:245-265 (+ LlamaAttention.__init__ modeling_llama.py:207-228)
     def __init__(self, c: LibraConfig):
         super().__init__()
         H = c.hidden_size
@@ -60,7 +64,7 @@ class LibraAttention(nn.Module):        # modeling_libra.py:245-265 (+ LlamaAtte
             setattr(self, n, LibraLinear(H, H, rank=c.bridge_rank))
 
 
-class LibraMLP(nn.Module):              # modeling_libra.py:208-238 (+ LlamaMLP modeling_llama.py:185-201)
+class LibraMLP(_EngineOwned):              # modeling_libra.py:208-238 (+ LlamaMLP modeling_llama.py:185-201)
     def __init__(self, c: LibraConfig):
         super().__init__()
         H, I = c.hidden_size, c.intermediate_size
@@ -72,7 +76,7 @@ class LibraMLP(nn.Module):              # modeling_libra.py:208-238 (+ LlamaMLP 
         self.vision_up_proj = LibraLinear(H, I, down_ratio=c.vision_down_ratio)
 
 
-class LibraDecoderLayer(nn.Module):     # modeling_libra.py:416-435
+class LibraDecoderLayer(_EngineOwned):     # modeling_libra.py:416-435
     def __init__(self, c: LibraConfig):
         super().__init__()
         self.self_attn = LibraAttention(c)
@@ -83,7 +87,7 @@ class LibraDecoderLayer(nn.Module):     # modeling_libra.py:416-435
         self.vision_post_attention_layernorm = LlamaRMSNorm(c.hidden_size, eps=c.rms_norm_eps)
 
 
-class LibraModel(nn.Module):            # modeling_libra.py:524-600 (parameter holder)
+class LibraModel(_EngineOwned):            # modeling_libra.py:524-600 (parameter holder)
     def __init__(self, c: LibraConfig):
         super().__init__()
         self.embed_tokens = nn.Embedding(c.vocab_size, c.hidden_size, c.pad_token_id)
@@ -95,9 +99,12 @@ class LibraModel(nn.Module):            # modeling_libra.py:524-600 (parameter h
         self.vision_norm = LlamaRMSNorm(c.hidden_size, eps=c.rms_norm_eps)
         self.vision_contiguous_signal_processor = nn.Linear(c.contiguous_signal_size + c.hidden_size, c.hidden_size, bias=False)
         self.vision_signal_norm = LlamaRMSNorm(c.contiguous_signal_size + c.hidden_size, eps=c.rms_norm_eps)
+        # modeling_libra.py:597 - PreTrainedModel.gradient_checkpointing_enable() flips it (both recipes do:
+        # libra_pretrain.yaml:120); the engine then keeps only each layer's input and recomputes the layer in backward
+        self.gradient_checkpointing = False
 
 
-class MultiLMHead(nn.Module):           # modeling_libra.py:834-843
+class MultiLMHead(_EngineOwned):           # modeling_libra.py:834-843
     def __init__(self, head_num, input_dim, output_dim):
         super().__init__()
         self.heads = nn.ModuleList([nn.Linear(input_dim, output_dim, bias=False) for _ in range(head_num)])
@@ -105,22 +112,34 @@ class MultiLMHead(nn.Module):           # modeling_libra.py:834-843
 
 @dataclass
 class LibraCausalLMOutputWithPast(CausalLMOutputWithPast):     # modeling_libra.py:98-109
+    """`.logits` is the reference's [Q,B,S,V+514] tensor.  Under autograd (a training step, where HF Trainer reads only
+    `.loss`) the 2.1 GB tensor (B=8, S=2048) is built on FIRST ACCESS of `.logits` / `["logits"]` from the compact per-modality
+    logits the fused CE consumed; without autograd (evaluation / prediction) it is materialised eagerly, so `items()`,
+    `to_tuple()` and `Trainer.prediction_step` see it.  It carries no grad_fn: a custom loss on `.logits` is not supported
+    (the loss is fused - pass `labels`)."""
     past_hidden_states: Optional[torch.FloatTensor] = None
     past_vision_flag: Optional[torch.BoolTensor] = None
 
+    def _materialize(self):
+        lazy = self.__dict__.get("_lazy_logits")
+        if lazy is None:
+            return None
+        val = DE.dense_logits(*lazy)
+        self.__dict__["_lazy_logits"] = None
+        self.logits = val                      # ModelOutput.__setattr__ also registers the dict key
+        return val
 
-class _LazyLogits:
-    """`.logits` of the output: the reference materialises [Q,B,S,V+514] (2.1 GB at B=8,S=2048) even though the Trainer
-    only reads `.loss`; here it is built on first access."""
+    def __getattribute__(self, name):
+        if name == "logits":
+            d = object.__getattribute__(self, "__dict__")
+            if d.get("_lazy_logits") is not None:
+                return object.__getattribute__(self, "_materialize")()
+        return super().__getattribute__(name)
 
-    def __init__(self, out, dims, B, S):
-        self._args = (out, dims, B, S)
-        self._t = None
-
-    def get(self):
-        if self._t is None:
-            self._t = DE.dense_logits(*self._args)
-        return self._t
+    def __getitem__(self, k):
+        if k == "logits" and self.__dict__.get("_lazy_logits") is not None:
+            return self._materialize()
+        return super().__getitem__(k)
 
 
 class LibraForCausalLM(PreTrainedModel):
@@ -136,6 +155,10 @@ class LibraForCausalLM(PreTrainedModel):
                 or c.use_vision_position_embedding or c.vision_prediction_mode != "1d"):
             raise NotImplementedError("only the configuration used by both Libra recipes is built "
                                       "(bridge on, concat+norm signals, 1d prediction; SURVEY §8f-4 lists the rest)")
+        for nm in ("resid_pdrop", "attn_pdrop", "embd_pdrop", "vision_resid_pdrop", "vision_embd_pdrop"):
+            if getattr(c, nm, 0.0):
+                raise NotImplementedError(f"{nm}={getattr(c, nm)}: dropout is 0 in both Libra recipes and is not built into "
+                                          "the fused kernels")
         if c.hidden_size // c.num_attention_heads != 128:
             raise NotImplementedError("the fused bridge attention kernel is specialised for head_dim 128 (LLaMA-2-7B)")
         self.model = LibraModel(c)
@@ -149,7 +172,7 @@ class LibraForCausalLM(PreTrainedModel):
                                 codebooks=c.vision_codebook_num, max_vision_len=c.max_vision_token_length,
                                 signal=c.contiguous_signal_size, rank=c.bridge_rank, down_ratio=c.vision_down_ratio,
                                 eps=c.rms_norm_eps, max_pos=c.max_position_embeddings)
-        self._pack_key, self._packed = None, None
+        self._packed: Optional[DE.PackedOperands] = None
         self.post_init()
 
     def _init_weights(self, module):        # modeling_libra.py:502-519
@@ -176,12 +199,28 @@ class LibraForCausalLM(PreTrainedModel):
     def get_output_embeddings(self):
         return self.lm_head
 
+    def _refresh_packed(self, sd):
+        """Fused operand copies ([q;k;v|bridge A], [gate;up], bridge B / B^T): built once, then refreshed in place - always
+        for trainable parameters (optimizers that write through `.data`, e.g. DeepSpeed ZeRO, bump no version counter),
+        by (data_ptr, _version) for frozen ones.  See DE.PackedOperands."""
+        dev = sd["model.embed_tokens.weight"].device
+        if self._packed is None or self._packed.device != dev:
+            self._packed = DE.PackedOperands(sd, self._dims)
+        else:
+            self._packed.refresh(sd)
+        return self._packed
+
+    def invalidate_packed(self):
+        """Force a full rebuild of the fused operand copies at the next forward (e.g. after writing FROZEN weights through
+        `.data`; trainable ones are refreshed every forward anyway)."""
+        self._packed = None
+
     def _state(self):
         sd = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version) for p in sd.values())
-        if key != self._pack_key:
-            self._pack_key, self._packed = key, DE.pack(sd, self._dims)
-        return sd, self._packed
+        return sd, self._refresh_packed(sd)
+
+    def _ptr_key(self):
+        return tuple(p.data_ptr() for p in self.parameters())
 
     def forward(self, input_ids: torch.LongTensor = None, attention_mask: Optional[torch.Tensor] = None,
                 position_ids=None, past_key_values=None, inputs_embeds=None, labels: Optional[torch.LongTensor] = None,
@@ -217,10 +256,11 @@ class LibraForCausalLM(PreTrainedModel):
         hs = None
         if output_hidden_states:
             hs = tuple(h.view(B, S, -1) for h in out["hidden_states"]) + (out["hidden"],)
-        lazy = _LazyLogits(out, self._dims, B, S)
-        res = LibraCausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None, hidden_states=hs, attentions=None)
-        object.__setattr__(res, "_lazy_logits", lazy)
-        object.__setattr__(res, "_engine_out", out)
+        training_step = out["saved"] is not None              # autograd will call back: the Trainer reads only .loss
+        logits = None if training_step else DE.dense_logits(out, self._dims, B, S)
+        res = LibraCausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None)
+        res.__dict__["_lazy_logits"] = (out, self._dims, B, S) if training_step else None
+        res.__dict__["_engine_out"] = out
         return res
 
     @torch.no_grad()
@@ -239,7 +279,7 @@ class LibraForCausalLM(PreTrainedModel):
             if position_ids is not None and not torch.equal(position_ids.reshape(B, S).to(dev), torch.arange(S, device=dev).expand(B, S)):
                 raise NotImplementedError("prefill positions other than arange(S)")
             cache = DE.KVCache(dims.layers, B, max(dims.max_pos, S), dims.hidden, dev)
-            cache.pack_key = self._pack_key
+            cache.pack_key = self._ptr_key()
             out = DE.forward(sd, packed, dims, input_ids, attention_mask, vision_indices, signal, None, cache=cache)
         else:
             if not isinstance(past, DE.KVCache):
@@ -249,9 +289,9 @@ class LibraForCausalLM(PreTrainedModel):
             if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
                 raise NotImplementedError("cached generation handles unpadded sequences only")
             cache = past
-            if getattr(cache, "pack_key", None) != self._pack_key:      # parameters changed since the graphs were captured:
-                cache.graphs.clear()                                     # they hold the old packed operands' addresses
-                cache.pack_key = self._pack_key
+            if getattr(cache, "pack_key", None) != self._ptr_key():     # parameter storage moved since the graphs were captured
+                cache.graphs.clear()                                     # (values may change freely: operands are refreshed in place)
+                cache.pack_key = self._ptr_key()
             if position_ids is None:                                                    # attention_mask.cumsum(-1) - 1, :1207
                 position_ids = torch.full((B, 1), cache.length, dtype=torch.long, device=dev)
             out = DE.decode_step(sd, packed, dims, cache, input_ids, vision_indices, position_ids,
@@ -317,7 +357,7 @@ class LibraForCausalLM(PreTrainedModel):
     @staticmethod
     def materialize_logits(output) -> torch.Tensor:
         """[Q,B,S,V+Vv] exactly as the reference's `.logits` (text rows [lm_head | -inf], vision rows [-inf | head_q])."""
-        return output.logits if output.logits is not None else output._lazy_logits.get()
+        return output.logits
 
 
 class _LibraFunction(torch.autograd.Function):
@@ -328,12 +368,11 @@ class _LibraFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, holder, names, input_ids, attention_mask, vision_indices, signal, labels, want_hs, *params):
         sd = dict(zip(names, params))
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if key != model._pack_key:
-            model._pack_key, model._packed = key, DE.pack(sd, model._dims)
+        packed = model._refresh_packed(sd)
         need = labels is not None and any(ctx.needs_input_grad[9:])
-        out = DE.forward(sd, model._packed, model._dims, input_ids, attention_mask, vision_indices, signal, labels,
-                         want_hidden_states=want_hs, save=need)
+        out = DE.forward(sd, packed, model._dims, input_ids, attention_mask, vision_indices, signal, labels,
+                         want_hidden_states=want_hs, save=need,
+                         recompute=need and model.model.gradient_checkpointing and model.training)
         holder["out"] = out
         ctx.model, ctx.sd, ctx.out, ctx.names = model, sd, out, names
         ctx.want = {n for n, ng in zip(names, ctx.needs_input_grad[9:]) if ng}
@@ -348,10 +387,95 @@ class _LibraFunction(torch.autograd.Function):
         # per step instead of one elementwise kernel per parameter
         grads = DE.backward(ctx.sd, ctx.model._packed, ctx.model._dims, ctx.out, ctx.want, gscale=float(gloss))
         res = []
+        from .. import dp
         for n in ctx.names:
-            gr = grads.get(n) if n in ctx.want else None
+            gr = grads.get(n) if n in ctx.want and not dp.is_captured(n) else None      # captured: lives in the DP bucket
             if gr is not None:
                 gr = gr.reshape(ctx.sd[n].shape)
             res.append(gr)
         ctx.out["saved"] = None
         return (None,) * 9 + tuple(res)
+
+
+def _cfg_get(cfg, key, default=None):
+    g = getattr(cfg, "get", None)
+    return g(key, default) if g is not None else getattr(cfg, key, default)
+
+
+@registry.register_model("libra_train_wrapper")
+class LibraTrainWrapper(PreTrainedModel):
+    """What `train.py` builds (`registry.get_model_class("libra_train_wrapper").from_config(cfg)`, train.py:29-30) and HF
+    Trainer steps: tokenizer -> labels -> LibraForCausalLM, with the reference's freeze switches.  Mirrors
+    modeling_libra.py:1292-1437 (cfg fields `pretrained`, `custom_kwargs`, `tokenizer_kwargs`, `model_kwargs.{frozen_language,
+    freeze_vision_value, freeze_text_embedding, freeze_vision_embedding, debug}`, `pretrained_weight`).
+
+    `module=` / `tokenizer=` inject pre-built parts (random-init benchmarks and tests: no checkpoint exists offline)."""
+    config_class = LibraConfig
+    base_model_prefix = "module"
+    supports_gradient_checkpointing = True
+
+    def __init__(self, config, *, module: Optional["LibraForCausalLM"] = None, tokenizer=None):
+        from .tokenization_libra import LibraTokenizer, apply_freeze_policy
+        pretrained = _cfg_get(config, "pretrained")
+        if module is not None:
+            libra_config = module.config
+        else:
+            import json
+            import os
+            with open(os.path.join(pretrained, "config.json")) as f:
+                libra_config = LibraConfig(**json.load(f))
+        super().__init__(libra_config)
+        self.module = module if module is not None else LibraForCausalLM.from_pretrained(
+            pretrained, **dict(_cfg_get(config, "custom_kwargs", {}) or {}))
+        self.tokenizer = tokenizer if tokenizer is not None else LibraTokenizer(
+            pretrained, **dict(_cfg_get(config, "tokenizer_kwargs", {}) or {}))
+        tt = self.tokenizer.text_tokenizer
+        self.change_pad_token_to_eos(pad_token_id=tt.pad_token_id, eos_token_id=tt.eos_token_id)
+        weight = _cfg_get(config, "pretrained_weight", None)
+        if weight is not None:
+            sd = torch.load(weight, map_location="cpu")
+            wrapped = any(k.startswith("model.model.") for k in sd)
+            mod_wrapped = any(k.startswith("module.model.") for k in sd)
+            assert not (wrapped and mod_wrapped), "'has_wrapper' and 'has_module_wrapper' cannot both be True."
+            if mod_wrapped:                                                     # :1325-1331 (only this branch re-binds upstream)
+                sd = {k[7:]: v for k, v in sd.items() if k.startswith("module.")}
+            missing, unexpected = self.module.load_state_dict(sd, strict=False)
+            print("missing keys: ", missing)
+            print("unexpected keys: ", unexpected)
+        mk = dict(_cfg_get(config, "model_kwargs", {}) or {})
+        apply_freeze_policy(self.module, frozen_language=mk.get("frozen_language", False),
+                            freeze_vision_value=mk.get("freeze_vision_value", False),
+                            freeze_text_embedding=mk.get("freeze_text_embedding", False),
+                            freeze_vision_embedding=mk.get("freeze_vision_embedding", False), debug=mk.get("debug", False))
+
+    def _init_weights(self, module):
+        pass                                           # the wrapped LibraForCausalLM initialises / loads its own weights
+
+    @classmethod
+    def get_model_from_config(cls, config):
+        from .tokenization_libra import LibraTokenizer
+        pretrained = _cfg_get(config, "pretrained")
+        model = LibraForCausalLM.from_pretrained(pretrained, torch_dtype="auto", **dict(_cfg_get(config, "custom_kwargs", {}) or {}))
+        return model, LibraTokenizer(pretrained, **dict(_cfg_get(config, "tokenizer_kwargs", {}) or {}))
+
+    def change_pad_token_to_eos(self, pad_token_id=0, eos_token_id=2):
+        """:1383-1388 - the padding row of the text embedding gets the EOS row's values (same scale as real tokens)."""
+        emb = self.module.get_input_embeddings()
+        emb.weight.data[pad_token_id] = emb.weight.data[eos_token_id].clone()
+
+    def get_labels(self, inputs, label_mask_position_map):
+        from .tokenization_libra import get_labels
+        return get_labels(inputs, label_mask_position_map, boi_token_id=self.tokenizer.image_tokenizer.boi_token_id,
+                          bos_token_id=self.tokenizer.text_tokenizer.bos_token_id)
+
+    def forward(self, samples, return_loss=None, **kwargs):
+        inputs = self.tokenizer(samples, return_tensors="pt", padding="longest",
+                                max_length=self.tokenizer.text_tokenizer.model_max_length, truncation=True)
+        labels = self.get_labels(inputs, samples["label_mask_position_map"])
+        return self.module(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                           vision_indices=inputs["vision_indices"], contiguous_signal=inputs["coninous_signal"],
+                           labels=labels, use_cache=False, **kwargs)
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(config)

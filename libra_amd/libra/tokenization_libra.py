@@ -7,9 +7,15 @@ arithmetic hot path).  The text half of the reference tokenizer (sentencepiece L
 is outside the hot path: callers hand in the text ids with every ``<img_ph>`` already expanded to
 ``max_vision_token_length`` placeholder slots, exactly what ``self.text_tokenizer(texts, ...)`` returns upstream (:245).
 """
+import json
+import logging
+import os
 from typing import Optional, Sequence
 
 import torch
+from transformers import BatchEncoding
+
+MAX_TOKEN_LENGTH = 2048                                                         # tokenization_libra.py:15
 
 
 def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_inputs: Optional[dict], *,
@@ -89,3 +95,124 @@ def apply_freeze_policy(module: torch.nn.Module, *, frozen_language: bool = Fals
             if "vision_lm_head" not in n:
                 p.requires_grad = False
     return module
+
+
+class LibraTokenizer(torch.nn.Module):
+    """The reference's multimodal tokenizer module (tokenization_libra.py:109-316): `.text_tokenizer` (LLaMA tokenizer with the
+    `<img_ph>` / `<img_gen>` tokens added, pad = unk, :135-146), `.image_tokenizer` (CLIP ViT -> VQ encode on the gfx950 kernels),
+    `.device` / `.dtype` (:126-133), and `forward(samples, **tokenizer_kwargs)` -> the four tensors LibraTrainWrapper.forward
+    consumes (:305-316).  The sample parsing follows :170-219; the tensor assembly is `assemble_inputs` above.
+
+    `pretrained_model_path` is the checkpoint directory (tokenizer files + `vision_tokenizer_config.yaml`, :149-160).
+    Pre-built tokenizers can be injected instead (`text_tokenizer=`, `image_tokenizer=`): no LLaMA `tokenizer.model` exists
+    in the offline build / test environments, so tests pass a word-level `PreTrainedTokenizerFast`."""
+
+    def __init__(self, pretrained_model_path=None, vision_config_overwrite={}, *, text_tokenizer=None, image_tokenizer=None,
+                 **kwargs):
+        super().__init__()
+        self.raw_output = kwargs.pop("raw_output", False)
+        self.text_tokenizer = (self._prepare_text_tokenizer(text_tokenizer) if text_tokenizer is not None
+                               else self.init_text_tokenizer(pretrained_model_path, **kwargs))
+        self.image_tokenizer_offset = self.text_tokenizer.vocab_size
+        self.image_tokenizer = (image_tokenizer if image_tokenizer is not None else
+                                self.init_image_tokenizer(pretrained_model_path, self.image_tokenizer_offset,
+                                                          vision_config_overwrite))
+        L = self.image_tokenizer.max_vision_token_length
+        self.register_buffer("img_indices_ph", torch.arange(0, L, dtype=torch.long)[None, :])
+        self.num_codebook = self.image_tokenizer.num_codebook
+
+    @property
+    def device(self):
+        return self.image_tokenizer.device
+
+    @property
+    def dtype(self):
+        return self.image_tokenizer.dtype
+
+    @staticmethod
+    def _prepare_text_tokenizer(tok):
+        tok.add_tokens("<img_ph>")
+        tok.add_tokens("<img_gen>")
+        tok.img_ph_token_id = tok.convert_tokens_to_ids("<img_ph>")
+        tok.img_gen_token_id = tok.convert_tokens_to_ids("<img_gen>")
+        tok.pad_token = tok.unk_token                                           # :143
+        return tok
+
+    @classmethod
+    def init_text_tokenizer(cls, pretrained_model_path, **kwargs):
+        from transformers import LlamaTokenizerFast
+        return cls._prepare_text_tokenizer(LlamaTokenizerFast.from_pretrained(pretrained_model_path, **kwargs))
+
+    @classmethod
+    def init_image_tokenizer(cls, pretrained_model_path, offset, vision_config_overwrite={}):
+        import yaml
+        from .image_tokenizer import ImageTokenizer
+        with open(os.path.join(pretrained_model_path, "vision_tokenizer_config.yaml")) as f:
+            config = yaml.safe_load(f)
+        if config.get("ckpt_path") is not None:
+            config["ckpt_path"] = os.path.join(pretrained_model_path, config["ckpt_path"])
+        params = config["params"]
+        if params.get("ckpt_path") is not None:
+            params["ckpt_path"] = os.path.join(pretrained_model_path, params["ckpt_path"])
+        if params["ddconfig"].get("encoder_name") is not None:
+            params["ddconfig"]["encoder_name"] = os.path.join(pretrained_model_path, params["ddconfig"]["encoder_name"])
+        config.update(**vision_config_overwrite)
+        return ImageTokenizer.from_config(config, token_offset=offset)
+
+    @staticmethod
+    def _flatten(samples, key):
+        out = []
+        for sample in samples:
+            v = sample.get(key, None)
+            if v is not None:
+                out += list(v) if isinstance(v, (list, tuple)) else [v]
+        return out
+
+    @torch.no_grad()
+    def forward(self, samples, **kwargs):
+        if not isinstance(samples, (list, tuple)):
+            samples = [samples]
+        texts = self._flatten(samples, "language")
+        images = self._flatten(samples, "vision")
+        signs = self._flatten(samples, "contiguous_ignore_sign")
+        dev = self.device
+        if images:
+            images = [img.to(dev) for img in images]
+            if images[0].dim() == 3:
+                images = torch.stack(images)
+            elif images[0].dim() == 4:
+                images = torch.cat(images)
+            else:
+                raise ValueError("Invalid vision inputs.")                      # :196
+        else:
+            images = None
+        if signs:
+            signs = torch.cat(signs) if isinstance(signs[0], torch.Tensor) else torch.tensor(signs, device=dev)
+        else:
+            signs = None
+        has_image_flag = samples[-1].get("has_image", None)                      # (:209 reads the LAST sample's key)
+        if has_image_flag is not None:
+            has_image_flag = torch.tensor(has_image_flag, device=dev, dtype=torch.bool)
+        if not texts and images is None:
+            raise ValueError("Empty inputs")                                    # :229
+        if not texts:
+            raise NotImplementedError                                           # :231
+        if kwargs.pop("return_tensors", "pt") != "pt":
+            raise ValueError("return_tensors = \"pt\" is fixed, and should not be specified to other values.")
+        truncation = kwargs.pop("truncation", False)
+        max_length = kwargs.pop("max_length", self.text_tokenizer.model_max_length)
+        text_inputs = self.text_tokenizer(texts, return_tensors="pt", return_length=True, **kwargs).to(dev)     # :245
+        if (text_inputs["length"] > MAX_TOKEN_LENGTH).sum():
+            logging.warning("The input token length ecceeds the max number that the model can hold. This may cause "
+                            "performance degradation or OOM.")
+        image_inputs = None
+        if images is not None:
+            image_inputs = self.image_tokenizer(images.to(self.dtype))                                          # :258-259
+        out = assemble_inputs(text_inputs["input_ids"], text_inputs["attention_mask"], image_inputs,
+                              img_ph_token_id=self.text_tokenizer.img_ph_token_id,
+                              img_gen_token_id=self.text_tokenizer.img_gen_token_id,
+                              boi_token_id=self.image_tokenizer.boi_token_id, num_codebook=self.image_tokenizer.num_codebook,
+                              max_vision_token_length=self.image_tokenizer.max_vision_token_length,
+                              contiguous_ignore_signs=signs, has_image_flag=has_image_flag, truncation=truncation,
+                              max_length=max_length)
+        return out if self.raw_output else BatchEncoding(out)

@@ -49,32 +49,51 @@ class VitDims:
 
 
 class _Packed:
-    """Device-side operand copies derived from the parameters (rebuilt when a parameter changes):
-    fused [q;k;v] weight/bias and the zero-padded patch-embedding matrix."""
+    """Device-side operand copies derived from the parameters: fused [q;k;v] weight/bias and the zero-padded patch-embedding
+    matrix.  Allocated once and refreshed IN PLACE: a slice is re-copied when its source parameter is trainable (an optimizer
+    may have updated it through `.data`, which bumps neither `_version` nor `data_ptr` - DeepSpeed, master-weight
+    optimizers) or when its (data_ptr, _version) key changed.  Version counters alone are never trusted."""
 
     def __init__(self):
-        self.key = None
         self.fwd = None
+        self._slices: List[tuple] = []
+        self._keys: Dict[int, tuple] = {}
 
+    def get(self, params: Dict[str, torch.Tensor], dims: VitDims):
+        dev = params[P + "embeddings.patch_embedding.weight"].device
+        if self.fwd is None or self.fwd["wpe"].device != dev:
+            self._build(dims, dev)
+            force = True
+        else:
+            force = False
+        with torch.no_grad():
+            for k, (dst, name, shape) in enumerate(self._slices):
+                p = params[name]
+                key = (p.data_ptr(), p._version)
+                if force or p.requires_grad or self._keys.get(k) != key:
+                    dst.copy_(p.detach().reshape(shape))
+                    self._keys[k] = key
+        return self.fwd
 
-def _versions(params: Dict[str, torch.Tensor]):
-    return tuple((p.data_ptr(), p._version) for p in params.values())
+    def _build(self, dims: VitDims, dev):
+        D = dims.hidden
+        kk = dims.channels * dims.patch * dims.patch
+        wpad = torch.zeros((D, dims.kpe), dtype=BF16, device=dev)
+        self.fwd = {"wpe": wpad, "layers": []}
+        self._slices = [(wpad[:, :kk], P + "embeddings.patch_embedding.weight", (D, kk))]
+        self._keys = {}
+        for i in range(dims.layers):
+            pre = f"{P}encoder.layers.{i}.self_attn."
+            w = torch.empty((3 * D, D), dtype=BF16, device=dev)
+            bq = torch.empty((3 * D,), dtype=BF16, device=dev)
+            for j, n in enumerate("qkv"):
+                self._slices.append((w[j * D:(j + 1) * D], pre + f"{n}_proj.weight", (D, D)))
+                self._slices.append((bq[j * D:(j + 1) * D], pre + f"{n}_proj.bias", (D,)))
+            self.fwd["layers"].append({"wqkv": w, "bqkv": bq})
 
 
 def pack_forward(params: Dict[str, torch.Tensor], dims: VitDims):
-    D = dims.hidden
-    out = {"layers": []}
-    wpe = params[P + "embeddings.patch_embedding.weight"].detach().reshape(D, -1)
-    wpad = torch.zeros((D, dims.kpe), dtype=BF16, device=wpe.device)
-    wpad[:, : wpe.shape[1]] = wpe
-    out["wpe"] = wpad
-    for i in range(dims.layers):
-        pre = f"{P}encoder.layers.{i}.self_attn."
-        out["layers"].append({
-            "wqkv": torch.cat([params[pre + f"{n}_proj.weight"].detach() for n in "qkv"], 0).contiguous(),
-            "bqkv": torch.cat([params[pre + f"{n}_proj.bias"].detach() for n in "qkv"], 0).contiguous(),
-        })
-    return out
+    return _Packed().get(params, dims)
 
 
 def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: VitDims, *, save: bool,
@@ -127,9 +146,20 @@ def _full(t: torch.Tensor, m_pad: int) -> torch.Tensor:
     return torch.as_strided(t, (m_pad, t.shape[1]), t.stride(), t.storage_offset())
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int) -> torch.Tensor:
-    """dW[N_out, K_in] = sum_m dY[m, N_out] X[m, K_in]: both operands are read token-major as they lie in HBM."""
-    return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True)
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int, name: Optional[str] = None) -> torch.Tensor:
+    """dW[N_out, K_in] = sum_m dY[m, N_out] X[m, K_in]: both operands are read token-major as they lie in HBM.
+    With a capturing data-parallel gradient store the GEMM writes straight into the parameter's bucket slot."""
+    return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True, out=dp.grad_out(name) if name else None)
+
+
+def emit_group(name: str, n_layers: int) -> int:
+    """Backward-order group of a parameter for the data-parallel bucket layout (dp.GradBuckets): the weight matrices of
+    encoder layer i are finished at step L-1-i of the backward; every bias / LayerNorm vector (one fp32 arena converted at
+    the end) and the embedding gradients come last."""
+    parts = name.split(".")
+    if "layers" in parts and name.endswith(("proj.weight", "fc1.weight", "fc2.weight")):
+        return n_layers - 1 - int(parts[parts.index("layers") + 1])
+    return n_layers
 
 
 def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims: VitDims,
@@ -176,7 +206,7 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
 
         # (Weight gradients used to run on a second stream; once the kernels were tuned that overlap measured as no gain -
         # 56.6 vs 56.5 ms/step - so the whole backward is one stream and per-launch timings mean what they say.)
-        grads[wname] = _wgrad(dy, x, m_pad)
+        grads[wname] = _wgrad(dy, x, m_pad, wname)
         if bslice is not None:
             K.colsum(dy, bslice)
 

@@ -327,3 +327,34 @@ def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_
         if signal is not None:
             signal = signal[:, :max_length]
     return ids.contiguous(), attention_mask.contiguous(), vi.contiguous(), signal
+
+
+def random_layer_state_dict(*, hidden: int = 4096, inter: int = 11008, rank: int = 8, down_ratio: int = 4, layer: int = 0,
+                            seed: int = 5, dtype=torch.bfloat16, bridge_b_std: float = 0.3) -> Dict[str, torch.Tensor]:
+    """Random weights of ONE LibraDecoderLayer under the reference's state-dict keys, fan-in scaled so that
+    activations stay O(1); bridge weight_B is drawn non-zero (zero-initialised upstream, modeling_libra.py:184) so the
+    bridge path is numerically live.  Used by the full-width parity tests and bench.py's CPU baseline."""
+    g = torch.Generator().manual_seed(seed)
+    H, I, r, rg = hidden, inter, hidden // down_ratio, inter // down_ratio
+    sd: Dict[str, torch.Tensor] = {}
+
+    def rn(*shape, std):
+        return (torch.randn(*shape, generator=g) * std).to(dtype)
+    p = f"model.layers.{layer}."
+    for n in ("q", "k", "v", "o"):
+        sd[p + f"self_attn.{n}_proj.weight"] = rn(H, H, std=H ** -0.5)
+        sd[p + f"self_attn.vision_{n}_proj.weight_A"] = rn(r, H, std=H ** -0.5)
+        sd[p + f"self_attn.vision_{n}_proj.weight_B"] = rn(H, r, std=r ** -0.5)
+    for kv in ("k", "v"):
+        for w in ("language", "vision"):
+            sd[p + f"self_attn.vision_{kv}_bridge_on_{w}.weight_A"] = rn(rank, H, std=H ** -0.5)
+            sd[p + f"self_attn.vision_{kv}_bridge_on_{w}.weight_B"] = rn(H, rank, std=bridge_b_std)
+    sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = rn(I, H, std=H ** -0.5), rn(I, H, std=H ** -0.5)
+    sd[p + "mlp.down_proj.weight"] = rn(H, I, std=I ** -0.5)
+    for n in ("gate", "up"):
+        sd[p + f"mlp.vision_{n}_proj.weight_A"] = rn(rg, H, std=H ** -0.5)
+        sd[p + f"mlp.vision_{n}_proj.weight_B"] = rn(I, rg, std=rg ** -0.5)
+    sd[p + "mlp.vision_down_proj.weight_A"], sd[p + "mlp.vision_down_proj.weight_B"] = rn(r, I, std=I ** -0.5), rn(H, r, std=r ** -0.5)
+    for n in ("input_layernorm", "post_attention_layernorm", "vision_input_layernorm", "vision_post_attention_layernorm"):
+        sd[p + n + ".weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
+    return sd

@@ -27,3 +27,68 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.double()
     b = b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def word_level_tokenizer(words, model_max_length=64):
+    """A real HF `PreTrainedTokenizerFast` (word-level model built in memory) standing in for the LLaMA sentencepiece
+    tokenizer, which does not exist offline: ids 0..2 = <unk>, <s>, </s> like LLaMA; BOS is prepended like
+    LlamaTokenizerFast's post-processor does."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    for w in words:
+        vocab.setdefault(w, len(vocab))
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tk.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 1)])
+    return PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="<unk>", bos_token="<s>", eos_token="</s>",
+                                   model_max_length=model_max_length, padding_side="right")
+
+
+class FakeImageTokenizer:
+    """Image-tokenizer stand-in returning prebuilt ids / features (fixture-driven tests of the tensor assembly)."""
+
+    def __init__(self, image_ids, feat, boi, L, Q, device="cpu", dtype=None):
+        import torch
+        self.image_ids, self.feat = image_ids.to(device), feat.to(device)
+        self.boi_token_id, self.eoi_token_id, self.max_vision_token_length, self.num_codebook = boi, boi + 1, L, Q
+        self.device, self.dtype = torch.device(device), dtype or feat.dtype
+
+    def __call__(self, images):
+        return {"input_ids": self.image_ids.clone(), "encoder_feat": self.feat.clone()}
+
+    def get_token_length(self, images):
+        return self.max_vision_token_length
+
+
+class FakeTextTokenizer:
+    """Text-tokenizer stand-in returning prebuilt ids (the fixtures' text ids were built by hand: no sentencepiece model)."""
+    bos_token_id, eos_token_id, pad_token_id, unk_token = 1, 2, 0, "<unk>"
+
+    def __init__(self, ids, am, vocab_size, ph, gen, model_max_length):
+        self.ids, self.am, self.vocab_size, self.model_max_length = ids, am, vocab_size, model_max_length
+        self._ph, self._gen = ph, gen
+
+    def add_tokens(self, t):
+        return 1
+
+    def convert_tokens_to_ids(self, t):
+        return {"<img_ph>": self._ph, "<img_gen>": self._gen}[t]
+
+    def __call__(self, texts, return_tensors="pt", return_length=True, **kw):
+        from transformers import BatchEncoding
+        return BatchEncoding({"input_ids": self.ids.clone(), "attention_mask": self.am.clone(), "length": self.am.sum(1)})
+
+
+def torch_adamw_update(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2,
+                       grad_scale=1.0):
+    """Plain-torch statement of `libra_adamw_step` (torch.optim.AdamW's arithmetic on an fp32 master): the checker for the
+    HIP kernel, and the `update_fn` the CPU (gloo) tests inject into dp.FlatAdamW - the product has no CPU optimizer."""
+    import math
+    g = grad.float() * grad_scale
+    master.mul_(1.0 - lr * weight_decay)
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    denom = v.sqrt() / math.sqrt(bias_corr2) + eps
+    master.addcdiv_(m, denom, value=-lr / bias_corr1)
+    param.copy_(master)

@@ -141,8 +141,10 @@ def test_libra_full_width_single_layer_vs_oracle():
 
 def test_libra_backward_emits_trainable_gradients_to_a_capturing_reducer():
     """Same contract as the ViT test for the decoder under the pretraining freeze policy: only the trainable
-    ("vision") gradients are exchanged, all of them leave during the backward, results equal the plain backward."""
-    from libra_amd.dp import BucketedGradReducer
+    ("vision") gradients are exchanged, all of them leave during the backward (weight-gradient GEMMs writing straight into
+    the flat buckets), results equal the plain backward; a second step reuses the buckets."""
+    from libra_amd import decoder_engine as DE
+    from libra_amd import dp
     from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy
     t, meta = load_golden("libra_tiny.safetensors")
     m = LibraForCausalLM(LibraConfig(**meta["cfg"]))
@@ -153,19 +155,50 @@ def test_libra_backward_emits_trainable_gradients_to_a_capturing_reducer():
               vision_indices=t["in.vision_indices"].cuda(), contiguous_signal=t["in.signal"].to(BF).cuda(),
               labels=t["in.labels"].cuda())
     m(**kw).loss.backward()
-    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad and n != "vision_hidden_placeholder"]
     plain = {n: p.grad.clone() for n, p in named if p.grad is not None}
-    assert plain and all("vision" in n for n in plain)
+    assert plain and all("vision" in n for n in plain) and set(plain) == {n for n, _ in named}
     m.zero_grad(set_to_none=True)
-    red = BucketedGradReducer(bucket_bytes=1 << 14, only={n for n, _ in named})
-    with red.capture():
-        m(**kw).loss.backward()
-    captured = set(red.seen)
-    red.finish_into(named)
-    assert captured == set(plain), set(plain) ^ captured
-    for n, p in named:
-        if n in plain:
+    L = meta["cfg"]["num_hidden_layers"]
+    st = dp.GradBuckets(named, bucket_bytes=1 << 14, group_fn=lambda n: DE.emit_group(n, L))
+    for _ in range(2):
+        with st.capture():
+            m(**kw).loss.backward()
+        captured, sent = set(st._seen), st._next
+        st.finish_into(named)
+        assert captured == set(plain), set(plain) ^ captured
+        assert sent == len(st.buckets)                     # every bucket left while the backward was running
+        for n, p in named:
             assert torch.equal(p.grad, plain[n]), n
+            assert p.grad.data_ptr() == st.view(n).data_ptr()
+
+
+def test_libra_text_only_batch_emits_zero_vision_gradients():
+    """a micro-batch without a single vision token must still produce (zero) gradients for every trainable
+    vision parameter - the reference runs the vision modules on empty tensors and autograd yields zeros - so that all
+    data-parallel ranks exchange the same buckets; text parameters get their usual gradients."""
+    from libra_amd.libra import LibraConfig, LibraForCausalLM
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    m = LibraForCausalLM(LibraConfig(**c))
+    m.load_state_dict(sub(t, "w."), strict=True)
+    m = m.to(BF).cuda()
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, c["vocab_size"], (1, 2, 12), generator=g).repeat(2, 1, 1).cuda()
+    ids[:, :, 0] = 1
+    vi = torch.full((2, 12), c["max_vision_token_length"], dtype=torch.long).cuda()
+    labels = ids.clone(); labels[:, :, 0] = -100
+    out = m(input_ids=ids, attention_mask=torch.ones(2, 12, dtype=torch.long).cuda(), vision_indices=vi, contiguous_signal=None,
+            labels=labels)
+    assert torch.isfinite(out.loss)
+    out.loss.backward()
+    for n, p in m.named_parameters():
+        if n == "vision_hidden_placeholder":
+            assert p.grad is None
+        elif "vision" in n:
+            assert p.grad is not None and float(p.grad.float().abs().max()) == 0.0, n
+        else:
+            assert p.grad is not None and float(p.grad.float().abs().max()) > 0.0, n
 
 
 def test_libra_tiny_cached_decode_vs_reference_fixture():

@@ -1,118 +1,227 @@
-"""world_size-2 gloo test of the bucketed gradient all-reduce used by the data-parallel path."""
+"""world_size-2 gloo tests (CPU) of the data-parallel gradient store (fixed flat buckets; all-reduce / reduce-scatter +
+all-gather / ZeRO-1 modes), gradient accumulation, the rank-with-a-missing-modality case, and the sharded AdamW step."""
 import os
 import socket
+import sys
 
+import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from libra_amd.dp import BucketedGradReducer
-    g = torch.Generator().manual_seed(100 + rank)
-    grads_a = {f"l1.p{i}": torch.randn(33 + i, 7, generator=g) for i in range(5)}
-    grads_b = {f"l0.p{i}": torch.randn(1000, generator=g) for i in range(3)}
-    red = BucketedGradReducer(bucket_bytes=4096)
-    red.add(grads_a)          # "layer 1" grads arrive first (backward order)
-    red.add(grads_b)
-    out = red.finish()
-    # numpy payloads are pickled by value (torch tensors would travel as shared-memory handles that die with the child)
-    q.put((rank, {k: v.numpy().copy() for k, v in out.items()},
-           {k: v.numpy().copy() for k, v in {**grads_a, **grads_b}.items()}, red.bytes_reduced))
-    dist.destroy_process_group()
-
-
-def _worker_capture(rank, world, port, q):
-    """The overlap path: a fake 3-layer backward emits each layer's gradients through libra_amd.dp.emit_new (what the
-    engines do), one parameter lives outside the engine (picked up by finish_into), one emitted name is frozen."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from libra_amd import dp
-    gen = torch.Generator().manual_seed(7 + rank)
-    params = {f"layers.{i}.w": torch.nn.Parameter(torch.zeros(50, 9)) for i in range(3)}
-    params["outside.b"] = torch.nn.Parameter(torch.zeros(11))
-    local = {n: torch.randn(p.shape, generator=gen) for n, p in params.items()}
-    red = dp.BucketedGradReducer(bucket_bytes=2048, only=set(params))
-    launches = []
-    with red.capture():
-        g, seen = {}, set()
-        for i in (2, 1, 0):                         # backward order
-            g[f"layers.{i}.w"] = local[f"layers.{i}.w"]
-            g[f"layers.{i}.frozen"] = torch.ones(3)  # not in `only`: never exchanged
-            dp.emit_new(g, seen)
-            launches.append(red.launches)
-    dp.emit({"late": torch.ones(2)})                 # outside the capture: a no-op
-    for n, p in params.items():
-        p.grad = local[n].clone()                    # what autograd would have installed
-    red.finish_into(params.items())
-    q.put((rank, {n: p.grad.detach().numpy().copy() for n, p in params.items()},
-           {n: v.numpy().copy() for n, v in local.items()}, launches))
-    dist.destroy_process_group()
-
-
-def test_capture_overlap_world2():
+def _run(worker, world=2, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker_capture, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=worker, args=(r, world, port, q, *args)) for r in range(world)]
     [p.start() for p in ps]
-    res = [q.get(timeout=120) for _ in range(2)]
+    res = [q.get(timeout=180) for _ in range(world)]
     [p.join(60) for p in ps]
     res.sort(key=lambda t: t[0])
-    (_, g0, l0, launches), (_, g1, l1, _) = res
-    import numpy as np
-    assert set(g0) == {"layers.0.w", "layers.1.w", "layers.2.w", "outside.b"}
+    return res
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, HERE)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _params():
+    shapes = {f"layers.{i}.w": (50, 9) for i in range(3)}
+    shapes.update({"layers.1.norm": (37,), "head.w": (20, 9), "embed.w": (13, 9)})
+    return {n: torch.nn.Parameter(torch.zeros(s)) for n, s in shapes.items()}
+
+
+def _group(n):            # backward order: head first, layers 2..0, embeddings last
+    return 0 if n.startswith("head") else (4 if n.startswith("embed") else 3 - int(n.split(".")[1]))
+
+
+def _np(d):
+    # numpy payloads are pickled by value (torch tensors would travel as shared-memory handles that die with the child)
+    return {k: v.detach().float().numpy().copy() for k, v in d.items()}
+
+
+def _worker_modes(rank, world, port, q, mode):
+    _init(rank, world, port)
+    from libra_amd import dp
+    params = _params()
+    gen = torch.Generator().manual_seed(100 + rank)
+    local = {n: torch.randn(p.shape, generator=gen) for n, p in params.items()}
+    st = dp.GradBuckets(params.items(), bucket_bytes=2048, group_fn=_group, mode=mode, dtype=torch.float32)
+    launches = []
+    with st.capture():
+        g, seen = {}, set()
+        g["head.w"] = local["head.w"]; dp.emit_new(g, seen); launches.append(st.launches)
+        for i in (2, 1, 0):
+            out = dp.grad_out(f"layers.{i}.w")              # the direct-write path the wgrad GEMMs use
+            out.copy_(local[f"layers.{i}.w"]); g[f"layers.{i}.w"] = out
+            g[f"layers.{i}.frozen"] = torch.ones(3)         # not a bucket member: never exchanged
+            if i == 1:
+                g["layers.1.norm"] = local["layers.1.norm"]
+            dp.emit_new(g, seen); launches.append(st.launches)
+        g["embed.w"] = local["embed.w"]; dp.emit_new(g, seen)
+    dp.emit({"late": torch.ones(2)})                        # outside the capture: a no-op
+    assert dp.grad_out("layers.0.w") is None
+    st.finish_into(params.items())
+    layout = [(b.names, b.flat.numel()) for b in st.buckets]
+    q.put((rank, _np({n: p.grad for n, p in params.items()}), _np(local), launches, layout, st.bytes_exchanged))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_capture_overlap_world2(mode):
+    (_, g0, l0, launches, lay0, nbytes), (_, g1, l1, _, lay1, _) = _run(_worker_modes, 2, mode)
+    assert set(g0) == set(l0) and lay0 == lay1                           # rank-independent layout
     for k in g0:
         assert np.allclose(g0[k], (l0[k] + l1[k]) / 2, atol=1e-6), k
         assert np.array_equal(g0[k], g1[k]), k
-    assert launches == [0, 1, 1] or launches[-1] >= 1      # 1800-B layers against 2048-B buckets: one left mid-backward
+    assert launches[-1] >= 2 and launches[0] <= launches[-1]             # buckets went out during the "backward"
+    assert nbytes > 0
 
 
-def test_reducer_rejects_double_add_and_nested_capture():
-    import pytest
-    from libra_amd.dp import BucketedGradReducer
-    red = BucketedGradReducer()
-    red.add({"a": torch.ones(2)})
-    with pytest.raises(ValueError):
-        red.add({"a": torch.ones(2)})
-    with red.capture():
+def _worker_missing(rank, world, port, q):
+    """Rank 1's micro-batch has no vision token: its engine emits nothing for the 'vision' members (or zero gradients) -
+    both ranks must still run identical collectives and the result is the mean with zeros."""
+    _init(rank, world, port)
+    from libra_amd import dp
+    params = _params()
+    gen = torch.Generator().manual_seed(5 + rank)
+    local = {n: torch.randn(p.shape, generator=gen) for n, p in params.items()}
+    st = dp.GradBuckets(params.items(), bucket_bytes=1024, group_fn=_group, dtype=torch.float32)
+    for b in st.buckets:
+        b.flat.fill_(7.0)                                   # stale contents of an earlier step must not leak
+    with st.capture():
+        g, seen = {}, set()
+        for n in sorted(local, key=_group):
+            if rank == 1 and n in ("layers.1.w", "layers.1.norm"):
+                continue                                    # never emitted on this rank
+            g[n] = local[n]
+            dp.emit_new(g, seen)
+    out = st.finish()
+    q.put((rank, _np(out), _np(local)))
+    dist.destroy_process_group()
+
+
+def test_rank_with_missing_gradients_world2():
+    (_, g0, l0), (_, g1, l1) = _run(_worker_missing, 2)
+    for k in g0:
+        want = (l0[k] + (0 if k in ("layers.1.w", "layers.1.norm") else l1[k])) / 2
+        assert np.allclose(g0[k], want, atol=1e-6), k
+        assert np.array_equal(g0[k], g1[k]), k
+
+
+def _worker_accum(rank, world, port, q):
+    _init(rank, world, port)
+    from libra_amd import dp
+    params = _params()
+    gen = torch.Generator().manual_seed(50 + rank)
+    micro = [{n: torch.randn(p.shape, generator=gen) for n, p in params.items()} for _ in range(3)]
+    st = dp.GradBuckets(params.items(), bucket_bytes=2048, group_fn=_group, dtype=torch.float32)
+    for k, loc in enumerate(micro):
+        with st.capture(sync=(k == 2)):
+            g, seen = {}, set()
+            for n in sorted(loc, key=_group):
+                out = dp.grad_out(n)
+                assert (out is None) == (k > 0)             # direct writes only into an empty bucket
+                g[n] = loc[n] if out is None else out.copy_(loc[n])
+                dp.emit_new(g, seen)
+        st.finish_into(params.items())
+        assert st.launches == (0 if k < 2 else len(st.buckets))
+    tot = {n: sum(m[n] for m in micro) for n in params}
+    q.put((rank, _np({n: p.grad for n, p in params.items()}), _np(tot)))
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_world2():
+    """libra_pretrain.yaml:96 gradient_accumulation_steps: micro-steps add into the buckets, only the last one communicates."""
+    (_, g0, t0), (_, g1, t1) = _run(_worker_accum, 2)
+    for k in g0:
+        assert np.allclose(g0[k], (t0[k] + t1[k]) / 2, atol=1e-5), k
+        assert np.array_equal(g0[k], g1[k]), k
+
+
+def _worker_zero1(rank, world, port, q, mode):
+    _init(rank, world, port)
+    from helpers import torch_adamw_update
+    from libra_amd import dp
+    torch.manual_seed(3)
+    params = {n: torch.nn.Parameter(torch.randn(p.shape).to(torch.bfloat16)) for n, p in _params().items()}
+    ref = {n: p.detach().float().clone().requires_grad_(True) for n, p in params.items()}
+    nodecay = [n for n, p in params.items() if p.ndim < 2]
+    opt_ref = torch.optim.AdamW([{"params": [ref[n] for n in ref if n not in nodecay], "weight_decay": 0.1},
+                                 {"params": [ref[n] for n in nodecay], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    st = dp.GradBuckets(params.items(), bucket_bytes=2048, group_fn=_group, mode=mode)
+    opt = dp.FlatAdamW(st, params.items(), lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1,
+                       update_fn=torch_adamw_update)
+    for step in range(3):
+        gens = [torch.Generator().manual_seed(1000 * step + r) for r in range(world)]
+        allg = [{n: torch.randn(p.shape, generator=gens[r]).to(torch.bfloat16) for n, p in params.items()} for r in range(world)]
+        with st.capture():
+            g, seen = {}, set()
+            for n in sorted(params, key=_group):
+                g[n] = allg[rank][n]
+                dp.emit_new(g, seen)
+        st.finish()
+        opt.step()
+        for n in ref:                                       # the unsharded expectation: mean of the bf16 gradients, fp32 AdamW
+            ref[n].grad = (sum(a[n].float() for a in allg) / world).to(torch.bfloat16).float()
+        opt_ref.step()
+    state_elems = sum(s["master"].numel() for s in opt.state)
+    q.put((rank, _np(params), _np({n: r.detach().to(torch.bfloat16) for n, r in ref.items()}), state_elems,
+           sum(b.flat.numel() for b in st.buckets)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["zero1", "allreduce"])
+def test_sharded_adamw_equals_unsharded_world2(mode):
+    """Row e2: reduce-scatter -> AdamW on the rank's fp32-master shard -> all-gather of the bf16 parameters equals an
+    unsharded fp32-master AdamW on the averaged gradients, on every rank, after 3 steps; state is 1/W per rank."""
+    (_, p0, r0, ne0, tot), (_, p1, r1, ne1, _) = _run(_worker_zero1, 2, mode)
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k                            # ranks agree bit for bit
+        assert np.allclose(p0[k], r0[k], atol=0, rtol=2 ** -7), k          # vs the reference: <= 1 bf16 ulp
+        assert np.mean(p0[k] == r0[k]) > 0.98, k
+    assert (ne0 == tot // 2 and ne1 == tot // 2) if mode == "zero1" else ne0 == tot
+
+
+def test_store_rejects_double_add_and_nested_capture():
+    from libra_amd import dp
+    params = _params()
+    st = dp.GradBuckets(params.items(), bucket_bytes=1 << 20, dtype=torch.float32)
+    with st.capture():
+        st.add({"head.w": torch.ones(20, 9)})
+        with pytest.raises(ValueError):
+            st.add({"head.w": torch.ones(20, 9)})
+        with pytest.raises(ValueError):
+            st.add({"embed.w": torch.ones(3)})              # wrong element count
         with pytest.raises(RuntimeError):
-            with BucketedGradReducer().capture():
+            with dp.GradBuckets(params.items(), dtype=torch.float32).capture():
                 pass
-    red.finish()
-    red.add({"a": torch.ones(2)})                   # a new step may reuse the names
+    st.finish()
+    with st.capture():
+        st.add({"head.w": torch.ones(20, 9)})               # a new step may reuse the names
+    with pytest.raises(ValueError):
+        dp.GradBuckets(params.items(), mode="ring")
 
 
-def test_bucketed_allreduce_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in ps]
-    res = [q.get(timeout=120) for _ in range(2)]
-    [p.join(60) for p in ps]
-    res.sort(key=lambda t: t[0])
-    (_, out0, loc0, nbytes), (_, out1, loc1, _) = res
-    assert set(out0) == set(loc0)
-    import numpy as np
-    for k in out0:
-        mean = (loc0[k] + loc1[k]) / 2
-        assert np.allclose(out0[k], mean, atol=1e-6), k
-        assert np.array_equal(out0[k], out1[k]), k
-        assert out0[k].shape == loc0[k].shape
-    assert nbytes == sum(v.size * 4 for v in loc0.values())
-
-
-def test_single_process_passthrough():
-    from libra_amd.dp import BucketedGradReducer
-    red = BucketedGradReducer(bucket_bytes=64)
-    g = {"a": torch.arange(10.0), "b": torch.ones(3, 3)}
-    red.add(g)
-    out = red.finish()
-    assert torch.equal(out["a"], g["a"]) and torch.equal(out["b"], g["b"])
+def test_single_process_passthrough_and_alignment():
+    from libra_amd import dp
+    params = _params()
+    st = dp.GradBuckets(params.items(), bucket_bytes=256, group_fn=_group, dtype=torch.float32)
+    g = {n: torch.randn(p.shape) for n, p in params.items()}
+    with st.capture():
+        st.add(g)
+    out = st.finish()
+    for n in g:
+        assert torch.equal(out[n], g[n]) and out[n].shape == params[n].shape
+        assert out[n].data_ptr() % 128 == 0 or out[n].storage_offset() % dp.ALIGN == 0
+    assert [b.names for b in st.buckets][0] == ["head.w"] and st.buckets[-1].names[-1] == "embed.w"

@@ -91,3 +91,84 @@ def test_kv_cache_container_and_reorder():
         for bi, buf in enumerate(layer):
             assert torch.equal(buf[:, 0, 0].float(), beam.float() + 8 * li + 32 * bi)
     assert torch.equal(c.flag[:, 0], beam.to(torch.uint8))
+
+
+def test_libra_tokenizer_module_matches_reference_fixture():
+    """a11 / §8b: the LibraTokenizer nn.Module surface (.text_tokenizer, .image_tokenizer.*, .device, .dtype, forward(samples))
+    reproduces the tensors of the reference's own LibraTokenizer.forward (fixture made by make_golden_libra.py)."""
+    from helpers import FakeImageTokenizer, FakeTextTokenizer
+    from libra_amd.libra import LibraTokenizer
+    t, meta = load_golden("libra_tokenizer_assembly.safetensors")
+    tok = LibraTokenizer(text_tokenizer=FakeTextTokenizer(t["in.text_ids"], t["in.attention_mask"], 96, meta["img_ph"],
+                                                          meta["img_gen"], meta["max_length"]),
+                         image_tokenizer=FakeImageTokenizer(t["in.image_ids"], t["in.encoder_feat"], meta["boi"], meta["L"],
+                                                            meta["Q"]), raw_output=True)
+    assert isinstance(tok, torch.nn.Module) and tok.device == torch.device("cpu") and tok.dtype == torch.float32
+    assert tok.image_tokenizer_offset == 96 and tok.num_codebook == 2 and tok.img_indices_ph.shape == (1, meta["L"])
+    assert tok.text_tokenizer.img_ph_token_id == meta["img_ph"] and tok.image_tokenizer.boi_token_id == meta["boi"]
+    samples = [{"language": c, "vision": torch.zeros(3, 8, 8), "contiguous_ignore_sign": s}
+               for c, s in zip("abc", meta["ignore"])]
+    out = tok(samples, padding="longest", truncation=True, max_length=meta["max_length"])
+    for k_out, k_ref in (("input_ids", "out.input_ids"), ("attention_mask", "out.attention_mask"),
+                         ("vision_indices", "out.vision_indices"), ("coninous_signal", "out.signal")):
+        assert torch.equal(out[k_out], t[k_ref]), k_out
+    # the collated-dict form LibraTrainWrapper.forward passes (one dict of lists) gives the same tensors
+    out2 = tok({"language": list("abc"), "vision": [torch.zeros(3, 8, 8)] * 3, "contiguous_ignore_sign": meta["ignore"]},
+               padding="longest", truncation=True, max_length=meta["max_length"])
+    assert all(torch.equal(out[k], out2[k]) for k in out)
+
+
+def test_libra_tokenizer_with_a_real_hf_text_tokenizer():
+    """Same module around a real PreTrainedTokenizerFast: <img_ph>/<img_gen> are added as tokens (tokenization_libra.py:137-141),
+    padding='longest' pads right with the unk id, BatchEncoding comes back, <img_gen> becomes BOI with vision index 0 (:275)."""
+    from helpers import FakeImageTokenizer, word_level_tokenizer
+    from libra_amd.libra import LibraTokenizer
+    L, Q, Cs = 6, 2, 8
+    words = "a cute dog and cat i like them".split()
+    tt = word_level_tokenizer(words)
+    V = tt.vocab_size
+    g = torch.Generator().manual_seed(0)
+    boi = V + 16
+    image_ids = torch.stack([torch.cat([torch.full((2, 1), boi), V + torch.randint(0, 16, (2, 4), generator=g),
+                                        torch.full((2, 1), boi + 1)], 1) for _ in range(Q)])
+    feat = torch.randn(2, 4, Cs, generator=g)
+    tok = LibraTokenizer(text_tokenizer=tt, image_tokenizer=FakeImageTokenizer(image_ids, feat, boi, L, Q))
+    ph = " ".join(["<img_ph>"] * L)
+    samples = {"language": [f"a cute dog {ph} and", f"{ph} i like them a cat"], "vision": [torch.zeros(3, 8, 8)] * 2,
+               "contiguous_ignore_sign": [False, False]}
+    out = tok(samples, padding="longest", truncation=True, max_length=32)
+    from transformers import BatchEncoding
+    assert isinstance(out, BatchEncoding)
+    ids, am, vi, sig = out["input_ids"], out["attention_mask"], out["vision_indices"], out["coninous_signal"]
+    assert ids.shape == (Q, 2, 12) and am.tolist() == [[1] * 11 + [0], [1] * 12]
+    assert ids[0, 0, 0] == 1 and ids[0, 0, 11] == tt.pad_token_id == 0                 # BOS first, unk-id right padding
+    assert torch.equal(ids[:, 0, 4:10], image_ids[:, 0]) and torch.equal(ids[:, 1, 1:7], image_ids[:, 1])
+    assert vi[0].tolist() == [L] * 4 + list(range(L)) + [L, L] and vi[1].tolist() == [L] + list(range(L)) + [L] * 5
+    assert torch.equal(sig[0, 5:9], feat[0]) and float(sig[0, 4].abs().sum() + sig[0, 9].abs().sum()) == 0.0
+    gen = tok({"language": ["a dog <img_gen>"]}, padding="longest")
+    assert gen["input_ids"][:, 0, -1].tolist() == [boi, boi] and gen["vision_indices"][0].tolist() == [L, L, L, 0]
+    assert gen["coninous_signal"] is None
+
+
+def test_registry_and_wrapper_surface():
+    """train.py:29-30: registry.get_model_class('libra_train_wrapper').from_config(cfg); trainer.py:3 imports LlamaRMSNorm from
+    the llama package; LibraConfig is a LlamaConfig; gradient_checkpointing_enable() works (libra_pretrain.yaml:120)."""
+    from libra_amd.common.registry import registry
+    from libra_amd.libra import LibraConfig, LibraForCausalLM, LibraTrainWrapper
+    from libra_amd.llama import LlamaConfig
+    from libra_amd.llama.modeling_llama import LlamaRMSNorm
+    assert registry.get_model_class("libra_train_wrapper") is LibraTrainWrapper and hasattr(LibraTrainWrapper, "from_config")
+    assert issubclass(LibraConfig, LlamaConfig)
+    cfg = LibraConfig(vocab_size=96, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                      max_position_embeddings=64, vision_vocab_size=18, max_vision_token_length=6, contiguous_signal_size=64)
+    m = LibraForCausalLM(cfg)
+    assert isinstance(m.model.norm, LlamaRMSNorm)
+    m.gradient_checkpointing_enable()
+    assert m.model.gradient_checkpointing is True
+    m.gradient_checkpointing_disable()
+    assert m.model.gradient_checkpointing is False
+    import pytest
+    with pytest.raises(RuntimeError, match="only owns parameters"):
+        m.model.layers[0](torch.zeros(1))
+    with pytest.raises(NotImplementedError, match="dropout"):
+        LibraForCausalLM(LibraConfig(**{**cfg.to_dict(), "resid_pdrop": 0.1}))
