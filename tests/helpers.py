@@ -92,3 +92,17 @@ def torch_adamw_update(master, m, v, grad, param, *, lr, beta1, beta2, eps, weig
     denom = v.sqrt() / math.sqrt(bias_corr2) + eps
     master.addcdiv_(m, denom, value=-lr / bias_corr1)
     param.copy_(master)
+
+
+def parity_report(line: str):
+    """Append one line to the parity report of this GPU visit (gpurun_out/parity_report.txt; copied to profiles/rNN_parity.txt
+    by the builder): the measured ours / theirs numbers behind the tolerance floors, per config."""
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line.rstrip() + "\n")
+    except OSError:
+        pass
+    print(line)
