@@ -180,17 +180,17 @@ int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, co
  * of valid cached tokens including the new one; scale = 1/sqrt(128).                                                       */
 int libra_bridge_attn_decode(const void* q, int64_t ldq, const void* k_same, const void* k_cross, const void* v_same,
                              const void* v_cross, int64_t ldc, int64_t batch_stride, const uint8_t* key_flag,
-                             int64_t flag_stride, const uint8_t* query_flag, const int* kv_len, void* out, int64_t ldo,
-                             int64_t B, int64_t H, float scale, void* stream);
+                             int64_t flag_stride, const uint8_t* query_flag, const int* kv_len, const int* kv_start,
+                             void* out, int64_t ldo, int64_t B, int64_t H, float scale, void* stream);
 /* Fused routed-bridge causal flash attention, forward (LibraAttention.forward + attn_with_bridge,
- * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right-padding via
- * kv_len[b]), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row
+ * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right padding via
+ * kv_len[b] = end of the valid keys, +left padding via kv_start[b] = first valid key; either may be NULL), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row
  * strides ldq/ldk/ldkc/ldv/ldvc; flag [B*S] (1 = vision token); out [B*S, H*128]; lse [B,H,S] fp32 optional.      */
 int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                           int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                           const uint8_t* flag,
-                          const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
-                          int64_t H, float scale, void* stream);
+                          const int32_t* kv_len, const int32_t* kv_start, void* out, int64_t ldo, float* lse, int64_t B,
+                          int64_t S, int64_t H, float scale, void* stream);
 /* Backward of libra_bridge_attn_fwd (deterministic, two passes): from dO and the forward's operands / lse produce
  * dq [B*S,H*128] (w.r.t. the rotated q) and the four operand gradients dK_same, dK_cross, dV_same, dV_cross
  * ([B*S, H*128], row stride ldg).  `out` is the forward output (for D = rowsum(dO*O)); delta [B,H,S] is scratch.  */

@@ -43,8 +43,8 @@ SIGNATURES = {
     "libra_rmsnorm_routed_fwd": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _F, _P],
     "libra_rope_bridge": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "libra_rope_bridge_pos": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _P],
-    "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _F, _P],
-    "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
+    "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
+    "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
     "libra_bridge_attn_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
                               _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
     "libra_swiglu": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],

@@ -32,7 +32,8 @@ struct BridgeArgs {
     const bf16_t* k_same; const bf16_t* k_cross; long ldk, ldkc;
     const bf16_t* v_same; const bf16_t* v_cross; long ldv, ldvc;
     const unsigned char* flag;     // [B*S] 1 = vision token
-    const int* kv_len;             // [B] valid (non-padded) length, right padding
+    const int* kv_len;             // [B] end of the valid keys (right padding), or null
+    const int* kv_start;           // [B] first valid key (LEFT padding: generation prompts, demo/libra_demo.ipynb), or null
     bf16_t* out; long ldo;
     float* lse;                    // [B,H,S] or null
     int B, S, H, n_qt;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     const int S = p.S;
     const long tok0 = (long)b * S;
     const int len = p.kv_len ? p.kv_len[b] : S;
+    const int start = p.kv_start ? p.kv_start[b] : 0;
     const int q0w = qt * BQ + wave * 32;
     const bool active = q0w < S;
     int q = q0w + l31;
@@ -238,13 +240,16 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
                 crB |= (cb ? 1u : 0u) << r;
             }
         }
-        if (kv0 + BKV - 1 > q0w || kv0 + BKV > len) {               // causal diagonal / padded keys inside this tile
+        if (kv0 + BKV - 1 > q0w || kv0 + BKV > len || kv0 < start) {   // causal diagonal / padded keys inside this tile
             const int qabs = q0w + l31;
+            // left padding: keys before `start` are masked for real queries; a padding QUERY row keeps them (its output is
+            // never used, but an all-masked row would be NaN and 0 x NaN would leak through P.V of later rows' tiles)
+            const int lo = qabs < start ? 0 : start;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                sA[r] = (key <= qabs && key < len) ? sA[r] : -INFINITY;
-                sB[r] = (key + 32 <= qabs && key + 32 < len) ? sB[r] : -INFINITY;
+                sA[r] = (key <= qabs && key < len && key >= lo) ? sA[r] : -INFINITY;
+                sB[r] = (key + 32 <= qabs && key + 32 < len && key + 32 >= lo) ? sB[r] : -INFINITY;
             }
         }
         // ---- online softmax; the running max only advances when a tile exceeds it by 2^DEFER_THR ----
@@ -340,8 +345,8 @@ using namespace libra;
 extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                                      int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                                      const uint8_t* flag,
-                                     const int32_t* kv_len, void* out, int64_t ldo, float* lse, int64_t B, int64_t S,
-                                     int64_t H, float scale, void* stream) {
+                                     const int32_t* kv_len, const int32_t* kv_start, void* out, int64_t ldo, float* lse,
+                                     int64_t B, int64_t S, int64_t H, float scale, void* stream) {
     if (B <= 0 || S <= 0) return LIBRA_OK;
     if (H <= 0 || ldq < H * BD || ldk < H * BD || ldv < H * BD || ldkc < H * BD || ldvc < H * BD || ldo < H * BD || S > 4096 ||
         ldk >= (1 << 18) || ldkc >= (1 << 18) || ldv >= (1 << 18) || ldvc >= (1 << 18))
@@ -353,7 +358,7 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     BridgeArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.k_cross = (const bf16_t*)k_cross; a.ldk = ldk; a.ldkc = ldkc;
     a.v_same = (const bf16_t*)v_same; a.v_cross = (const bf16_t*)v_cross; a.ldv = ldv; a.ldvc = ldvc;
-    a.flag = flag; a.kv_len = kv_len; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
+    a.flag = flag; a.kv_len = kv_len; a.kv_start = kv_start; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.n_qt = (int)((S + BQ - 1) / BQ);
     a.sl2 = scale * 1.4426950408889634f;
     const long nblk = (long)B * H * a.n_qt;

@@ -19,7 +19,8 @@ struct DecodeArgs {
     long ldc, bstride;                               // row stride, batch stride (elements)
     const unsigned char* kflag; long fstride;        // [B, Lmax] modality of every cached token
     const unsigned char* qflag;                      // [B] modality of the query token
-    const int* lens;                                 // [B] number of valid cached tokens (the new one included)
+    const int* lens;                                 // [B] end of the valid cached tokens (the new one included)
+    const int* starts;                               // [B] first valid cached token (left-padded prompts), or null
     bf16_t* out; long ldo;                           // [B, H*128]
     int H; float sl2;                                // scale * log2(e)
 };
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void bridge_attn_decode_kernel(const DecodeArg
     float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j = grp; j < len; j += 16) {
+    for (int j = (p.starts ? p.starts[b] : 0) + grp; j < len; j += 16) {
         const bool cross = (fl[j] != 0) != (mq != 0);
         const long off = base + (long)j * p.ldc;
         float kf[8], vf[8];
@@ -85,8 +86,9 @@ using namespace libra;
 
 extern "C" int libra_bridge_attn_decode(const void* q, int64_t ldq, const void* k_same, const void* k_cross, const void* v_same,
                                         const void* v_cross, int64_t ldc, int64_t batch_stride, const uint8_t* key_flag,
-                                        int64_t flag_stride, const uint8_t* query_flag, const int* kv_len, void* out,
-                                        int64_t ldo, int64_t B, int64_t H, float scale, void* stream) {
+                                        int64_t flag_stride, const uint8_t* query_flag, const int* kv_len,
+                                        const int* kv_start, void* out, int64_t ldo, int64_t B, int64_t H, float scale,
+                                        void* stream) {
     if (B <= 0) return LIBRA_OK;
     if (H <= 0 || H > 65535 || B > 65535 || ldq < H * 128 || ldc < H * 128 || ldo < H * 128 || batch_stride < ldc) return LIBRA_ERR_SHAPE;
     if ((ldq % 8) || (ldc % 8) || (batch_stride % 8)) return LIBRA_ERR_ALIGN;
@@ -95,7 +97,7 @@ extern "C" int libra_bridge_attn_decode(const void* q, int64_t ldq, const void* 
     DecodeArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.ks = (const bf16_t*)k_same; a.kc = (const bf16_t*)k_cross;
     a.vs = (const bf16_t*)v_same; a.vc = (const bf16_t*)v_cross; a.ldc = ldc; a.bstride = batch_stride;
-    a.kflag = key_flag; a.fstride = flag_stride; a.qflag = query_flag; a.lens = kv_len; a.out = (bf16_t*)out; a.ldo = ldo;
+    a.kflag = key_flag; a.fstride = flag_stride; a.qflag = query_flag; a.lens = kv_len; a.starts = kv_start; a.out = (bf16_t*)out; a.ldo = ldo;
     a.H = (int)H; a.sl2 = scale * 1.4426950408889634f;
     hipLaunchKernelGGL(bridge_attn_decode_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;

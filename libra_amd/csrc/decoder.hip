@@ -68,6 +68,7 @@ struct RopeArgs {
     bf16_t* k_cross; bf16_t* v_cross; long ldc;   // [N, H*128]
     long N; int S;
     const int* positions;                         // optional [N]: RoPE position of token n (NULL: n % S)
+    int max_pos;                                  // rows of cos / sin: explicit positions are clamped into the table
 };
 
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
         const long n = n_first + (long)j * tpb;
         if (n >= p.N) break;
         while (s >= p.S) s -= p.S;
-        const int pos = p.positions ? p.positions[n] : s;
+        const int pos = p.positions ? min(max(p.positions[n], 0), p.max_pos - 1) : s;
         const int vis = p.flag[n] != 0;
         if (vis != cur_mod) {
             const bf16_t* bk = vis ? p.bk_v : p.bk_l;
@@ -298,7 +299,7 @@ static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, c
     a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
     a.flag = flag; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
     a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
-    a.positions = positions;
+    a.positions = positions; a.max_pos = (int)max_pos;
     const long LT = H * 16, tpb = LT >= 256 ? 1 : 256 / LT;
     const long gx = (N + ROPE_TOK * tpb - 1) / (ROPE_TOK * tpb), gy = LT >= 256 ? (LT + 255) / 256 : 1;
     if (gx > 0x7fffffffL || gy > 65535) return LIBRA_ERR_SHAPE;

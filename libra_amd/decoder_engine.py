@@ -134,19 +134,33 @@ def pack(sd: Dict[str, torch.Tensor], d: DecDims) -> PackedOperands:
     return PackedOperands(sd, d)
 
 
-def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims):
-    """-> flag uint8 [N], lang_idx / vis_idx int32, kv_len int32 [B].  One host sync (nonzero) per batch."""
+def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims, *, allow_left: bool = False):
+    """-> flag uint8 [N], lang_idx / vis_idx int32, kv_len int32 [B] (end of the valid tokens) and - with `allow_left` -
+    kv_start int32 [B] or None.  One host sync per batch.
+    Training pads RIGHT (libra_pretrain.yaml:17 `padding_side: right`); batched generation pads LEFT (demo/libra_demo.ipynb sets
+    `padding_side = 'left'`): the inference forward accepts one contiguous block of valid tokens per sequence."""
     B, S = vision_indices.shape
     flag = (vision_indices < d.max_vision_len).reshape(-1)
     lang_idx = torch.nonzero(~flag).squeeze(1).to(torch.int32)
     vis_idx = torch.nonzero(flag).squeeze(1).to(torch.int32)
     am = attention_mask.to(torch.bool)
-    lens = am.sum(1).to(torch.int32)
+    n = am.sum(1).to(torch.int32)
     ar = torch.arange(S, device=am.device)[None, :]
-    if not bool(torch.equal(am, ar < lens[:, None])):
-        raise NotImplementedError("the fused attention kernel handles right padding only (the reference pads right: "
-                                  "tokenization_libra.py, padding='longest'); got a non-suffix attention_mask")
-    return flag.to(torch.uint8).contiguous(), lang_idx.contiguous(), vis_idx.contiguous(), lens.contiguous()
+    first = torch.where(am.any(1), am.to(torch.int32).argmax(1), torch.zeros_like(n)).to(torch.int32)
+    ends = first + n
+    holes = (am != ((ar >= first[:, None]) & (ar < ends[:, None]))).any()
+    code = int((holes.to(torch.int32) + 2 * (first > 0).any().to(torch.int32)).item())          # the one host read
+    if code & 1:
+        raise NotImplementedError("the fused attention kernels take one contiguous block of valid tokens per sequence (right "
+                                  "padding when training, left or right padding at inference); got an attention_mask with holes")
+    left = bool(code & 2)
+    if left and not allow_left:
+        raise NotImplementedError("left-padded batches are an inference-only path: the backward kernels assume right padding, "
+                                  "as the training recipes pad (libra_pretrain.yaml:17 `padding_side: right`)")
+    out = (flag.to(torch.uint8).contiguous(), lang_idx.contiguous(), vis_idx.contiguous(), ends.contiguous())
+    if allow_left:
+        out = out + (first.contiguous() if left else None,)
+    return out
 
 
 def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None):
@@ -194,6 +208,7 @@ class KVCache:
         self.B, self.capacity, self.length = B, capacity, 0
         self.layers = [tuple(torch.empty((B, capacity, H), dtype=BF16, device=device) for _ in range(4)) for _ in range(layers)]
         self.flag = torch.zeros((B, capacity), dtype=torch.uint8, device=device)
+        self.start: Optional[torch.Tensor] = None          # int32 [B] first valid slot of each sequence (left-padded prompts)
         self.graphs: Dict[tuple, tuple] = {}               # routing pattern of a decode step -> (hipGraph, static buffers, outputs)
         self.pack_key = None                               # version of the packed weights the graphs were captured against
 
@@ -203,12 +218,13 @@ class KVCache:
 
 def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None, *,
                   cache: Optional[KVCache] = None, positions: Optional[torch.Tensor] = None,
-                  slot: Optional[torch.Tensor] = None, need_out: bool = True):
+                  slot: Optional[torch.Tensor] = None, need_out: bool = True, kv_start: Optional[torch.Tensor] = None):
     """One LibraDecoderLayer (modeling_libra.py:437-491).  `sv` (dict) collects what the backward needs.
-    With `cache`: positions None = prefill (the S prompt tokens' K/V rows are stored at slots [0, S)); positions int32 [B] =
-    one cached decode step (S == 1): RoPE at positions[b], the new rows appended at slot cache.length, attention of the
-    single query over the cache_len + 1 cached tokens (bridge_attn_decode); `slot` is the cache slot as a device tensor
-    [1] int64 so that the step contains no host-side shape or index and can be captured in a hipGraph."""
+    `positions` (int32 [N]): explicit RoPE positions (left-padded prompts, decode steps); None = arange(S) per sequence.
+    With `cache`: slot None = prefill (the S prompt tokens' K/V rows are stored at slots [0, S)); slot = one cached decode step
+    (S == 1): the new rows appended at slot cache.length, attention of the single query over the cached tokens
+    [kv_start, cache_len] (bridge_attn_decode); `slot` is the cache slot as a device tensor [1] int64 so that the step
+    contains no host-side shape or index and can be captured in a hipGraph.  `kv_start` int32 [B]: first valid key."""
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S
     dev = x.device
@@ -238,17 +254,17 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
         kc, vc = K.rope_bridge_pos(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, positions, d.heads)
     if cache is not None:                                   # plumbing copies into the cache slots
         for buf, rows in zip(cache.layers[i], (qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc)):
-            if positions is None:
+            if slot is None:
                 buf[:, :S].copy_(rows.view(B, S, H))
             else:
                 buf.index_copy_(1, slot, rows.view(B, 1, H))
-    if positions is None:
+    if slot is None:
         o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
-                                   (H // d.heads) ** -0.5, need_lse=save)
+                                   (H // d.heads) ** -0.5, need_lse=save, kv_start=kv_start)
     else:
         ks_c, kc_c, vs_c, vc_c = cache.layers[i]
         o, lse = K.bridge_attn_decode(qkv[:, :H], ks_c, kc_c, vs_c, vc_c, cache.flag, flag, lens, d.heads,
-                                      (H // d.heads) ** -0.5), None
+                                      (H // d.heads) ** -0.5, kv_start=kv_start), None
     x_mid = torch.empty_like(x)
     to = None
     if n_l:
@@ -313,13 +329,18 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     dev = input_ids.device
     if labels is not None and labels.dtype != torch.int64:
         raise TypeError(f"labels must be int64 (torch.long), got {labels.dtype}")
-    flag, lang_idx, vis_idx, lens = route(vision_indices, attention_mask, d)
+    flag, lang_idx, vis_idx, lens, starts = route(vision_indices, attention_mask, d, allow_left=not save)
+    positions = None
+    if starts is not None:                      # left padding: position_ids = attention_mask.cumsum(-1) - 1, pads -> 1 (:1204-1207)
+        am = attention_mask.to(torch.long)
+        positions = (am.cumsum(-1) - 1).masked_fill(am == 0, 1).reshape(-1).to(torch.int32).contiguous()
     if cache is not None:
         if cache.length != 0 or S > cache.capacity or B != cache.B:
             raise ValueError("prefill needs an empty KV cache of the batch size with capacity >= the prompt length")
         if not bool((lens == S).all()):
-            raise NotImplementedError("cached generation handles unpadded prompts only (the decode kernel has one valid "
-                                      "length per sequence and no holes inside the cache)")
+            raise NotImplementedError("cached generation continues every sequence at slot S: pad the prompts on the LEFT "
+                                      "(tokenizer.padding_side = 'left', as the reference demo does); got right padding")
+        cache.start = starts
     check_ids(input_ids, flag.view(B, S).bool(), d)
     cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, S), dev)
     saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
@@ -328,7 +349,8 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     for i in range(d.layers):
         sv = {} if save and not recompute else None
         x_in = x
-        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv, cache=cache)
+        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv, cache=cache,
+                          positions=positions, kv_start=starts)
         if save:
             saved["layers"].append(sv if not recompute else {"x": x_in})
         if want_hidden_states:
@@ -385,7 +407,7 @@ def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
     x = embed(sd, d, st["ids"], flag, lang_idx, vis_idx, None)
     for i in range(d.layers):
         x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, st["kv_len"], cos, sin, B, 1, None, cache=cache,
-                          positions=st["positions"], slot=st["slot"])
+                          positions=st["positions"], slot=st["slot"], kv_start=cache.start)
     hidden, _ = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
@@ -399,6 +421,9 @@ def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
             z_vis.append(None)
     return dict(hidden=hidden.view(B, 1, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang, z_vis=z_vis,
                 loss=None, hidden_states=None, saved=None)
+
+
+MAX_DECODE_GRAPHS = 8       # routing patterns kept per cache (in practice 2: "all text" and "all inside an image")
 
 
 @torch.no_grad()
@@ -418,9 +443,13 @@ def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indice
         raise ValueError("decode_step needs a prefilled KV cache with a free slot")
     dev = input_ids.device
     flagb = (vision_indices < d.max_vision_len).reshape(-1)
-    pattern = tuple(torch.stack([flagb, (input_ids[0] >= d.vocab).reshape(-1)]).tolist())      # the one host read
+    tok = input_ids[:, :, 0]                                                            # [Q, B]
+    bad = (flagb & ((tok < d.vocab) | (tok >= d.vocab + d.vision_vocab)).any(0)) | (~flagb & (tok[0] < 0))
+    pattern = tuple(torch.stack([flagb, tok[0] >= d.vocab, bad]).tolist())               # the one host read
     if pattern[0] != pattern[1]:
         raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
+    if any(pattern[2]):
+        raise IndexError("a token id lies outside its embedding table (vision ids: every codebook in [V, V + Vv))")
     key = tuple(pattern[0])
     entry = cache.graphs.get(key) if use_graph else None
     if entry is None:
@@ -446,6 +475,8 @@ def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indice
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = _decode_core(sd, packed, d, cache, st)
+        while len(cache.graphs) >= MAX_DECODE_GRAPHS:               # bounded: each graph pins its static buffers and outputs
+            cache.graphs.pop(next(iter(cache.graphs)))              # (dicts keep insertion order: drop the oldest pattern)
         cache.graphs[key] = (graph, st, out)
         graph.replay()
     else:

@@ -452,7 +452,8 @@ def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, 
     return kc, vc
 
 
-def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag, kv_len, H: int, scale: float):
+def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag, kv_len, H: int, scale: float, *,
+                       kv_start=None):
     """One new query token per sequence against the KV cache: q [B, H*128]; caches [B, Lmax, H*128] (same strides);
     key_flag [B, Lmax] u8, query_flag [B] u8, kv_len [B] int32 (valid cached tokens incl. the new one, <= Lmax: the caller's
     invariant - checking it here would be a host synchronisation inside a capturable step) -> [B, H*128]."""
@@ -464,17 +465,20 @@ def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag
             raise ValueError("bridge_attn_decode: caches must be [B, Lmax, H*128] bf16 with identical strides")
     if key_flag.dtype != torch.uint8 or query_flag.dtype != torch.uint8 or kv_len.dtype != torch.int32:
         raise ValueError("bridge_attn_decode: flags are uint8, kv_len is int32")
+    if kv_start is not None and (kv_start.dtype != torch.int32 or kv_start.numel() != B):
+        raise ValueError("bridge_attn_decode: kv_start must be int32 [B]")
     out = torch.empty((B, H * 128), dtype=BF16, device=q.device)
     rc = _lib.lib().libra_bridge_attn_decode(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_cross.data_ptr(), v_same.data_ptr(),
                                              v_cross.data_ptr(), k_same.stride(1), k_same.stride(0), key_flag.data_ptr(),
-                                             key_flag.stride(0), query_flag.data_ptr(), kv_len.data_ptr(), out.data_ptr(),
-                                             out.stride(0), B, H, float(scale), _stream())
+                                             key_flag.stride(0), query_flag.data_ptr(), kv_len.data_ptr(), _ptr(kv_start),
+                                             out.data_ptr(), out.stride(0), B, H, float(scale), _stream())
     _lib.check(rc, "bridge_attn_decode")
     return out
 
 
 def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S: int, H: int, scale: float, *,
-                    need_lse: bool = False):
+                    need_lse: bool = False, kv_start=None):
+    """kv_len [B] int32 = end of the valid keys (right padding); kv_start [B] int32 = first valid key (left padding)."""
     for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross")):
         _chk2d(t, n)
     out = torch.empty((B * S, H * 128), dtype=BF16, device=q.device)
@@ -482,8 +486,8 @@ def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S
     rc = _lib.lib().libra_bridge_attn_fwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_same.stride(0), k_cross.data_ptr(),
                                           k_cross.stride(0), v_same.data_ptr(), v_same.stride(0), v_cross.data_ptr(),
                                           v_cross.stride(0), flag.data_ptr(),
-                                          _ptr(kv_len), out.data_ptr(), out.stride(0), _ptr(lse), B, S, H, float(scale),
-                                          _stream())
+                                          _ptr(kv_len), _ptr(kv_start), out.data_ptr(), out.stride(0), _ptr(lse), B, S, H,
+                                          float(scale), _stream())
     _lib.check(rc, "bridge_attn_fwd")
     return out, lse
 

@@ -23,6 +23,7 @@ from .. import decoder_engine as DE
 from ..common.registry import registry
 from ..llama.modeling_llama import LlamaRMSNorm          # noqa: F401  (re-exported: trainer.py:3 imports the name)
 from .configuration_libra import LibraConfig
+from .generation import LibraGenerationMixin
 
 
 class _EngineOwned(nn.Module):
@@ -142,7 +143,7 @@ class LibraCausalLMOutputWithPast(CausalLMOutputWithPast):     # modeling_libra.
         return super().__getitem__(k)
 
 
-class LibraForCausalLM(PreTrainedModel):
+class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
     config_class = LibraConfig
     base_model_prefix = "model"
     supports_gradient_checkpointing = True
@@ -226,7 +227,7 @@ class LibraForCausalLM(PreTrainedModel):
                 position_ids=None, past_key_values=None, inputs_embeds=None, labels: Optional[torch.LongTensor] = None,
                 use_cache: Optional[bool] = None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 contiguous_signal: Optional[torch.Tensor] = None, vision_indices: Optional[torch.LongTensor] = None,
-                past_hidden_states=None, past_vision_flag=None):
+                past_hidden_states=None, past_vision_flag=None, max_cache_len: Optional[int] = None):
         if input_ids is None or vision_indices is None:
             raise ValueError("You have to specify input_ids [Q,B,S] and vision_indices [B,S]")
         if inputs_embeds is not None:
@@ -239,7 +240,8 @@ class LibraForCausalLM(PreTrainedModel):
         if past_key_values is not None or use_cache:
             if labels is not None:
                 raise ValueError("labels with use_cache / past_key_values: the cached path is inference only (:1142)")
-            return self._forward_cached(input_ids, attention_mask, position_ids, past_key_values, contiguous_signal, vision_indices)
+            return self._forward_cached(input_ids, attention_mask, position_ids, past_key_values, contiguous_signal, vision_indices,
+                                        max_cache_len)
         if position_ids is not None:
             raise NotImplementedError("custom position_ids on the training path (positions are arange(S), :736-739)")
         Q, B, S = input_ids.shape
@@ -264,11 +266,13 @@ class LibraForCausalLM(PreTrainedModel):
         return res
 
     @torch.no_grad()
-    def _forward_cached(self, input_ids, attention_mask, position_ids, past, signal, vision_indices):
+    def _forward_cached(self, input_ids, attention_mask, position_ids, past, signal, vision_indices, max_cache_len=None):
         """Generation path (LibraForCausalLM.forward with use_cache / past_key_values, modeling_libra.py:1118-1188):
         `past` None = prefill of the prompt (returns a filled DE.KVCache as `.past_key_values`); otherwise one new token per
-        sequence.  `.logits` is materialised ([Q,B,q,V+Vv], q = the tokens of this call) with the cached branch's rule that an
-        EOI input token predicts nothing but a newline (:1141-1144)."""
+        sequence.  Batched prompts are padded on the LEFT (positions = attention_mask.cumsum - 1, :1204-1207; pad keys are
+        masked by the kernels through the cache's per-sequence start).  `.logits` is materialised ([Q,B,q,V+Vv], q = the tokens
+        of this call) with the cached branch's rule that an EOI input token predicts nothing but a newline (:1141-1144).
+        The KV cache holds `max_cache_len` tokens (default max_position_embeddings; generate() passes its max_length)."""
         Q, B, S = input_ids.shape
         dims = self._dims
         sd, packed = self._state()
@@ -276,9 +280,13 @@ class LibraForCausalLM(PreTrainedModel):
         if past is None:
             if attention_mask is None:
                 attention_mask = torch.ones((B, S), dtype=torch.bool, device=dev)
-            if position_ids is not None and not torch.equal(position_ids.reshape(B, S).to(dev), torch.arange(S, device=dev).expand(B, S)):
-                raise NotImplementedError("prefill positions other than arange(S)")
-            cache = DE.KVCache(dims.layers, B, max(dims.max_pos, S), dims.hidden, dev)
+            if position_ids is not None:
+                am = attention_mask.to(torch.long)
+                want = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+                if not torch.equal(position_ids.reshape(B, S).to(dev), want):
+                    raise NotImplementedError("prefill positions other than attention_mask.cumsum(-1) - 1")
+            cap = max(int(max_cache_len), S + 1) if max_cache_len else max(dims.max_pos, S + 1)
+            cache = DE.KVCache(dims.layers, B, cap, dims.hidden, dev)
             cache.pack_key = self._ptr_key()
             out = DE.forward(sd, packed, dims, input_ids, attention_mask, vision_indices, signal, None, cache=cache)
         else:
@@ -286,23 +294,24 @@ class LibraForCausalLM(PreTrainedModel):
                 raise TypeError("past_key_values must be the KVCache returned by a previous call of this model")
             if S != 1:
                 raise ValueError("only support generating token by token")             # cal_vision_logits_inference, :912
-            if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
-                raise NotImplementedError("cached generation handles unpadded sequences only")
             cache = past
+            if cache.length >= cache.capacity:
+                raise ValueError(f"the KV cache is full ({cache.capacity} tokens): pass a larger max_cache_len / max_length")
             if getattr(cache, "pack_key", None) != self._ptr_key():     # parameter storage moved since the graphs were captured
                 cache.graphs.clear()                                     # (values may change freely: operands are refreshed in place)
                 cache.pack_key = self._ptr_key()
             if position_ids is None:                                                    # attention_mask.cumsum(-1) - 1, :1207
                 position_ids = torch.full((B, 1), cache.length, dtype=torch.long, device=dev)
+                if cache.start is not None:
+                    position_ids = position_ids - cache.start.long()[:, None]
             out = DE.decode_step(sd, packed, dims, cache, input_ids, vision_indices, position_ids,
                                  use_graph=getattr(self, "decode_graphs", True))      # (False: launch the step kernel by kernel)
         logits = DE.dense_logits(out, dims, B, S)
         if past is not None:
             eoi = vision_indices[:, -1] == self.max_vision_token_length - 1
-            if bool(eoi.any()):
-                forced = torch.full((logits.shape[-1],), float("-inf"), dtype=logits.dtype, device=dev)
-                forced[self.config.newline_token_id] = float("inf")
-                logits[:, eoi, -1, :] = forced
+            forced = torch.full((logits.shape[-1],), float("-inf"), dtype=logits.dtype, device=dev)
+            forced[self.config.newline_token_id] = float("inf")
+            logits[:, :, -1, :] = torch.where(eoi[None, :, None], forced[None, None, :], logits[:, :, -1, :])   # no host read
         return LibraCausalLMOutputWithPast(loss=None, logits=logits, past_key_values=cache, hidden_states=None, attentions=None)
 
     # ---- generation glue (the reference's custom greedy_search / sample call these, modeling_libra_utils.py:61,:330) ----

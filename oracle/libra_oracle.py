@@ -358,3 +358,61 @@ def random_layer_state_dict(*, hidden: int = 4096, inter: int = 11008, rank: int
     for n in ("input_layernorm", "post_attention_layernorm", "vision_input_layernorm", "vision_post_attention_layernorm"):
         sd[p + n + ".weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
     return sd
+
+
+# ======================================================================================================
+# Generation loop: the reference's custom greedy_search over [Q,B,S] ids
+# (/root/reference/libra/models/libra/modeling_libra_utils.py:61-328) with its ValidImageLogitsProcessor
+# (/root/reference/libra/models/llama/modeling_llama_utils.py:23-76), restated on the cached step above.
+# Pinned by tests/test_oracle_libra_golden.py against tests/golden/libra_tiny_generate.safetensors
+# (tests/golden/make_golden_libra_generate.py runs the reference's own greedy_search, left-padded batch).
+# ======================================================================================================
+def valid_image_scores(ids_q: torch.Tensor, scores_q: torch.Tensor, *, valid_image_token_length: int, boi: int, eoi: int,
+                       offset: int) -> torch.Tensor:
+    """One codebook: ids_q [B,S], scores_q [B,V'].  n = trailing vision ids; 0 < n < len+1 -> only code ids; n == len+1 -> only EOI."""
+    full = valid_image_token_length + 2
+    n = (torch.cumsum(torch.flip(ids_q, dims=[-1]) < offset, dim=-1) == 0).sum(-1)
+    if bool((n > full).any()):
+        raise ValueError("You have generated an invalid image.")
+    out = scores_q.clone()
+    cols = torch.arange(scores_q.shape[-1])
+    code = (cols >= offset) & (cols != boi) & (cols != eoi)
+    body, close = (n > 0) & (n < full - 1), n == full - 1
+    out[body[:, None] & ~code[None, :]] = float("-inf")
+    out[close[:, None] & (cols != eoi)[None, :]] = float("-inf")
+    return out
+
+
+def greedy_generate(sd, input_ids, attention_mask, vision_indices, signal, *, steps: int, Q: int, layers: int, heads: int, vocab: int,
+                    max_vision_token_length: int, newline_token_id: int, pad_token_id: int, eos_token_id: int, image_rule: dict,
+                    eps: float = 1e-6, max_pos: int = 2048):
+    """-> (sequences [Q,B,S+steps], processed scores [steps,Q,B,V']).  position_ids = attention_mask.cumsum(-1) - 1 (pads -> 1,
+    modeling_libra.py:1204-1207); the vision index of a new token counts up inside an image and stays at L otherwise (:1270-1278);
+    finished sequences emit pad, codebook by codebook (modeling_libra_utils.py:276-296)."""
+    kw = dict(layers=layers, heads=heads, vocab=vocab, max_vision_token_length=max_vision_token_length, eps=eps, max_pos=max_pos)
+    am, vi, ids = attention_mask.clone(), vision_indices.clone(), input_ids.clone()
+    B = ids.shape[1]
+    unfinished = torch.ones(B, dtype=torch.long)
+    caches, all_scores = None, []
+    for t in range(steps):
+        pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 1)
+        if caches is None:
+            hid, flag, caches = model_step(sd, ids, vi, signal, None, pos, am.bool(), **kw)
+            z = cached_logits(sd, hid, flag, vi, Q, had_past=False, max_vision_token_length=max_vision_token_length,
+                              newline_token_id=newline_token_id)
+        else:
+            hid, flag, caches = model_step(sd, ids[:, :, -1:], vi[:, -1:], None, caches, pos[:, -1:], am.bool(), **kw)
+            z = cached_logits(sd, hid, flag, vi[:, -1:], Q, had_past=True, max_vision_token_length=max_vision_token_length,
+                              newline_token_id=newline_token_id)
+        sc = torch.stack([valid_image_scores(ids[q], z[q, :, -1, :], **image_rule) for q in range(Q)])
+        all_scores.append(sc)
+        nxt = sc.argmax(-1)
+        cols = []
+        for q in range(Q):
+            tok = nxt[q] * unfinished + pad_token_id * (1 - unfinished)
+            unfinished = unfinished * (tok != eos_token_id).long()
+            cols.append(tok)
+        ids = torch.cat([ids, torch.stack(cols)[:, :, None]], dim=-1)
+        am = torch.cat([am, am.new_ones((B, 1))], dim=-1)
+        vi = torch.cat([vi, (vi[:, -1] + 1).clamp(max=max_vision_token_length)[:, None]], dim=-1)
+    return ids, torch.stack(all_scores)

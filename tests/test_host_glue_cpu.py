@@ -172,3 +172,38 @@ def test_registry_and_wrapper_surface():
         m.model.layers[0](torch.zeros(1))
     with pytest.raises(NotImplementedError, match="dropout"):
         LibraForCausalLM(LibraConfig(**{**cfg.to_dict(), "resid_pdrop": 0.1}))
+
+
+def test_valid_image_logits_processor_rule():
+    """The product's ValidImageLogitsProcessor (generation.py) against the oracle's restatement of the reference rule
+    (modeling_llama_utils.py:23-76) on random id histories: text, mid-image, body complete, image closed, and the two errors."""
+    import pytest
+    from libra_amd.libra.generation import NoNewlineLogitsProcessor, ValidImageLogitsProcessor
+    from oracle import libra_oracle as LO
+    V, Vv, n_img = 96, 18, 4
+    boi, eoi = V + 16, V + 17
+    proc = ValidImageLogitsProcessor(n_img, boi, eoi, V, V + Vv)
+    g = torch.Generator().manual_seed(0)
+    text = lambda n: torch.randint(3, V, (n,), generator=g)
+    code = lambda n: V + torch.randint(0, 16, (n,), generator=g)
+    rows = [torch.cat([text(8)]), torch.cat([text(7), torch.tensor([boi])]), torch.cat([text(5), torch.tensor([boi]), code(2)]),
+            torch.cat([text(3), torch.tensor([boi]), code(4)]), torch.cat([text(2), torch.tensor([boi]), code(4), torch.tensor([eoi])]),
+            torch.cat([torch.tensor([boi]), code(4), torch.tensor([eoi]), text(2)])]
+    ids = torch.stack(rows)[None].repeat(2, 1, 1)
+    scores = torch.randn(2, len(rows), V + Vv, generator=g)
+    got = proc(ids, scores.clone())
+    want = torch.stack([LO.valid_image_scores(ids[q], scores[q], valid_image_token_length=n_img, boi=boi, eoi=eoi, offset=V)
+                        for q in range(2)])
+    assert torch.equal(got, want)
+    assert torch.equal(got[0, 0], scores[0, 0]) and torch.equal(got[0, 4], scores[0, 4])             # text / closed image: untouched
+    assert int(torch.isfinite(got[0, 3]).sum()) == 1 and torch.isfinite(got[0, 3, eoi])                # body complete: EOI only
+    assert not torch.isfinite(got[0, 2, :V]).any() and not torch.isfinite(got[0, 2, [boi, eoi]]).any() # mid-image: codes only
+    with pytest.raises(ValueError, match="invalid image"):
+        proc(torch.cat([torch.tensor([boi]), code(6)])[None, None], scores[:1, :1])
+    with pytest.raises(ValueError, match="do not end"):
+        proc(torch.cat([torch.tensor([boi]), code(5)])[None, None], scores[:1, :1])
+    with pytest.raises(AssertionError):
+        ValidImageLogitsProcessor(5, boi, eoi, V, V + Vv)
+    nn_ = NoNewlineLogitsProcessor(13, 2)
+    s2 = nn_(torch.tensor([[5, 13], [13, 7]]), torch.zeros(2, 20))
+    assert int(torch.isfinite(s2[0]).sum()) == 1 and torch.isfinite(s2[0, 2]) and torch.isfinite(s2[1]).all()

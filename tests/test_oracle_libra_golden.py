@@ -124,3 +124,22 @@ def test_kv_cache_decode_matches_reference():
         a, b = inc[:, :, keep], zf[:, :, keep]
         m = torch.isfinite(b)
         assert rel_err(a[m], b[m]) < 2e-5, name
+
+
+def test_greedy_generation_matches_reference_greedy_search():
+    """§8f-1: the oracle's generation loop (left-padded prompts, ValidImageLogitsProcessor rule, EOI -> newline, pad after EOS)
+    against the reference's own greedy_search run (make_golden_libra_generate.py): identical sequences, per-step scores."""
+    t, meta = load_golden("libra_tiny_generate.safetensors")
+    w = sub(load_golden("libra_tiny.safetensors")[0], "w.")
+    c = meta["cfg"]
+    seq, scores = LO.greedy_generate(
+        w, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"], t["in.signal"], steps=meta["steps"],
+        Q=c["vision_codebook_num"], layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+        max_vision_token_length=c["max_vision_token_length"], newline_token_id=meta["newline_token_id"],
+        pad_token_id=meta["pad_token_id"], eos_token_id=meta["eos_token_id"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"],
+        image_rule=dict(valid_image_token_length=meta["valid_image_token_length"], boi=meta["boi"], eoi=meta["eoi"], offset=c["vocab_size"]))
+    assert torch.equal(seq, t["out.sequences"])
+    ref = t["out.scores"]
+    assert torch.equal(torch.isfinite(scores), torch.isfinite(ref)) and torch.equal(torch.isposinf(scores), torch.isposinf(ref))
+    fin = torch.isfinite(ref)
+    assert rel_err(scores[fin], ref[fin]) < 2e-5
