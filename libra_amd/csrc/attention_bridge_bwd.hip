@@ -15,6 +15,7 @@
 //              first-stage work duplicated for the same output).  The workgroup's K/V operand tiles stay
 //              resident in LDS (64 KiB); Q / dO tiles of 32 queries stream through a double buffer in BOTH
 //              images (row image for the first-stage A operand, reduction-major image for the transpose reads).
+#include <cstdlib>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
@@ -553,6 +554,300 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     else { store(acc_s, 1.0f, p.dv_same); store(acc_c, 1.0f, p.dv_cross); }
 }
 
+// ================================================================================================
+// dK / dV pass, second structure (round 2).  What the round-1 PMC profile of the kernel above showed: matrix pipe busy 21 %,
+// 12.4 VALU and ~1.6 LDS operand reads per MFMA - S was computed by both roles (2 of 5 matmuls), both MFMA operands of the
+// first stage came from LDS, and every LDS address was rebuilt (swizzle XORs) per read.  Here:
+//   * one variant at a time: pass 0 accumulates dK_same / dV_same, pass 1 dK_cross / dV_cross (a tile pair belongs to one
+//     variant except at modality boundaries, so almost no tile is visited twice; tiles without the pass's variant are
+//     neither staged nor computed) - a wave therefore holds dV AND dK of ONE variant (128 accumulator VGPRs) and computes
+//     S and dP once: 4 matmuls per tile pair instead of 5;
+//   * the wave's 32 K rows (B operand of S = Q K^T) live in REGISTERS for the whole pass (32 VGPRs, loaded once from HBM);
+//     only V (B operand of dP = dO V^T) stays in a 16-KiB LDS tile;
+//   * 128-query tiles of Q and dO stream through a 2-deep ring: 8 waves = 2 key sub-blocks x 4 query sub-blocks, one
+//     (32 queries x 32 keys) pair per wave and tile, one barrier per 128 queries instead of per 64;
+//   * LDS addresses are lane constants XOR a compile-time constant (xr / xt0 / xt1 below): one VALU op per read.
+// Per pair: 32 MFMAs, 8 + 8 + 8 row reads + 16 transposed reads (b128 equivalents: 40, was 64 for the same work).
+constexpr int QT2 = 128;
+constexpr int ST2 = 2 * 32768 + 1024;          // Q image, dO image (128 queries each), L[128], D[128]
+constexpr int DKV2_VRES = 2 * ST2;             // resident V tile of the pass's variant: [64 keys][128 d]
+constexpr int DKV2_MASK = DKV2_VRES + 16384;
+constexpr int DKV2_LDS_B = DKV2_MASK + 1024;
+
+__global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const BridgeBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* vres = smem + DKV2_VRES;
+    unsigned* qmask = (unsigned*)(smem + DKV2_MASK);             // per 32 queries: bit i = query i is a vision token
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kw = wave & 1, qs = wave >> 1;                     // key sub-block (32 keys), query sub-block (32 of 128)
+    const int fk = lane >> 5, l31 = lane & 31;
+    const int nblk = p.B * p.H * p.n_t;
+    const int L = xcd_remap(blockIdx.x, nblk);
+    const int ktile = L % p.n_t;                                 // low key tiles see the most queries: they come first
+    const int bh = L / p.n_t;
+    const int h = bh % p.H, b = bh / p.H;
+    const int S = p.S;
+    const long tok0 = (long)b * S;
+    int len = p.kv_len ? p.kv_len[b] : S;
+    len = len < S ? len : S;
+    const int key0 = ktile * 64;
+    const int kbase_w = key0 + kw * 32;
+    int key = kbase_w + l31;
+    const bool kin = key < S;
+    key = kin ? key : S - 1;
+    int k_vis_i = p.flag[tok0 + key] != 0;
+    pin(k_vis_i);
+    const bool k_vis = k_vis_i != 0;
+    const bool wkV = __ballot(k_vis && kin) != 0, wkL = __ballot(!k_vis && kin) != 0;
+    bool bkV, bkL;                                               // modality content of the whole 64-key block (workgroup-uniform)
+    {
+        const int kk = key0 + lane;
+        int f = (kk < S) ? (p.flag[tok0 + kk] != 0 ? 1 : 2) : 0;
+        pin(f);
+        bkV = __ballot(f == 1) != 0; bkL = __ballot(f == 2) != 0;
+    }
+    const int n32 = (S + 31) / 32;
+    for (int t = wave; t < n32 + 4; t += 8) {                    // spare words: a ragged 128-query tile reads zeros
+        const int qq = t * 32 + l31;
+        const bool vis = (qq < S) && (fk == 0) && p.flag[tok0 + qq] != 0;
+        const unsigned long long bal = __ballot(vis);
+        if (lane == 0) qmask[t] = (unsigned)bal;
+    }
+    __syncthreads();
+
+    const bf16_t* qbase = p.q + tok0 * p.ldq + h * D128;
+    const bf16_t* dobase = p.dout + tok0 * p.ldo + h * D128;
+    const float* lbase = p.lse + ((long)b * p.H + h) * S;
+    const float* dbase = p.delta + ((long)b * p.H + h) * S;
+    auto stage_q = [&](int buf, int t) {
+        char* dst = smem + buf * ST2;
+        stage_t64(qbase, (unsigned)p.ldq * 2u, t * QT2, S, dst, wave, lane);
+        stage_t64(qbase, (unsigned)p.ldq * 2u, t * QT2 + 64, S, dst + 16384, wave, lane);
+        stage_t64(dobase, (unsigned)p.ldo * 2u, t * QT2, S, dst + 32768, wave, lane);
+        stage_t64(dobase, (unsigned)p.ldo * 2u, t * QT2 + 64, S, dst + 49152, wave, lane);
+        if (wave < 4) {                                          // 128 fp32 each: two 4-byte direct-to-LDS ops per array
+            int qi = t * QT2 + (wave & 1) * 64 + lane; qi = qi < S ? qi : S - 1;
+            glds4((wave < 2 ? lbase : dbase) + qi, dst + 65536 + (wave >> 1) * 512 + (wave & 1) * 256);
+        }
+    };
+    const int nqt = (S + QT2 - 1) / QT2;
+    const int it0 = key0 / QT2;                                  // first query tile that can see this key block
+    // does tile `t` hold a (query, key-of-this-block) pair of variant v?  (workgroup-uniform)
+    auto need = [&](int t, int v) -> bool {
+        unsigned m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[4 * t + j]);
+        bool qV = false, qL = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int nv = S - (t * QT2 + 32 * j); nv = nv > 32 ? 32 : nv;
+            if (nv <= 0) continue;
+            const unsigned full = nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u);
+            qV = qV || (m[j] & full) != 0; qL = qL || ((~m[j]) & full) != 0;
+        }
+        return v == 0 ? ((qV && bkV) || (qL && bkL)) : ((qV && bkL) || (qL && bkV));
+    };
+    auto next_needed = [&](int t, int v) -> int {
+        for (; t < nqt; ++t) if (need(t, v)) break;
+        return t;
+    };
+    // lane-constant halves of the LDS offsets (see the header comment): row image reads and the two transposed reads
+    const int tz = tswz(l31);
+    const int xr = l31 * 256 + ((fk ^ tz) << 4);                 // nread_t(tile, l31, 2 ks + fk) = tile + (xr ^ (ks << 5))
+    int xt0, xt1;                                                // tread_t(tile, lane, dt, sx) = {tile + 4096 sx + (xt0 ^ (dt << 6)), tile + 4096 sx + 2048 + (xt1 ^ (dt << 6))}
+    {
+        const int pp = lane & 15, g16 = (lane >> 4) & 1;
+        const int r1 = 4 * fk + (pp >> 2);
+        const int lp = 2 * g16 + ((pp & 3) >> 1);
+        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
+        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
+    }
+    const int xv = l31 * 128 + ((fk ^ ((l31 >> 1) & 7)) << 4);   // nfrag(tile, l31, ks, fk, 8192) = tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5))
+    auto rd_row = [&](const char* tile, int ks) -> bf16x8 { return *(const bf16x8*)(tile + (xr ^ (ks << 5))); };
+    auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
+        union { bf16x8 v; s16x4 h2[2]; } u;
+        u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
+        u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
+        return u.v;
+    };
+    auto rd_v = [&](const char* tile, int ks) -> bf16x8 { return *(const bf16x8*)(tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5))); };
+
+    constexpr int OROW = 264;
+#pragma unroll 1
+    for (int v = 0; v < 2; ++v) {
+        const bf16_t* kp = (v ? p.k_cross + tok0 * p.ldkc : p.k_same + tok0 * p.ldk) + h * D128;
+        const long ldkk = v ? p.ldkc : p.ldk;
+        const bf16_t* vp = (v ? p.v_cross + tok0 * p.ldvc : p.v_same + tok0 * p.ldv) + h * D128;
+        const unsigned ldvv = (unsigned)(v ? p.ldvc : p.ldv) * 2u;
+        bf16x8 kf[8];                                             // K[key = l31][16 ks + 8 fk .. +8]: B operand of S = Q K^T
+        {
+            const bf16_t* kr = kp + (long)key * ldkk + fk * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks] = *(const bf16x8*)(kr + ks * 16);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) pin(kf[ks]);          // landed before any LDS-DMA of this pass is in flight
+        }
+        f32x16 dV[4], dK[4];                                      // [128 d x 32 keys] each, this pass's variant
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dV[i][r] = 0.f; dK[i][r] = 0.f; }
+        stage_res64(vp, ldvv, key0, S, vres, wave, lane);
+        int it = next_needed(it0, v);
+        if (it < nqt) stage_q(0, it);
+        int buf = 0;
+        const char* rV = vres + kw * 32 * 128;                    // this wave's 32 key rows inside each 64-row sub-tile
+        while (it < nqt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nx = next_needed(it + 1, v);
+            if (nx < nqt) stage_q(buf ^ 1, nx);
+            const int q0 = it * QT2 + qs * 32;
+            const char* stg = smem + buf * ST2;
+            it = nx; buf ^= 1;
+            if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
+            const unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[q0 >> 5]);
+            int nvalid = S - q0; nvalid = nvalid > 32 ? 32 : nvalid;
+            const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
+            const bool qV = (qm & full) != 0, qL = ((~qm) & full) != 0;
+            const bool wsame = (qL && wkL) || (qV && wkV);
+            const bool wcross = (qL && wkV) || (qV && wkL);
+            if (!(v ? wcross : wsame)) continue;
+            const bool mixed = wsame && wcross;
+            const bool masked = q0 < kbase_w + 31 || q0 + 32 > S || kbase_w + 32 > len;
+            const char* sq = stg + qs * 8192;                     // this wave's 32 query rows of the Q image
+            const char* sdo = sq + 32768;                         //                          ... of the dO image
+            const float* sL = (const float*)(stg + 65536) + qs * 32;
+            const float* sD = sL + 128;
+            // accumulator row r <-> query q0 + (r&3) + 8(r>>2) + 4fk ; column <-> this lane's key
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq, ks), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sdo, ks), rd_v(rV, ks), dp, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // s <- P = exp2(S*sl2 - L);  dp <- dS = P (dP - D)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 Lv = *(const f32x4*)(sL + 8 * g + 4 * fk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * g + e], p.sl2, -Lv[e] * LOG2E));
+            }
+            if (masked) {
+                const int kabs = kbase_w + l31;
+                const bool kok = kabs < len;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qa = q0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    s[r] = (qa >= kabs && qa < S && kok) ? s[r] : 0.f;
+                }
+            }
+            if (mixed) {                                           // modality boundary inside the pair: keep this pass's variant only
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    s[r] = (((((qm >> ql) & 1u) != 0) != k_vis) == (v != 0)) ? s[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 Dv = *(const f32x4*)(sD + 8 * g + 4 * fk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[4 * g + e] = s[4 * g + e] * (dp[4 * g + e] - Dv[e]);
+            }
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                __builtin_amdgcn_sched_barrier(0);
+                union { bf16x8 v; unsigned u[4]; } pP, pS;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pP.u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
+                    pS.u[j] = pack2bf(dp[8 * sx + 2 * j], dp[8 * sx + 2 * j + 1]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sdo, dt, sx), pP.v, dV[dt], 0, 0, 0);   // dV^T += dO^T P
+                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sq, dt, sx), pS.v, dK[dt], 0, 0, 0);    // dK^T += Q^T dS
+                }
+            }
+        }
+        // ---- combine the four query sub-blocks' partial sums (waves qs = 1..3 hand theirs to qs = 0 through LDS) and store ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* xch = (float*)smem + ((qs > 0 ? qs - 1 : 0) * 2 + kw) * 4096;   // 16 KiB per (qs, kw) pair and round
+        auto give = [&](const f32x16* acc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = acc[i][4 * g + e];
+                    *(f32x4*)(xch + ((i * 4 + g) * 64 + lane) * 4) = a;
+                }
+        };
+        auto take = [&](f32x16* acc) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float* src = (const float*)smem + (j * 2 + kw) * 4096;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 a = *(const f32x4*)(src + ((i * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][4 * g + e] += a[e];
+                    }
+            }
+        };
+        if (qs > 0) give(dV);
+        __syncthreads();
+        if (qs == 0) take(dV);
+        __syncthreads();
+        if (qs > 0) give(dK);
+        __syncthreads();
+        if (qs == 0) take(dK);
+        __syncthreads();
+        if (qs == 0 && kbase_w < S) {
+            // each wave's [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
+            char* so = smem + wave * (32 * OROW);
+            auto store = [&](const f32x16* acc, float mul, bf16_t* dst) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = dt * 32 + 8 * g + 4 * fk;
+                        u32x2 w;
+                        w[0] = pack2bf(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
+                        w[1] = pack2bf(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+                        *(u32x2*)(so + l31 * OROW + d * 2) = w;
+                    }
+                // same-wave LDS write -> read: LDS ops of one wave execute in order and no other wave touches `so`
+#pragma unroll
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int r = pass * 4 + (lane >> 4);
+                    const int kk = kbase_w + r;
+                    if (kk < S) {
+                        const char* src = so + r * OROW + (lane & 15) * 16;
+                        const u32x2 a = *(const u32x2*)src;
+                        const u32x2 c2 = *(const u32x2*)(src + 8);
+                        u32x4 o;
+                        o[0] = a[0]; o[1] = a[1]; o[2] = c2[0]; o[3] = c2[1];
+                        *(u32x4*)(dst + (tok0 + kk) * p.ldg + h * D128 + (lane & 15) * 8) = o;
+                    }
+                }
+            };
+            store(dV, 1.0f, v ? p.dv_cross : p.dv_same);
+            store(dK, p.scale, v ? p.dk_cross : p.dk_same);
+        }
+        __syncthreads();                                           // the next pass restages V and the ring
+    }
+}
+
 // delta[b,h,s] = sum_d dO * O   (16 lanes per (token, head), head_dim 128)
 __global__ __launch_bounds__(256) void bridge_delta_kernel(const bf16_t* __restrict__ o, long ldo_, const bf16_t* __restrict__ dout,
                                                            long lddo, float* __restrict__ delta, int S, int H, long total_chunks) {
@@ -616,6 +911,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
@@ -626,6 +922,11 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    // LIBRA_ATTN_DKV=1 selects the round-1 structure (A/B measurements inside one box visit); read once, never written again
+    static const int dkv_structure = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 1; }();
+    if (dkv_structure == 1)
+        hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(bridge_attn_bwd_dkv2_kernel, dim3((unsigned)nblk), dim3(512), DKV2_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -360,7 +360,10 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         cache.length = S
     hidden, rstd_f = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
-    z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
+    z_lang = None
+    if n_l:                                                   # (row stride padded to 8 elements: any vocabulary size)
+        zl = torch.empty((n_l, K.round_up(d.vocab, 8)), dtype=BF16, device=dev)
+        z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx, out=zl[:, :d.vocab])
     z_vis = []
     vv_ld = K.round_up(d.vision_vocab, 8)
     for q in range(Q):
@@ -410,7 +413,10 @@ def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
                           positions=st["positions"], slot=st["slot"], kv_start=cache.start)
     hidden, _ = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
-    z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx) if n_l else None
+    z_lang = None
+    if n_l:                                                   # (row stride padded to 8 elements: any vocabulary size)
+        zl = torch.empty((n_l, K.round_up(d.vocab, 8)), dtype=BF16, device=dev)
+        z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx, out=zl[:, :d.vocab])
     z_vis = []
     vv_ld = K.round_up(d.vision_vocab, 8)
     for q in range(Q):

@@ -250,6 +250,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
         holder = {}
+        # (grad mode is always off inside Function.forward and needs_input_grad ignores no_grad(): read it here)
+        holder["grad_on"] = torch.is_grad_enabled()
         loss = _LibraFunction.apply(self, holder, names, input_ids, attention_mask, vision_indices, contiguous_signal, labels,
                                     bool(output_hidden_states), *params)
         out = holder["out"]
@@ -378,7 +380,7 @@ class _LibraFunction(torch.autograd.Function):
     def forward(ctx, model, holder, names, input_ids, attention_mask, vision_indices, signal, labels, want_hs, *params):
         sd = dict(zip(names, params))
         packed = model._refresh_packed(sd)
-        need = labels is not None and any(ctx.needs_input_grad[9:])
+        need = labels is not None and holder.get("grad_on", True) and any(ctx.needs_input_grad[9:])
         out = DE.forward(sd, packed, model._dims, input_ids, attention_mask, vision_indices, signal, labels,
                          want_hidden_states=want_hs, save=need,
                          recompute=need and model.model.gradient_checkpointing and model.training)

@@ -106,7 +106,7 @@ def test_vit_l_336_backward_vs_oracle_autograd():
             P + "pre_layrnorm.weight"]
     for i in (0, 11, 22):
         pre = f"{P}encoder.layers.{i}."
-        pick += [pre + n for n in ("self_attn.q_proj.weight", "self_attn.k_proj.bias", "self_attn.v_proj.weight",
+        pick += [pre + n for n in ("self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
                                    "self_attn.out_proj.weight", "self_attn.out_proj.bias", "layer_norm1.weight", "layer_norm2.bias",
                                    "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
     named = dict(m.named_parameters())
@@ -117,6 +117,10 @@ def test_vit_l_336_backward_vs_oracle_autograd():
         if ours > worst[1]:
             worst = (name, ours, theirs)
         assert ours < max(2 * theirs, 1e-2), (name, ours, theirs)
+    # d(loss)/d(k_proj.bias) is identically zero (a constant added to every key shifts each softmax row uniformly): both sides
+    # must leave only rounding noise there, far below the q bias gradient
+    kb, qb = f"{P}encoder.layers.11.self_attn.k_proj.bias", f"{P}encoder.layers.11.self_attn.q_proj.bias"
+    assert float(named[kb].grad.float().abs().max()) < 1e-2 * float(named[qb].grad.float().abs().max())
     # the last encoder layer is never reached by select_layer=[-2,-3]: no gradient, as in the reference's autograd
     assert named[f"{P}encoder.layers.23.mlp.fc1.weight"].grad is None and f"{P}encoder.layers.23.mlp.fc1.weight" not in g32
     parity_report(f"[configs[1] ViT-L/14@336 B=1 backward] {len(pick)} sampled weight gradients: worst ours {worst[1]:.3e} "
@@ -160,12 +164,13 @@ def test_vq_indices_at_baseline_batch_vs_fp64_oracle():
     # ---- stage A
     diff = h2d != hb
     nA = int(diff.sum())
-    ulp = (hb.float().abs() * 2.0 ** -7).clamp_min(1e-30)
     if nA:
-        assert bool(((h2d.float() - hb.float()).abs()[diff] <= ulp[diff]).all()), "h differs by more than one bf16 step"
-        mid = (h2d.double() + hb.double())[diff] / 2      # the rounding boundary between the two candidates
-        dist_ = (h64[diff] - mid).abs() / h64.abs().amax(1, keepdim=True).expand_as(h64)[diff]
-        assert float(dist_.max()) < 3e-5, f"h rounding differs away from a boundary (rel dist {float(dist_.max()):.2e})"
+        # hb is the bf16 nearest to h64; the kernel rounds h64 + eps (eps = fp32 accumulation noise of a 2048-deep reduction,
+        # bounded here by 1.5e-5 of the row scale): its result may be the neighbouring bf16 only when h64 lies within eps of the
+        # rounding boundary, i.e. |h2d - h64| <= |hb - h64| + 2 eps
+        eps = 1.5e-5 * h64.abs().amax(1, keepdim=True).expand_as(h64)[diff]
+        excess = (h2d.double() - h64)[diff].abs() - (hb.double() - h64)[diff].abs()
+        assert bool((excess <= 2 * eps).all()), f"h rounded away from a boundary: worst excess / eps = {float((excess / eps).max()):.2f}"
     # ---- stage B (on the kernel's own h)
     Wi, bi = sd["quantize.project_in.weight"].double().cuda(), sd["quantize.project_in.bias"].double().cuda()
     xk = h2d.double() @ Wi.t() + bi
@@ -184,7 +189,7 @@ def test_vq_indices_at_baseline_batch_vs_fp64_oracle():
     mflip = float(x64.abs().view(N, Q, 9)[flip].max()) if nflip else 0.0
     min_margin = float(x64.abs().min())
     parity_report(f"[configs[1] VQ encode B=32 E=512] {N * Q * 9} sign bits: stage A (h rounding) {nA} of {h2d.numel()} elements "
-                  f"one bf16 step off, all at a rounding boundary; stage B (bits on the kernel's own h) {nB} flips, max margin "
+                  f"differ from bf16(h64), all within fp32 accumulation noise of a rounding boundary; stage B (bits on the kernel's own h) {nB} flips, max margin "
                   f"{mB:.2e}; end-to-end vs float64 chain: {nflip} bit flips in {nidx} of {N * Q} indices, largest |x64| among "
                   f"flips {mflip:.2e}, min |x64| over all bits {min_margin:.2e}")
     assert nflip <= max(4, int(2e-4 * N * Q * 9)) and mflip < 2e-2, (nflip, mflip)
