@@ -650,11 +650,11 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
     };
     auto next_needed = [&](int t, int v) -> int {
         for (; t < nqt; ++t) if (need(t, v)) break;
-        return t;
+        return __builtin_amdgcn_readfirstlane(t);                // (workgroup-uniform by construction: keep it in an SGPR)
     };
     // lane-constant halves of the LDS offsets (see the header comment): row image reads and the two transposed reads
     const int tz = tswz(l31);
-    const int xr = l31 * 256 + ((fk ^ tz) << 4);                 // nread_t(tile, l31, 2 ks + fk) = tile + (xr ^ (ks << 5))
+    int xr = l31 * 256 + ((fk ^ tz) << 4);                 // nread_t(tile, l31, 2 ks + fk) = tile + (xr ^ (ks << 5))
     int xt0, xt1;                                                // tread_t(tile, lane, dt, sx) = {tile + 4096 sx + (xt0 ^ (dt << 6)), tile + 4096 sx + 2048 + (xt1 ^ (dt << 6))}
     {
         const int pp = lane & 15, g16 = (lane >> 4) & 1;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
         xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
         xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
     }
-    const int xv = l31 * 128 + ((fk ^ ((l31 >> 1) & 7)) << 4);   // nfrag(tile, l31, ks, fk, 8192) = tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5))
+    int xv = l31 * 128 + ((fk ^ ((l31 >> 1) & 7)) << 4);   // nfrag(tile, l31, ks, fk, 8192) = tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5))
     auto rd_row = [&](const char* tile, int ks) -> bf16x8 { return *(const bf16x8*)(tile + (xr ^ (ks << 5))); };
     auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
         union { bf16x8 v; s16x4 h2[2]; } u;
@@ -705,17 +705,22 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
             if (nx < nqt) stage_q(buf ^ 1, nx);
             const int q0 = it * QT2 + qs * 32;
             const char* stg = smem + buf * ST2;
+            // the four lane constants are re-materialised per tile: hoisted out of the loop, their XOR-ed variants (24
+            // registers) would be kept alive across it and spill
+            asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
             it = nx; buf ^= 1;
-            if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
+            // every branch below is wave-uniform and must LOOK uniform to the compiler (MFMA ignores EXEC: under a branch it
+            // believes divergent it copies every accumulator it touches) - conditions go through readfirstlane
+            if (__builtin_amdgcn_readfirstlane((int)(kbase_w >= S || q0 >= S || q0 + 31 < kbase_w))) continue;   // no (query >= key) pair
             const unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[q0 >> 5]);
             int nvalid = S - q0; nvalid = nvalid > 32 ? 32 : nvalid;
             const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
             const bool qV = (qm & full) != 0, qL = ((~qm) & full) != 0;
             const bool wsame = (qL && wkL) || (qV && wkV);
             const bool wcross = (qL && wkV) || (qV && wkL);
-            if (!(v ? wcross : wsame)) continue;
-            const bool mixed = wsame && wcross;
-            const bool masked = q0 < kbase_w + 31 || q0 + 32 > S || kbase_w + 32 > len;
+            if (__builtin_amdgcn_readfirstlane((int)!(v ? wcross : wsame))) continue;
+            const bool mixed = __builtin_amdgcn_readfirstlane((int)(wsame && wcross)) != 0;
+            const bool masked = __builtin_amdgcn_readfirstlane((int)(q0 < kbase_w + 31 || q0 + 32 > S || kbase_w + 32 > len)) != 0;
             const char* sq = stg + qs * 8192;                     // this wave's 32 query rows of the Q image
             const char* sdo = sq + 32768;                         //                          ... of the dO image
             const float* sL = (const float*)(stg + 65536) + qs * 32;

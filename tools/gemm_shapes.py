@@ -10,10 +10,9 @@ from libra_amd import kernels as K
 wl = sys.argv[1] if len(sys.argv) > 1 else "libra"
 dev = torch.device("cuda", 0)
 if wl == "vit":
-    clip, tok, pixel, cot = bench.build(dev, 32)
-    step = bench.make_step(clip, tok, pixel, cot, 1)
+    step = bench.make_vit(dev, 32, 1, "allreduce").step
 else:
-    step, _ = bench.build_libra(dev, 8)
+    step = bench.make_bridge(dev, 8, 2048, 1, "allreduce").step
 recs = []
 mods = [m for m in sys.modules.values() if m is not None and getattr(m, "__name__", "").startswith("libra_amd")]
 orig = K.gemm_nt
