@@ -574,6 +574,9 @@ constexpr int DKV2_VRES = 2 * ST2;             // resident V tile of the pass's 
 constexpr int DKV2_MASK = DKV2_VRES + 16384;
 constexpr int DKV2_LDS_B = DKV2_MASK + 1024;
 
+// DBG (timing experiments only, results are wrong): 1 = no partial-sum exchange / store, 2 = no prefetch of the next tile,
+// 4 = no per-pair compute
+template <int DBG>
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* vres = smem + DKV2_VRES;
@@ -702,13 +705,14 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int nx = next_needed(it + 1, v);
-            if (nx < nqt) stage_q(buf ^ 1, nx);
+            if (!(DBG & 2) && nx < nqt) stage_q(buf ^ 1, nx);
             const int q0 = it * QT2 + qs * 32;
             const char* stg = smem + buf * ST2;
             // the four lane constants are re-materialised per tile: hoisted out of the loop, their XOR-ed variants (24
             // registers) would be kept alive across it and spill
             asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
             it = nx; buf ^= 1;
+            if (DBG & 4) continue;
             // every branch below is wave-uniform and must LOOK uniform to the compiler (MFMA ignores EXEC: under a branch it
             // believes divergent it copies every accumulator it touches) - conditions go through readfirstlane
             if (__builtin_amdgcn_readfirstlane((int)(kbase_w >= S || q0 >= S || q0 + 31 < kbase_w))) continue;   // no (query >= key) pair
@@ -809,6 +813,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
                     }
             }
         };
+        if (!(DBG & 1)) {
         if (qs > 0) give(dV);
         __syncthreads();
         if (qs == 0) take(dV);
@@ -817,7 +822,8 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
         __syncthreads();
         if (qs == 0) take(dK);
         __syncthreads();
-        if (qs == 0 && kbase_w < S) {
+        }
+        if (!(DBG & 1) && qs == 0 && kbase_w < S) {
             // each wave's [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
             char* so = smem + wave * (32 * OROW);
             auto store = [&](const f32x16* acc, float mul, bf16_t* dst) {
@@ -916,7 +922,11 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
@@ -931,7 +941,11 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     static const int dkv_structure = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 1; }();
     if (dkv_structure == 1)
         hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(bridge_attn_bwd_dkv2_kernel, dim3((unsigned)nblk), dim3(512), DKV2_LDS_B, (hipStream_t)stream, a);
+    else {
+        static const int dbg = [] { const char* e = getenv("LIBRA_DKV2_DBG"); return e ? atoi(e) : 0; }();
+        auto kern = dbg == 1 ? bridge_attn_bwd_dkv2_kernel<1> : dbg == 2 ? bridge_attn_bwd_dkv2_kernel<2>
+                  : dbg == 4 ? bridge_attn_bwd_dkv2_kernel<4> : dbg == 6 ? bridge_attn_bwd_dkv2_kernel<6> : bridge_attn_bwd_dkv2_kernel<0>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), DKV2_LDS_B, (hipStream_t)stream, a);
+    }
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -135,8 +135,8 @@ def pack(sd: Dict[str, torch.Tensor], d: DecDims) -> PackedOperands:
 
 
 def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims, *, allow_left: bool = False):
-    """-> flag uint8 [N], lang_idx / vis_idx int32, kv_len int32 [B] (end of the valid tokens) and - with `allow_left` -
-    kv_start int32 [B] or None.  One host sync per batch.
+    """-> flag uint8 [N], lang_idx / vis_idx int32, kv_len int32 [B] (end of the valid tokens), kv_start int32 [B] (first valid
+    token; None unless some sequence is left-padded, which needs `allow_left`).  One host sync per batch.
     Training pads RIGHT (libra_pretrain.yaml:17 `padding_side: right`); batched generation pads LEFT (demo/libra_demo.ipynb sets
     `padding_side = 'left'`): the inference forward accepts one contiguous block of valid tokens per sequence."""
     B, S = vision_indices.shape
@@ -157,10 +157,8 @@ def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims
     if left and not allow_left:
         raise NotImplementedError("left-padded batches are an inference-only path: the backward kernels assume right padding, "
                                   "as the training recipes pad (libra_pretrain.yaml:17 `padding_side: right`)")
-    out = (flag.to(torch.uint8).contiguous(), lang_idx.contiguous(), vis_idx.contiguous(), ends.contiguous())
-    if allow_left:
-        out = out + (first.contiguous() if left else None,)
-    return out
+    return (flag.to(torch.uint8).contiguous(), lang_idx.contiguous(), vis_idx.contiguous(), ends.contiguous(),
+            first.contiguous() if left else None)
 
 
 def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None):

@@ -181,7 +181,8 @@ class LibraGenerationMixin:
                streamer=None, generator: Optional[torch.Generator] = None, **model_kwargs):
         """one multinomial draw per codebook and sequence from softmax(scores) (modeling_libra_utils.py:330-620)."""
         def choose(scores):
-            probs = torch.softmax(scores.float(), dim=-1)
+            # a forced token is scored +inf (the EOI -> newline rule): clamp so that its probability is 1, not NaN
+            probs = torch.softmax(torch.nan_to_num(scores.float(), posinf=torch.finfo(torch.float32).max), dim=-1)
             return torch.stack([torch.multinomial(p, num_samples=1, generator=generator).squeeze(1) for p in probs])
         return self._generation_loop(input_ids, choose, logits_processor=logits_processor, logits_warper=logits_warper,
                                      stopping_criteria=stopping_criteria, max_length=max_length, pad_token_id=pad_token_id,

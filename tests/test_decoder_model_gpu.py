@@ -124,7 +124,7 @@ def test_libra_full_width_single_layer_vs_oracle():
                    signal=2048)
     dsd = {k: v.cuda() for k, v in sd.items()}
     pk = DE.pack(dsd, d)
-    flag, li, vidx, lens = DE.route(vi.cuda(), am.cuda(), d)
+    flag, li, vidx, lens, _ = DE.route(vi.cuda(), am.cuda(), d)
     cos, sin = DE.rope_tables(128, 2048, "cuda")
     y = DE.layer_forward(dsd, pk[0], 0, d, x.view(B * S, H).cuda(), flag, li, vidx, lens, cos, sin, B, S).view(B, S, H)
     f = vi < L

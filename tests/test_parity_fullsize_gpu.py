@@ -34,7 +34,7 @@ def test_full_width_decoder_layer_backward_vs_oracle_autograd():
     dsd = {k: v.cuda() for k, v in sd.items()}
     dsd["model.embed_tokens.weight"] = torch.zeros(8, H, dtype=BF, device="cuda")
     pk = DE.pack(dsd, d)
-    flag, li, vidx, lens = DE.route(vi.cuda(), am.cuda(), d)
+    flag, li, vidx, lens, _ = DE.route(vi.cuda(), am.cuda(), d)
     cos, sin = DE.rope_tables(128, 2048, "cuda")
     sv = {}
     y = DE.layer_forward(dsd, pk[0], 0, d, x.view(B * S, H).cuda(), flag, li, vidx, lens, cos, sin, B, S, sv)
