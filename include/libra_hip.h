@@ -117,12 +117,16 @@ int libra_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t cols, flo
 /* ---- ViT self-attention, flash style (CLIPAttention.forward, modeling_clip.py:287-363) -------------
  * qkv [B*T, 3*H*64] bf16 (q | k | v, head h at columns h*64 of each third; q UNscaled).
  * out [B*T, H*64] bf16, lse [B,H,T] fp32 (natural-log-sum-exp of the scaled scores; may be NULL).
- * head_dim is fixed at 64 (CLIP ViT-L/14).  K and V tiles are read where they lie (no transposed copies). */
-int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B,
+ * head_dim is fixed at 64 (CLIP ViT-L/14).  K and V tiles are read where they lie (no transposed copies).
+ * out_lo (optional, layout of out): the rounding residual bf16(O - bf16(O)) of the fp32 output.  The backward's
+ * D_i = sum_d dO_id O_id is a difference-sensitive term (dS = P (dP - D)): taken from the bf16 O alone, q / k weight gradients
+ * of ViT-L came out 3-9 % off where the reference's bf16 autograd is 1-2 % off (profiles/r02_parity.txt); with O + out_lo
+ * (~16 mantissa bits) they are within 1 %. */
+int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, void* out_lo, int64_t B,
                        int64_t T, int64_t H, float scale, void* stream);
 /* D = rowsum(dO * O) per (image, head, token): delta [B,H,T] fp32.                                   */
-int libra_vit_attn_delta(const void* out, const void* dout, int64_t ld, float* delta, int64_t B,
-                         int64_t T, int64_t H, void* stream);
+int libra_vit_attn_delta(const void* out, const void* out_lo, const void* dout, int64_t ld, float* delta, int64_t B, int64_t T,
+                         int64_t H, void* stream);
 /* Backward (autograd of modeling_clip.py:308-348): from qkv, dO [B*T,H*64], lse and delta produce
  * dqkv [B*T, 3*H*64] (dq/dk already multiplied by `scale`, i.e. gradients w.r.t. the UNscaled q, k).
  * Deterministic: two passes (dQ; dK/dV), no atomics, no transposed operand copies.                    */
@@ -185,18 +189,20 @@ int libra_bridge_attn_decode(const void* q, int64_t ldq, const void* k_same, con
 /* Fused routed-bridge causal flash attention, forward (LibraAttention.forward + attn_with_bridge,
  * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right padding via
  * kv_len[b] = end of the valid keys, +left padding via kv_start[b] = first valid key; either may be NULL), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row
- * strides ldq/ldk/ldkc/ldv/ldvc; flag [B*S] (1 = vision token); out [B*S, H*128]; lse [B,H,S] fp32 optional.      */
+ * strides ldq/ldk/ldkc/ldv/ldvc; flag [B*S] (1 = vision token); out [B*S, H*128]; lse [B,H,S] fp32 optional;
+ * out_lo optional (layout of out): rounding residual of the output for the backward's D term, see libra_vit_attn_fwd.   */
 int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                           int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                           const uint8_t* flag,
-                          const int32_t* kv_len, const int32_t* kv_start, void* out, int64_t ldo, float* lse, int64_t B,
-                          int64_t S, int64_t H, float scale, void* stream);
+                          const int32_t* kv_len, const int32_t* kv_start, void* out, int64_t ldo, float* lse, void* out_lo,
+                          int64_t B, int64_t S, int64_t H, float scale, void* stream);
 /* Backward of libra_bridge_attn_fwd (deterministic, two passes): from dO and the forward's operands / lse produce
  * dq [B*S,H*128] (w.r.t. the rotated q) and the four operand gradients dK_same, dK_cross, dV_same, dV_cross
- * ([B*S, H*128], row stride ldg).  `out` is the forward output (for D = rowsum(dO*O)); delta [B,H,S] is scratch.  */
+ * ([B*S, H*128], row stride ldg).  `out` (+ optional `out_lo`) is the forward output (for D = rowsum(dO*O)); delta [B,H,S] is
+ * scratch.  */
 int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                           int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
-                          const void* out, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
+                          const void* out, const void* out_lo, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
                           const int32_t* kv_len, const float* lse, float* delta, void* dq, int64_t lddq,
                           void* dk_same, void* dk_cross, void* dv_same, void* dv_cross, int64_t ldg, int64_t B,
                           int64_t S, int64_t H, float scale, void* stream);
@@ -250,6 +256,27 @@ int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const void* dk_cr
 int libra_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 /* y = a + b (bf16, n % 8 == 0 not required) */
 int libra_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* ---- VQ image decoder (image generation: LFQ.indices_to_codes -> post_quant_conv -> taming Decoder) -----------------------
+ * Activations are NHWC bf16 ([pixels, channels] row-major); 1x1 convs and the gathered 3x3 convs run on libra_gemm_bf16_nt. */
+/* codes[m, q*nbits + j] = +-1 from bit (nbits-1-j) of indices[m,q] (MSB first; lookup_free_quantization.py:111,:129-158);
+ * columns >= Q*nbits up to ldc are zero (GEMM K granule).  ldc % 8 == 0. */
+int libra_lfq_codes(const int64_t* indices, void* codes, int64_t M, int64_t Q, int64_t nbits, int64_t ldc, void* stream);
+/* GroupNorm(G groups, eps) statistics of x [B, HW, C] folded with gamma / beta into the per-(image, channel) affine
+ * y = x * scale + shift (fp32 [B, C] each; Normalize = GroupNorm(32, eps 1e-6), diffusionmodules/model.py:34-35).
+ * Deterministic two-stage reduction; C % 8 == 0, C <= 1024. */
+size_t libra_groupnorm_workspace_bytes(int64_t B, int64_t HW, int64_t C);
+int libra_groupnorm_affine(const void* x, const void* gamma, const void* beta, float* scale, float* shift, int64_t B, int64_t HW,
+                           int64_t C, int64_t G, float eps, void* workspace, size_t workspace_bytes, void* stream);
+/* Gathered conv operand: out[(b,y,x), tap*C + c] = f(x[b, sy, sx, c]) over the ksize x ksize window (ksize 1 or 3, zero padding)
+ * of the nearest-neighbour upsampled image [H, W] of x [B, Hs, Ws, C] (source index = min(int(floorf(dst * inv_scale)), n-1),
+ * PyTorch's rule; Upsample, model.py:38-56); f = identity, or GroupNorm affine (scale/shift [B,C], result rounded to bf16) then
+ * optionally swish (x * sigmoid(x), model.py:28-31) with the reference's bf16 rounding points.  Columns up to ldo are zero. */
+int libra_conv_gather(const void* x, void* out, int64_t ldo, const float* scale, const float* shift, int swish, int64_t B,
+                      int64_t Hs, int64_t Ws, int64_t C, int64_t H, int64_t W, int64_t ksize, float inv_scale_h,
+                      float inv_scale_w, void* stream);
+/* x[r, :cols] <- softmax(bf16(x[r, :cols] * scale)), x[r, cols:ld] <- 0  (AttnBlock, model.py:170-196: bmm * c^-0.5, softmax) */
+int libra_softmax_rows(void* x, int64_t rows, int64_t cols, int64_t ld, float scale, void* stream);
 
 /* ---- optimizer -----------------------------------------------------------------------------------*/
 /* Fused AdamW on a flat range of n elements (the data-parallel optimizer step of the reference's recipes: AdamW via HF

@@ -34,8 +34,8 @@ SIGNATURES = {
     "libra_patch_im2col": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_patch_col2im": [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_vit_embed_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
-    "libra_vit_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
-    "libra_vit_attn_delta": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_vit_attn_fwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _P],
+    "libra_vit_attn_delta": [_P, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_vit_attn_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
     "libra_feature_select": [_P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_feature_select_bwd": [_P, _P, _P, _I64, _I64, _I64, _I64, _P],
@@ -44,8 +44,8 @@ SIGNATURES = {
     "libra_rope_bridge": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "libra_rope_bridge_pos": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _P],
     "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
-    "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
-    "libra_bridge_attn_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
+    "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _P],
+    "libra_bridge_attn_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
                               _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
     "libra_swiglu": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_gather_rows": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _P],
@@ -60,6 +60,11 @@ SIGNATURES = {
                               _I64, _I64, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
+    "libra_lfq_codes": [_P, _P, _I64, _I64, _I64, _I64, _P],
+    "libra_groupnorm_workspace_bytes": [_I64, _I64, _I64],
+    "libra_groupnorm_affine": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, C.c_size_t, _P],
+    "libra_conv_gather": [_P, _P, _I64, _P, _P, _I, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _F, _P],
+    "libra_softmax_rows": [_P, _I64, _I64, _I64, _F, _P],
     "libra_adamw_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P],
 }
 

@@ -36,6 +36,7 @@ struct BridgeArgs {
     const int* kv_start;           // [B] first valid key (LEFT padding: generation prompts, demo/libra_demo.ipynb), or null
     bf16_t* out; long ldo;
     float* lse;                    // [B,H,S] or null
+    bf16_t* out_lo;                // optional rounding residual of `out` (same layout), see libra_bridge_attn_fwd
     int B, S, H, n_qt;
     float sl2;
 };
@@ -304,35 +305,47 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     __syncthreads();
     constexpr int OROW = 264;                           // 128 bf16 + 8 B pad
     char* so = smem + wave * (32 * OROW);
-    if (active) {
+    // two passes through the per-wave staging rows: the bf16 output, then (when asked for) its rounding residual
+#pragma unroll 1
+    for (int part = 0; part < (p.out_lo ? 2 : 1); ++part) {
+        if (part) __syncthreads();
+        if (active) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + 8 * g + 4 * fk;
-                u32x2 w;
-                w[0] = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-                w[1] = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-                *(u32x2*)(so + l31 * OROW + d * 2) = w;
-            }
-        if (p.lse && fk == 0 && q0w + l31 < S)
-            p.lse[((long)b * p.H + h) * S + q0w + l31] =
-                l_tot > 0.f ? (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f : -INFINITY;
-    }
-    __syncthreads();
-    if (active) {
-        // 32 rows x 256 B: lane -> (row = pass*4 + lane/16, 16-byte chunk lane%16)
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * fk;
+                    float x[4];
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 4 + (lane >> 4);
-            const int qq = q0w + r;
-            if (qq < S) {
-                const char* src = so + r * OROW + (lane & 15) * 16;
-                const u32x2 a = *(const u32x2*)src;
-                const u32x2 c2 = *(const u32x2*)(src + 8);
-                u32x4 v;
-                v[0] = a[0]; v[1] = a[1]; v[2] = c2[0]; v[3] = c2[1];
-                *(u32x4*)(p.out + (tok0 + qq) * p.ldo + h * BD + (lane & 15) * 8) = v;
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = o[dt][4 * g + e] * inv;
+                        if (part) x[e] -= bf2f(f2bf(x[e]));
+                    }
+                    u32x2 w;
+                    w[0] = pack2bf(x[0], x[1]);
+                    w[1] = pack2bf(x[2], x[3]);
+                    *(u32x2*)(so + l31 * OROW + d * 2) = w;
+                }
+            if (!part && p.lse && fk == 0 && q0w + l31 < S)
+                p.lse[((long)b * p.H + h) * S + q0w + l31] =
+                    l_tot > 0.f ? (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f : -INFINITY;
+        }
+        __syncthreads();
+        if (active) {
+            bf16_t* dst = part ? p.out_lo : p.out;
+            // 32 rows x 256 B: lane -> (row = pass*4 + lane/16, 16-byte chunk lane%16)
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 4 + (lane >> 4);
+                const int qq = q0w + r;
+                if (qq < S) {
+                    const char* src = so + r * OROW + (lane & 15) * 16;
+                    const u32x2 a = *(const u32x2*)src;
+                    const u32x2 c2 = *(const u32x2*)(src + 8);
+                    u32x4 v;
+                    v[0] = a[0]; v[1] = a[1]; v[2] = c2[0]; v[3] = c2[1];
+                    *(u32x4*)(dst + (tok0 + qq) * p.ldo + h * BD + (lane & 15) * 8) = v;
+                }
             }
         }
     }
@@ -346,7 +359,7 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
                                      int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                                      const uint8_t* flag,
                                      const int32_t* kv_len, const int32_t* kv_start, void* out, int64_t ldo, float* lse,
-                                     int64_t B, int64_t S, int64_t H, float scale, void* stream) {
+                                     void* out_lo, int64_t B, int64_t S, int64_t H, float scale, void* stream) {
     if (B <= 0 || S <= 0) return LIBRA_OK;
     if (H <= 0 || ldq < H * BD || ldk < H * BD || ldv < H * BD || ldkc < H * BD || ldvc < H * BD || ldo < H * BD || S > 4096 ||
         ldk >= (1 << 18) || ldkc >= (1 << 18) || ldv >= (1 << 18) || ldvc >= (1 << 18))
@@ -358,7 +371,8 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     BridgeArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.k_cross = (const bf16_t*)k_cross; a.ldk = ldk; a.ldkc = ldkc;
     a.v_same = (const bf16_t*)v_same; a.v_cross = (const bf16_t*)v_cross; a.ldv = ldv; a.ldvc = ldvc;
-    a.flag = flag; a.kv_len = kv_len; a.kv_start = kv_start; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
+    a.flag = flag; a.kv_len = kv_len; a.kv_start = kv_start; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse; a.out_lo = (bf16_t*)out_lo;
+    if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.n_qt = (int)((S + BQ - 1) / BQ);
     a.sl2 = scale * 1.4426950408889634f;
     const long nblk = (long)B * H * a.n_qt;

@@ -571,7 +571,8 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
 constexpr int QT2 = 128;
 constexpr int ST2 = 2 * 32768 + 1024;          // Q image, dO image (128 queries each), L[128], D[128]
 constexpr int DKV2_VRES = 2 * ST2;             // resident V tile of the pass's variant: [64 keys][128 d]
-constexpr int DKV2_MASK = DKV2_VRES + 16384;
+constexpr int DKV2_KRES = DKV2_VRES + 16384;   // resident K, d 0..63 only: [64 keys][64 d] (d 64..127 of the wave's keys live in registers)
+constexpr int DKV2_MASK = DKV2_KRES + 8192;
 constexpr int DKV2_LDS_B = DKV2_MASK + 1024;
 
 // DBG (timing experiments only, results are wrong): 1 = no partial-sum exchange / store, 2 = no prefetch of the next tile,
@@ -580,6 +581,7 @@ template <int DBG>
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* vres = smem + DKV2_VRES;
+    char* kres = smem + DKV2_KRES;
     unsigned* qmask = (unsigned*)(smem + DKV2_MASK);             // per 32 queries: bit i = query i is a vision token
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -623,12 +625,39 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
     const bf16_t* dobase = p.dout + tok0 * p.ldo + h * D128;
     const float* lbase = p.lse + ((long)b * p.H + h) * S;
     const float* dbase = p.delta + ((long)b * p.H + h) * S;
+    // per-lane byte offsets of this wave's two 1-KiB pieces inside a 64-row block (row r = 4 pc + lane/16, chunk (lane%16)^tswz(r)):
+    // tile-independent, so a full tile is staged with a scalar base per 64-row block and NO per-lane arithmetic
+    unsigned vq[2], vd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 4 + (lane >> 4);
+        const unsigned c16 = (unsigned)(((lane & 15) ^ tswz(r)) * 16);
+        vq[j] = (unsigned)r * (unsigned)p.ldq * 2u + c16;
+        vd[j] = (unsigned)r * (unsigned)p.ldo * 2u + c16;
+    }
+    // (under the register pressure of the tile loop the compiler parks the uniform S in a VGPR and spills it: the loop-side users
+    // re-read it from the kernel arguments - a scalar load - instead of a scratch reload behind the LDS-DMA queue)
+    auto S_arg = [&]() -> int { return __builtin_amdgcn_readfirstlane(*(const volatile int*)&p.S); };
     auto stage_q = [&](int buf, int t) {
         char* dst = smem + buf * ST2;
-        stage_t64(qbase, (unsigned)p.ldq * 2u, t * QT2, S, dst, wave, lane);
-        stage_t64(qbase, (unsigned)p.ldq * 2u, t * QT2 + 64, S, dst + 16384, wave, lane);
-        stage_t64(dobase, (unsigned)p.ldo * 2u, t * QT2, S, dst + 32768, wave, lane);
-        stage_t64(dobase, (unsigned)p.ldo * 2u, t * QT2 + 64, S, dst + 49152, wave, lane);
+        const int S = S_arg();
+        if (__builtin_amdgcn_readfirstlane((int)(t * QT2 + QT2 <= S))) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const bf16_t* qb = qbase + (long)(t * QT2 + hb * 64) * p.ldq;
+                const bf16_t* db = dobase + (long)(t * QT2 + hb * 64) * p.ldo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    glds16_off(qb, vq[j], dst + hb * 16384 + (wave * 2 + j) * 1024);
+                    glds16_off(db, vd[j], dst + 32768 + hb * 16384 + (wave * 2 + j) * 1024);
+                }
+            }
+        } else {                                                 // the ragged last tile: clamped rows
+            stage_t64(qbase, (unsigned)p.ldq * 2u, t * QT2, S, dst, wave, lane);
+            stage_t64(qbase, (unsigned)p.ldq * 2u, t * QT2 + 64, S, dst + 16384, wave, lane);
+            stage_t64(dobase, (unsigned)p.ldo * 2u, t * QT2, S, dst + 32768, wave, lane);
+            stage_t64(dobase, (unsigned)p.ldo * 2u, t * QT2 + 64, S, dst + 49152, wave, lane);
+        }
         if (wave < 4) {                                          // 128 fp32 each: two 4-byte direct-to-LDS ops per array
             int qi = t * QT2 + (wave & 1) * 64 + lane; qi = qi < S ? qi : S - 1;
             glds4((wave < 2 ? lbase : dbase) + qi, dst + 65536 + (wave >> 1) * 512 + (wave & 1) * 256);
@@ -638,6 +667,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
     const int it0 = key0 / QT2;                                  // first query tile that can see this key block
     // does tile `t` hold a (query, key-of-this-block) pair of variant v?  (workgroup-uniform)
     auto need = [&](int t, int v) -> bool {
+        const int S = S_arg();
         unsigned m[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[4 * t + j]);
@@ -652,6 +682,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
         return v == 0 ? ((qV && bkV) || (qL && bkL)) : ((qV && bkL) || (qL && bkV));
     };
     auto next_needed = [&](int t, int v) -> int {
+        const int nqt = (S_arg() + QT2 - 1) / QT2;
         for (; t < nqt; ++t) if (need(t, v)) break;
         return __builtin_amdgcn_readfirstlane(t);                // (workgroup-uniform by construction: keep it in an SGPR)
     };
@@ -683,13 +714,15 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
         const long ldkk = v ? p.ldkc : p.ldk;
         const bf16_t* vp = (v ? p.v_cross + tok0 * p.ldvc : p.v_same + tok0 * p.ldv) + h * D128;
         const unsigned ldvv = (unsigned)(v ? p.ldvc : p.ldv) * 2u;
-        bf16x8 kf[8];                                             // K[key = l31][16 ks + 8 fk .. +8]: B operand of S = Q K^T
+        // B operand of S = Q K^T, K[key = l31][16 ks + 8 fk .. +8]: k-steps 4..7 (d 64..127) in registers for the whole pass, k-steps
+        // 0..3 from the 8-KiB resident tile (all eight in registers spilled: 128 accumulator + 32 + 32 score registers are live)
+        bf16x8 kf[4];
         {
-            const bf16_t* kr = kp + (long)key * ldkk + fk * 8;
+            const bf16_t* kr = kp + (long)key * ldkk + 64 + fk * 8;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) kf[ks] = *(const bf16x8*)(kr + ks * 16);
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(kr + ks * 16);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) pin(kf[ks]);          // landed before any LDS-DMA of this pass is in flight
+            for (int ks = 0; ks < 4; ++ks) pin(kf[ks]);          // landed before any LDS-DMA of this pass is in flight
         }
         f32x16 dV[4], dK[4];                                      // [128 d x 32 keys] each, this pass's variant
 #pragma unroll
@@ -697,10 +730,12 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dV[i][r] = 0.f; dK[i][r] = 0.f; }
         stage_res64(vp, ldvv, key0, S, vres, wave, lane);
+        if (wave < 4) stage_res64(kp, (unsigned)ldkk * 2u, key0, S, kres, wave, lane);      // pieces 0..7 = the d 0..63 sub-tile
         int it = next_needed(it0, v);
         if (it < nqt) stage_q(0, it);
         int buf = 0;
         const char* rV = vres + kw * 32 * 128;                    // this wave's 32 key rows inside each 64-row sub-tile
+        const char* rK = kres + kw * 32 * 128;
         while (it < nqt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -735,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq, ks), kf[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq, ks), ks < 4 ? rd_v(rK, ks) : kf[ks - 4], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sdo, ks), rd_v(rV, ks), dp, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -860,8 +895,9 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
 }
 
 // delta[b,h,s] = sum_d dO * O   (16 lanes per (token, head), head_dim 128)
-__global__ __launch_bounds__(256) void bridge_delta_kernel(const bf16_t* __restrict__ o, long ldo_, const bf16_t* __restrict__ dout,
-                                                           long lddo, float* __restrict__ delta, int S, int H, long total_chunks) {
+__global__ __launch_bounds__(256) void bridge_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ o_lo, long ldo_,
+                                                           const bf16_t* __restrict__ dout, long lddo, float* __restrict__ delta,
+                                                           int S, int H, long total_chunks) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < total_chunks;
     const int cpr = H * 16;
@@ -872,6 +908,12 @@ __global__ __launch_bounds__(256) void bridge_delta_kernel(const bf16_t* __restr
         float a[8], g[8];
         unpack8(*(const u32x4*)(o + row * ldo_ + ch * 8), a);
         unpack8(*(const u32x4*)(dout + row * lddo + ch * 8), g);
+        if (o_lo) {                                           // O to ~16 mantissa bits (see libra_bridge_attn_fwd: out_lo)
+            float l[8];
+            unpack8(*(const u32x4*)(o_lo + row * ldo_ + ch * 8), l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += l[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += a[e] * g[e];
     }
@@ -890,7 +932,7 @@ using namespace libra;
 
 extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                                      int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
-                                     const void* out, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
+                                     const void* out, const void* out_lo, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
                                      const int32_t* kv_len, const float* lse, float* delta, void* dq, int64_t lddq,
                                      void* dk_same, void* dk_cross, void* dv_same, void* dv_cross, int64_t ldg, int64_t B,
                                      int64_t S, int64_t H, float scale, void* stream) {
@@ -906,10 +948,11 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     if (((uintptr_t)q | (uintptr_t)k_same | (uintptr_t)k_cross | (uintptr_t)v_same | (uintptr_t)v_cross | (uintptr_t)out |
          (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk_same | (uintptr_t)dk_cross | (uintptr_t)dv_same | (uintptr_t)dv_cross) & 15)
         return LIBRA_ERR_ALIGN;
+    if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
     const long rows = B * S;
     const long total = rows * H * 16;
     hipLaunchKernelGGL(bridge_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)out, (long)ldout, (const bf16_t*)dout, (long)lddo, delta, (int)S, (int)H, total);
+                       (const bf16_t*)out, (const bf16_t*)out_lo, (long)ldout, (const bf16_t*)dout, (long)lddo, delta, (int)S, (int)H, total);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     BridgeBwdArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.ldk = ldk; a.k_cross = (const bf16_t*)k_cross; a.ldkc = ldkc;

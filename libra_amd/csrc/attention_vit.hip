@@ -34,6 +34,7 @@ struct AttnFwdArgs {
     const bf16_t* qkv; long ld_qkv;
     bf16_t* out; long ld_out;
     float* lse;
+    bf16_t* out_lo;                // optional: bf16(O_fp32 - float(bf16(O_fp32))), same layout as out (see libra_vit_attn_fwd)
     int B, T, H, n_qt;
     float sl2;      // scale * log2(e)
 };
@@ -172,34 +173,46 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
     __syncthreads();                                   // everyone is done with the K/V buffers
     constexpr int OROW = 136;                          // bytes per staged output row (64 bf16 + 8 B pad)
     char* so = smem + wave * (32 * OROW);
-    if (active) {
+    // two passes through the per-wave staging rows: the bf16 output, then (when asked for) its rounding residual
+#pragma unroll 1
+    for (int part = 0; part < (p.out_lo ? 2 : 1); ++part) {
+        if (part) __syncthreads();
+        if (active) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + 8 * g + 4 * half;
-                u32x2 w;
-                w[0] = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-                w[1] = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-                *(u32x2*)(so + l31 * OROW + d * 2) = w;
-            }
-        if (p.lse && half == 0 && q0 + l31 < T)
-            p.lse[((long)b * p.H + h) * T + q0 + l31] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
-    }
-    __syncthreads();
-    if (active) {
-        // 32 rows x 128 B: lane -> (row = pass*8 + lane/8, 16-byte chunk lane%8)
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * half;
+                    float x[4];
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int r = pass * 8 + (lane >> 3);
-            const int q = q0 + r;
-            if (q < T) {
-                const char* src = so + r * OROW + (lane & 7) * 16;
-                u32x4 v;
-                const u32x2 a = *(const u32x2*)src;
-                const u32x2 c2 = *(const u32x2*)(src + 8);
-                v[0] = a[0]; v[1] = a[1]; v[2] = c2[0]; v[3] = c2[1];
-                *(u32x4*)(p.out + (tok0 + q) * p.ld_out + h * HD + (lane & 7) * 8) = v;
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = o[dt][4 * g + e] * inv;
+                        if (part) x[e] -= bf2f(f2bf(x[e]));
+                    }
+                    u32x2 w;
+                    w[0] = pack2bf(x[0], x[1]);
+                    w[1] = pack2bf(x[2], x[3]);
+                    *(u32x2*)(so + l31 * OROW + d * 2) = w;
+                }
+            if (!part && p.lse && half == 0 && q0 + l31 < T)
+                p.lse[((long)b * p.H + h) * T + q0 + l31] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        }
+        __syncthreads();
+        if (active) {
+            bf16_t* dst = part ? p.out_lo : p.out;
+            // 32 rows x 128 B: lane -> (row = pass*8 + lane/8, 16-byte chunk lane%8)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 8 + (lane >> 3);
+                const int q = q0 + r;
+                if (q < T) {
+                    const char* src = so + r * OROW + (lane & 7) * 16;
+                    u32x4 v;
+                    const u32x2 a = *(const u32x2*)src;
+                    const u32x2 c2 = *(const u32x2*)(src + 8);
+                    v[0] = a[0]; v[1] = a[1]; v[2] = c2[0]; v[3] = c2[1];
+                    *(u32x4*)(dst + (tok0 + q) * p.ld_out + h * HD + (lane & 7) * 8) = v;
+                }
             }
         }
     }
@@ -209,15 +222,16 @@ __global__ __launch_bounds__(256, 2) void vit_attn_fwd_kernel(const AttnFwdArgs 
 
 using namespace libra;
 
-extern "C" int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int64_t B, int64_t T, int64_t H, float scale,
-                                  void* stream) {
+extern "C" int libra_vit_attn_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, void* out_lo, int64_t B,
+                                  int64_t T, int64_t H, float scale, void* stream) {
     if (B <= 0 || T <= 0) return LIBRA_OK;
     if (H <= 0 || ld_qkv < 3 * H * HD || ld_out < H * HD) return LIBRA_ERR_SHAPE;
     if ((ld_qkv % 8) || (ld_out % 8)) return LIBRA_ERR_ALIGN;
     if (!qkv || !out || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return LIBRA_ERR_ALIGN;
     AttnFwdArgs a;
     a.qkv = (const bf16_t*)qkv; a.ld_qkv = ld_qkv;
-    a.out = (bf16_t*)out; a.ld_out = ld_out; a.lse = lse;
+    if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
+    a.out = (bf16_t*)out; a.ld_out = ld_out; a.lse = lse; a.out_lo = (bf16_t*)out_lo;
     a.B = (int)B; a.T = (int)T; a.H = (int)H; a.n_qt = (int)((T + QB - 1) / QB);
     a.sl2 = scale * 1.4426950408889634f;
     const long nblk = (long)B * H * a.n_qt;

@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256, 2) void vit_attn_bwd_dkv_kernel(const AttnBwdA
 }
 
 // delta[b,h,q] = sum_d dO[b*T+q, h*64+d] * O[...]   (8 lanes per (token, head))
-__global__ __launch_bounds__(256) void vit_attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                             long ld, float* __restrict__ delta, int T, int H,
-                                                             long total_chunks) {
+__global__ __launch_bounds__(256) void vit_attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ o_lo,
+                                                             const bf16_t* __restrict__ dout, long ld, float* __restrict__ delta,
+                                                             int T, int H, long total_chunks) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < total_chunks;
     const int cpr = H * 8;                                   // 8-element chunks per token row
@@ -299,6 +299,12 @@ __global__ __launch_bounds__(256) void vit_attn_delta_kernel(const bf16_t* __res
         float a[8], g[8];
         unpack8(*(const u32x4*)(o + row * ld + ch * 8), a);
         unpack8(*(const u32x4*)(dout + row * ld + ch * 8), g);
+        if (o_lo) {                                           // O to ~16 mantissa bits: see libra_vit_attn_fwd
+            float l[8];
+            unpack8(*(const u32x4*)(o_lo + row * ld + ch * 8), l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += l[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += a[e] * g[e];
     }
@@ -317,15 +323,15 @@ __global__ __launch_bounds__(256) void vit_attn_delta_kernel(const bf16_t* __res
 
 using namespace libra;
 
-extern "C" int libra_vit_attn_delta(const void* out, const void* dout, int64_t ld, float* delta, int64_t B, int64_t T,
-                                    int64_t H, void* stream) {
+extern "C" int libra_vit_attn_delta(const void* out, const void* out_lo, const void* dout, int64_t ld, float* delta, int64_t B,
+                                    int64_t T, int64_t H, void* stream) {
     const long rows = B * T;
     if (rows <= 0) return LIBRA_OK;
     if (H <= 0 || ld < H * HD || (ld % 8)) return LIBRA_ERR_SHAPE;
-    if (!out || !dout || !delta || (((uintptr_t)out | (uintptr_t)dout) & 15)) return LIBRA_ERR_ALIGN;
+    if (!out || !dout || !delta || (((uintptr_t)out | (uintptr_t)dout | (uintptr_t)out_lo) & 15)) return LIBRA_ERR_ALIGN;
     const long total = rows * H * 8;
     hipLaunchKernelGGL(vit_attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)out, (const bf16_t*)dout, (long)ld, delta, (int)T, (int)H, total);
+                       (const bf16_t*)out, (const bf16_t*)out_lo, (const bf16_t*)dout, (long)ld, delta, (int)T, (int)H, total);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
 

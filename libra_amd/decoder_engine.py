@@ -257,10 +257,12 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
             else:
                 buf.index_copy_(1, slot, rows.view(B, 1, H))
     if slot is None:
+        o_lo = torch.empty((N, H), dtype=BF16, device=dev) if save else None   # rounding residual of o (the backward's D = dO.O)
         o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
-                                   (H // d.heads) ** -0.5, need_lse=save, kv_start=kv_start)
+                                   (H // d.heads) ** -0.5, need_lse=save, kv_start=kv_start, out_lo=o_lo)
     else:
         ks_c, kc_c, vs_c, vc_c = cache.layers[i]
+        o_lo = None
         o, lse = K.bridge_attn_decode(qkv[:, :H], ks_c, kc_c, vs_c, vc_c, cache.flag, flag, lens, d.heads,
                                       (H // d.heads) ** -0.5, kv_start=kv_start), None
     x_mid = torch.empty_like(x)
@@ -290,7 +292,7 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
         if need_out:
             K.gemm_nt(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)
     if save:
-        sv.update(x=x, rstd1=rstd1, h=h, qkv=qkv, tb=tb, kc=kc, vc=vc, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu,
+        sv.update(x=x, rstd1=rstd1, h=h, qkv=qkv, tb=tb, kc=kc, vc=vc, o=o, o_lo=o_lo, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu,
                   act=act, t=t, to=to, tg=tg, guv=guv, actv=actv, td=td)
     return x_out
 
@@ -736,7 +738,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
             g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx), name=a + "vision_o_proj.weight_A")
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
     dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
-                                               sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5)
+                                               sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5, out_lo=sv["o_lo"])
     dqkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)     # [dq | dk | dv | dt_k dt_v 0..], mirrors the forward's qkvt
     dqkv, dtb = dqkvt[:, :3 * H], dqkvt[:, 3 * H:]
     dtb.zero_()

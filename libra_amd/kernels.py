@@ -254,26 +254,34 @@ def vit_embed_ln(patches, cls, pos, gamma, beta, B: int, T: int, eps: float, *, 
     return emb, hs0, mean, rstd
 
 
+def _chk_lo(out_lo, out, what):
+    if out_lo is not None and (out_lo.shape != out.shape or out_lo.stride() != out.stride() or out_lo.dtype != BF16):
+        raise ValueError(f"{what}: out_lo must have the shape / strides / dtype of out")
+
+
 def vit_attn_fwd(qkv: torch.Tensor, B: int, T: int, H: int, scale: float, *, need_lse: bool = True,
-                 out: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None):
+    """out_lo (same layout as out): receives the rounding residual of the output, for the backward's D term."""
     _chk2d(qkv, "qkv")
     if out is None:
         out = torch.empty((B * T, H * 64), dtype=BF16, device=qkv.device)
+    _chk_lo(out_lo, out, "vit_attn_fwd")
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device) if need_lse else None
-    rc = _lib.lib().libra_vit_attn_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), _ptr(lse), B, T, H,
-                                       float(scale), _stream())
+    rc = _lib.lib().libra_vit_attn_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), _ptr(lse), _ptr(out_lo), B, T,
+                                       H, float(scale), _stream())
     _lib.check(rc, "vit_attn_fwd")
     return out, lse
 
 
 def vit_attn_bwd(qkv, out, dout, lse, B: int, T: int, H: int, scale: float, *,
-                 out_dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out_dqkv: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk2d(qkv, "qkv"); _chk2d(out, "out"); _chk2d(dout, "dout")
     dev = qkv.device
     delta = torch.empty((B, H, T), dtype=torch.float32, device=dev)
     if dout.stride(0) != out.stride(0):
         raise ValueError("vit_attn_bwd: out/dout leading dims differ")
-    rc = _lib.lib().libra_vit_attn_delta(out.data_ptr(), dout.data_ptr(), out.stride(0), delta.data_ptr(), B, T, H,
+    _chk_lo(out_lo, out, "vit_attn_bwd")
+    rc = _lib.lib().libra_vit_attn_delta(out.data_ptr(), _ptr(out_lo), dout.data_ptr(), out.stride(0), delta.data_ptr(), B, T, H,
                                          _stream())
     _lib.check(rc, "vit_attn_delta")
     dqkv = torch.empty_like(qkv) if out_dqkv is None else out_dqkv
@@ -340,6 +348,60 @@ def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     rc = _lib.lib().libra_add_bf16(a.data_ptr(), b.data_ptr(), a.data_ptr(), a.numel(), _stream())
     _lib.check(rc, "add_bf16")
     return a
+
+
+# ---- VQ image decoder rows ------------------------------------------------------------------
+def lfq_codes(indices: torch.Tensor, nbits: int, ldc: int) -> torch.Tensor:
+    """indices int64 [M, Q] -> codes bf16 [M, ldc]: +-1 per bit (MSB first), zero beyond Q * nbits."""
+    if indices.dtype != torch.int64 or indices.dim() != 2 or not indices.is_contiguous() or not indices.is_cuda:
+        raise ValueError("lfq_codes: indices must be a contiguous cuda int64 [M, Q] tensor")
+    M, Q = indices.shape
+    out = torch.empty((M, ldc), dtype=BF16, device=indices.device)
+    rc = _lib.lib().libra_lfq_codes(indices.data_ptr(), out.data_ptr(), M, Q, nbits, ldc, _stream())
+    _lib.check(rc, "lfq_codes")
+    return out
+
+
+def groupnorm_affine(x: torch.Tensor, gamma, beta, B: int, HW: int, G: int, eps: float):
+    """x [B*HW, C] bf16 contiguous -> (scale, shift) fp32 [B, C]: GroupNorm(G) folded into y = x * scale + shift."""
+    _chk2d(x, "x")
+    C = x.shape[1]
+    if x.shape[0] != B * HW or not x.is_contiguous():
+        raise ValueError("groupnorm_affine: x must be contiguous [B*HW, C]")
+    scale = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    shift = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().libra_groupnorm_workspace_bytes(B, HW, C)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().libra_groupnorm_affine(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, HW,
+                                           C, G, float(eps), ws.data_ptr(), nbytes, _stream())
+    _lib.check(rc, "groupnorm_affine")
+    return scale, shift
+
+
+def conv_gather(x: torch.Tensor, B: int, Hs: int, Ws: int, H: int, W: int, ksize: int, ldo: int, *, scale=None, shift=None,
+                swish: bool = False, inv_scale: float = 1.0, pad_rows: int = 0) -> torch.Tensor:
+    """x [B*Hs*Ws, C] (NHWC) -> the GEMM operand [B*H*W (+ zeroed pad rows), ldo] of a ksize x ksize conv on the nearest-upsampled
+    [H, W] image, with the preceding GroupNorm affine / swish applied on the fly."""
+    _chk2d(x, "x")
+    C = x.shape[1]
+    if x.shape[0] != B * Hs * Ws or not x.is_contiguous():
+        raise ValueError("conv_gather: x must be contiguous [B*Hs*Ws, C]")
+    M = B * H * W
+    out = torch.empty((M + pad_rows, ldo), dtype=BF16, device=x.device)
+    if pad_rows:
+        out[M:].zero_()
+    rc = _lib.lib().libra_conv_gather(x.data_ptr(), out.data_ptr(), ldo, _ptr(scale), _ptr(shift), int(swish), B, Hs, Ws, C, H, W,
+                                      ksize, float(inv_scale), float(inv_scale), _stream())
+    _lib.check(rc, "conv_gather")
+    return out[:M] if pad_rows else out
+
+
+def softmax_rows_(x: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
+    """in place: x[r, :cols] = softmax(bf16(x[r, :cols] * scale)), x[r, cols:] = 0."""
+    _chk2d(x, "x")
+    rc = _lib.lib().libra_softmax_rows(x.data_ptr(), x.shape[0], cols, x.stride(0), float(scale), _stream())
+    _lib.check(rc, "softmax_rows")
+    return x
 
 
 def adamw_step(master, m, v, grad, param, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
@@ -477,17 +539,18 @@ def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag
 
 
 def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S: int, H: int, scale: float, *,
-                    need_lse: bool = False, kv_start=None):
+                    need_lse: bool = False, kv_start=None, out_lo: Optional[torch.Tensor] = None):
     """kv_len [B] int32 = end of the valid keys (right padding); kv_start [B] int32 = first valid key (left padding)."""
     for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross")):
         _chk2d(t, n)
     out = torch.empty((B * S, H * 128), dtype=BF16, device=q.device)
+    _chk_lo(out_lo, out, "bridge_attn_fwd")
     lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device) if need_lse else None
     rc = _lib.lib().libra_bridge_attn_fwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_same.stride(0), k_cross.data_ptr(),
                                           k_cross.stride(0), v_same.data_ptr(), v_same.stride(0), v_cross.data_ptr(),
                                           v_cross.stride(0), flag.data_ptr(),
-                                          _ptr(kv_len), _ptr(kv_start), out.data_ptr(), out.stride(0), _ptr(lse), B, S, H,
-                                          float(scale), _stream())
+                                          _ptr(kv_len), _ptr(kv_start), out.data_ptr(), out.stride(0), _ptr(lse), _ptr(out_lo),
+                                          B, S, H, float(scale), _stream())
     _lib.check(rc, "bridge_attn_fwd")
     return out, lse
 
@@ -527,18 +590,20 @@ def ce_rows(logits, target, target_sub: int = 0):
     return loss
 
 
-def bridge_attn_bwd(q, k_same, k_cross, v_same, v_cross, out, dout, flag, kv_len, lse, B: int, S: int, H: int, scale: float):
+def bridge_attn_bwd(q, k_same, k_cross, v_same, v_cross, out, dout, flag, kv_len, lse, B: int, S: int, H: int, scale: float, *,
+                    out_lo: Optional[torch.Tensor] = None):
     """-> dq, dk_same, dk_cross, dv_same, dv_cross  (each [B*S, H*128] bf16)."""
     for t, n in ((q, "q"), (k_same, "k_same"), (k_cross, "k_cross"), (v_same, "v_same"), (v_cross, "v_cross"), (out, "out"),
                  (dout, "dout")):
         _chk2d(t, n)
+    _chk_lo(out_lo, out, "bridge_attn_bwd")
     dev = q.device
     N, HD = B * S, H * 128
     g = [torch.empty((N, HD), dtype=BF16, device=dev) for _ in range(5)]
     delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     rc = _lib.lib().libra_bridge_attn_bwd(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_same.stride(0), k_cross.data_ptr(),
                                           k_cross.stride(0), v_same.data_ptr(), v_same.stride(0), v_cross.data_ptr(),
-                                          v_cross.stride(0), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0),
+                                          v_cross.stride(0), out.data_ptr(), _ptr(out_lo), out.stride(0), dout.data_ptr(), dout.stride(0),
                                           flag.data_ptr(), _ptr(kv_len), lse.data_ptr(), delta.data_ptr(), g[0].data_ptr(),
                                           g[0].stride(0), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(),
                                           HD, B, S, H, float(scale), _stream())

@@ -84,8 +84,26 @@ class ImageTokenizer(torch.nn.Module):
         attention_mask = torch.ones(input_ids[0].shape, dtype=torch.long, device=feat.device)
         return {"input_ids": input_ids, "image_size": [g, g], "attention_mask": attention_mask, "encoder_feat": feat}
 
+    @torch.no_grad()
     def decode(self, x):
-        raise NotImplementedError("image generation (VQ decode) is SURVEY §8f item 2 — not on the training hot path")
+        """token ids [Q, B, N (+2 with BOI / EOI)] (or [B, N] for one codebook) -> image [B, out_ch, H, W]
+        (image_tokenizer.py:97-124): strip the frame tokens, undo the text-vocabulary offset, square the sequence, VQ-decode."""
+        if len(x) == 0 or len(x[0]) == 0:
+            return x
+        if not isinstance(x, torch.Tensor):
+            x = torch.tensor(x, dtype=torch.long, device=self.device)
+        if x.dim() == 2:
+            x = x[None, ...]
+        elif x.dim() != 3:
+            raise NotImplementedError
+        if bool((x == self.boi_token_id).any()):
+            x = x[:, :, 1:-1]                                    # exclude <img> and <\img> tokens
+        Q, B, N = x.shape
+        side = math.isqrt(N)
+        if side * side != N:
+            raise ValueError('Input images are invalid. Currently, the image decoder only support square images.')
+        idx = (x.reshape(Q, B, side, side).permute(1, 2, 3, 0) - self.offset).contiguous()
+        return self.model.decode_code(idx)
 
     @classmethod
     def from_config(cls, config, **kwargs):

@@ -69,6 +69,33 @@ class LFQ(nn.Module):
                             eoi=eoi, want_ids=want_ids, want_xpre=want_xpre, want_quant=want_quant)
 
     @torch.no_grad()
+    def indices_to_codes_flat(self, indices2d: torch.Tensor) -> torch.Tensor:
+        """indices int64 [M, Q] -> codes [M, dim] bf16 (NHWC rows): +-1 per bit, MSB first, then `project_out` when the
+        tokenizer has projections (lookup_free_quantization.py:129-158).  The +-1 matrix is zero-padded to the GEMM K granule."""
+        kp = K.round_up(self.num_codebooks * self.codebook_dim, 64)
+        codes = K.lfq_codes(indices2d.contiguous(), self.codebook_dim, kp)
+        if not self.has_projections:
+            return codes[:, :self.dim]
+        po = self.project_out
+        key = (po.weight.data_ptr(), po.weight._version)
+        if getattr(self, "_po_key", None) != key:
+            w = torch.zeros((self.dim, kp), dtype=torch.bfloat16, device=po.weight.device)
+            w[:, :po.weight.shape[1]] = po.weight.detach()
+            self._po_key, self._po_w = key, w
+        return K.gemm_nt(codes, self._po_w, bias=po.bias.detach().to(torch.bfloat16))
+
+    @torch.no_grad()
+    def indices_to_codes(self, indices, project_out=True):
+        """[B, h, w, Q] -> codes [B, dim, h, w]  ('b ... d -> b d ...', :129-158)."""
+        if not project_out:
+            raise NotImplementedError("indices_to_codes(project_out=False)")
+        if not self.keep_num_codebooks_dim:
+            indices = indices[..., None]
+        B, H, W, Q = indices.shape
+        c = self.indices_to_codes_flat(indices.reshape(B * H * W, Q))
+        return c.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+    @torch.no_grad()
     def forward(self, x, inv_temperature=100., return_loss_breakdown=False, mask=None):
         """x [B, dim, h, w] -> Return(quant [B,dim,h,w], aux_loss (0), indices int64 [B,h,w,Q])  (positional!)."""
         if x.ndim != 4:

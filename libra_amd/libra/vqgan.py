@@ -1,9 +1,9 @@
 """VQModel (encode path) — mirror of /root/reference/libra/models/libra/taming/models/vqgan.py:26-114.
 
 ``encode`` = CLIP tower -> quant_conv (1x1 conv == GEMM with bias) -> LFQ, all on gfx950 kernels.
-The conv decoder / ``decode*`` / training_step parts of the reference class are image *generation*
-and tokenizer *training* code that Libra's train path never reaches: they are not
-implemented, and ``load_state_dict`` reports the skipped ``decoder.`` / ``post_quant_conv.`` keys.
+``decode`` / ``decode_code`` (image generation, SURVEY §8f-2, vqgan.py:122-130) = LFQ codes -> post_quant_conv -> taming
+Decoder on the kernels of ``vq_decoder.py``; built when the ddconfig carries the decoder's fields (``ch``, ``ch_mult`` ...).
+The tokenizer *training* parts of the reference class (losses, training_step) are outside the hot path.
 """
 import torch
 import torch.nn as nn
@@ -11,6 +11,7 @@ import torch.nn as nn
 from .. import kernels as K
 from .clip_encoder import CLIPVisionTower
 from .lookup_free_quantization import LFQ
+from .vq_decoder import Decoder, _Act
 
 
 class VQModel(nn.Module):
@@ -32,6 +33,12 @@ class VQModel(nn.Module):
         n_sel = len(self.encoder._select_list())
         self.quant_conv = nn.Conv2d(self.encoder.vision_tower.config.hidden_size * n_sel, embed_dim, 1)
         self.embed_dim = embed_dim
+        self.has_decoder = all(k in ddconfig for k in ("ch", "out_ch", "num_res_blocks", "attn_resolutions", "resolution", "z_channels"))
+        if self.has_decoder:                                              # vqgan.py:58,:75
+            dd = {k: v for k, v in dict(ddconfig).items() if k not in ("encoder_name", "select_layer", "only_auto_encoder")}
+            dd.setdefault("in_channels", 3)
+            self.decoder = Decoder(**dd)
+            self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
@@ -48,11 +55,11 @@ class VQModel(nn.Module):
         for k in list(sd.keys()):
             if any(k.startswith(ik) for ik in ignore_keys):
                 del sd[k]
-        skipped = [k for k in sd if k.startswith(("decoder.", "post_quant_conv."))]
+        skipped = [] if self.has_decoder else [k for k in sd if k.startswith(("decoder.", "post_quant_conv."))]
         for k in skipped:
             del sd[k]
         self.load_state_dict(sd, strict=True)
-        print(f"Restored from {path} ({len(skipped)} decoder-side keys skipped: generation path not built)")
+        print(f"Restored from {path}" + (f" ({len(skipped)} decoder-side keys skipped: no decoder fields in ddconfig)" if skipped else ""))
 
     def _quant_conv(self, feat2d, w):
         E = self.embed_dim
@@ -90,7 +97,27 @@ class VQModel(nn.Module):
         h2d = self._quant_conv(feat.view(B * hw, Cf), self.quant_conv.weight.view(self.embed_dim, Cf))
         return h2d.view(B, g, g, self.embed_dim).permute(0, 3, 1, 2), None, None
 
-    def decode(self, *a, **k):
-        raise NotImplementedError("VQ decode (image generation) is SURVEY §8f item 2 — not on the training hot path")
+    def _decode_act(self, codes2d, B, H, W):
+        if not self.has_decoder:
+            raise NotImplementedError("this VQModel was built without the decoder's ddconfig fields (ch, ch_mult, ...): encode only")
+        wp, b = self.decoder._w(self.post_quant_conv, "post_quant_conv")
+        op = codes2d if codes2d.shape[1] == wp.shape[1] and codes2d.is_contiguous() else \
+            K.conv_gather(codes2d.contiguous(), B, H, W, H, W, 1, wp.shape[1])
+        zc = self.post_quant_conv.out_channels
+        z = torch.empty((B * H * W, K.round_up(zc, 8)), dtype=torch.bfloat16, device=codes2d.device)
+        K.gemm_nt(op, wp, out=z[:, :zc], bias=b)                                          # vqgan.py:123
+        if zc % 8:
+            raise NotImplementedError("z_channels must be a multiple of 8")
+        return self.decoder(_Act(z, B, H, W))
 
-    decode_code = decode
+    @torch.no_grad()
+    def decode(self, quant):
+        """quant [B, embed_dim, h, w] -> image [B, out_ch, H, W]  (vqgan.py:122-125)."""
+        B, E, H, W = quant.shape
+        return self._decode_act(quant.to(torch.bfloat16).permute(0, 2, 3, 1).reshape(B * H * W, E).contiguous(), B, H, W)
+
+    @torch.no_grad()
+    def decode_code(self, code_b):
+        """code indices int64 [B, h, w, Q] -> image  (vqgan.py:127-130)."""
+        B, H, W, Q = code_b.shape
+        return self._decode_act(self.quantize.indices_to_codes_flat(code_b.reshape(B * H * W, Q)), B, H, W)

@@ -124,7 +124,8 @@ def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: 
         xn1, m1, r1 = K.layernorm_fwd(x, params[pre + "layer_norm1.weight"], params[pre + "layer_norm1.bias"], dims.eps,
                                       save_stats=save, out=rows(D))
         qkv = K.gemm_nt(xn1, pk["wqkv"], bias=pk["bqkv"])
-        o, lse = K.vit_attn_fwd(qkv, B, T, H, scale, need_lse=save, out=rows(D))
+        o_lo = torch.empty((M, D), dtype=BF16, device=x.device) if save else None      # rounding residual of o: the backward's D term
+        o, lse = K.vit_attn_fwd(qkv, B, T, H, scale, need_lse=save, out=rows(D), out_lo=o_lo)
         x_mid = K.gemm_nt(o, params[pre + "self_attn.out_proj.weight"], bias=params[pre + "self_attn.out_proj.bias"],
                           resid=x)
         xn2, m2, r2 = K.layernorm_fwd(x_mid, params[pre + "layer_norm2.weight"], params[pre + "layer_norm2.bias"],
@@ -134,7 +135,7 @@ def forward(params: Dict[str, torch.Tensor], packed, pixel: torch.Tensor, dims: 
                         preact_out=hpre, out=rows(dims.inter))
         x_out = K.gemm_nt(act, params[pre + "mlp.fc2.weight"], bias=params[pre + "mlp.fc2.bias"], resid=x_mid)
         if save:
-            saved["layers"].append(dict(x=x, xn1=xn1, m1=m1, r1=r1, qkv=qkv, o=o, lse=lse, x_mid=x_mid, xn2=xn2,
+            saved["layers"].append(dict(x=x, xn1=xn1, m1=m1, r1=r1, qkv=qkv, o=o, o_lo=o_lo, lse=lse, x_mid=x_mid, xn2=xn2,
                                         m2=m2, r2=r2, hpre=hpre, act=act))
         x = x_out
         hs.append(x)
@@ -227,7 +228,7 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
         param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D, bias_slice=bo)
         do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
-        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dqkv_buf)
+        dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dqkv_buf, out_lo=s["o_lo"])
         param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D)                   # [3D, D]
         dwqkv = grads.pop(pre + "self_attn.qkv_packed")
         o0 = cursor[0] - 3 * D

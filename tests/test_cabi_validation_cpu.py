@@ -33,7 +33,7 @@ def test_gemm_argument_validation(L):
 def test_row_kernels_argument_validation(L):
     assert L.libra_layernorm_fwd(FAKE, FAKE, FAKE, FAKE, None, None, 4, 1001, 1e-5, None) == ERR_SHAPE      # D % 8
     assert L.libra_layernorm_fwd(FAKE, FAKE, FAKE, FAKE, None, None, 0, 1024, 1e-5, None) == OK
-    assert L.libra_vit_attn_fwd(FAKE, 3072, FAKE, 1024, None, 1, 577, 0, 0.125, None) == ERR_SHAPE          # no heads
+    assert L.libra_vit_attn_fwd(FAKE, 3072, FAKE, 1024, None, None, 1, 577, 0, 0.125, None) == ERR_SHAPE          # no heads
     # rope_bridge_bwd: the 512-thread token group covers H <= 32 heads (Libra-7B / 11B); more is refused, not mis-computed
     args = [FAKE] * 5 + [8192, FAKE, FAKE, 4096, FAKE, 3 * 8192, FAKE, 8192] + [None] * 6 + [0, 10, 10]
     assert L.libra_rope_bridge_bwd(*args, 64, None) == ERR_SHAPE

@@ -134,6 +134,34 @@ def test_bridge_attention_bwd(K, B, S, H, mode):
         assert torch.isfinite(g.float()).all(), n
 
 
+def test_bridge_attention_output_residual(K):
+    """Same contract for the bridge kernels: identical bf16 output, O + out_lo ~ fp32 O, dq no worse (usually several times better)."""
+    from helpers import rel_err
+    B, S, H = 2, 512, 2
+    N, D = B * S, H * 128
+    q, ks, kc, vs, vc = [rnd(N, D, seed=60 + i) for i in range(5)]
+    do = rnd(N, D, seed=70)
+    flag = _flags(N, 8, "span")
+    lens = torch.full((B,), S, dtype=torch.int32)
+    sc = 128 ** -0.5
+    o_lo = torch.empty(N, D, dtype=BF, device="cuda")
+    o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag.cuda(), lens.cuda(), B, S, H, sc, need_lse=True, out_lo=o_lo)
+    o2, _ = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag.cuda(), lens.cuda(), B, S, H, sc, need_lse=True)
+    assert torch.equal(o, o2)
+    ins = [t.float().cpu().requires_grad_(True) for t in (q, ks, kc, vs, vc)]
+    ro, _ = _attn_ref(*ins, flag, lens.long(), B, S, H, sc)
+    e_hi = float((o.float().cpu() - ro.detach()).abs().max())
+    e_both = float(((o.float() + o_lo.float()).cpu() - ro.detach()).abs().max())
+    (ro * do.float().cpu()).sum().backward()
+    gp = K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag.cuda(), lens.cuda(), lse, B, S, H, sc)
+    gl = K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag.cuda(), lens.cuda(), lse, B, S, H, sc, out_lo=o_lo)
+    ep, el = rel_err(gp[0].float().cpu(), ins[0].grad), rel_err(gl[0].float().cpu(), ins[0].grad)
+    print(f"bridge O error {e_hi:.2e} -> {e_both:.2e}; dq rel err {ep:.2e} -> {el:.2e}")
+    assert e_both < 0.3 * e_hi and el <= ep * 1.05 + 1e-4
+    for g, r, n in zip(gl, ins, ("dq", "dk_same", "dk_cross", "dv_same", "dv_cross")):
+        close(g, r.grad, rel=6e-3, what=n)
+
+
 def test_bridge_attention_bwd_deterministic(K):
     """No atomics anywhere: two runs are bit-identical (also a race screen for the LDS-DMA / barrier ordering)."""
     B, S, H = 2, 1100, 2

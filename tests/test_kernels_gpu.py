@@ -239,6 +239,32 @@ def test_attention_bwd(K, B, T, H):
         close(dqkv[:, j * D:(j + 1) * D], ref_in.grad[:, j * D:(j + 1) * D], rel=4e-3, what=f"d{n}")
 
 
+def test_attention_output_residual_sharpens_the_backward(K):
+    """out_lo = bf16(O - bf16(O)): O + out_lo reproduces the fp32 output to ~2^-15, and the backward's D = rowsum(dO O) taken from
+    it brings dq / dk (difference-sensitive: dS = P (dP - D)) several times closer to the fp32 reference than the bf16 O alone."""
+    B, T, H = 1, 577, 4
+    D = H * 64
+    qkv = rnd(B * T, 3 * D, seed=5)
+    do = rnd(B * T, D, seed=6)
+    o_lo = torch.empty(B * T, D, dtype=BF, device="cuda")
+    o, lse = K.vit_attn_fwd(qkv, B, T, H, 0.125, out_lo=o_lo)
+    o_plain, _ = K.vit_attn_fwd(qkv, B, T, H, 0.125)
+    assert torch.equal(o, o_plain)
+    ref_in = qkv.float().requires_grad_(True)
+    ro, _ = _attn_ref(ref_in, B, T, H, 0.125)
+    e_hi = float((o.float().cpu() - ro.detach().cpu()).abs().max())
+    e_both = float(((o.float() + o_lo.float()).cpu() - ro.detach().cpu()).abs().max())
+    ro.backward(do.float())
+    g_plain = K.vit_attn_bwd(qkv, o, do, lse, B, T, H, 0.125)
+    g_lo = K.vit_attn_bwd(qkv, o, do, lse, B, T, H, 0.125, out_lo=o_lo)
+    from helpers import rel_err
+    ref = ref_in.grad.cpu()
+    ep, el = rel_err(g_plain[:, :D].float().cpu(), ref[:, :D]), rel_err(g_lo[:, :D].float().cpu(), ref[:, :D])
+    print(f"O error {e_hi:.2e} -> {e_both:.2e} with the residual; dq rel err {ep:.2e} -> {el:.2e}")
+    assert e_both < 0.3 * e_hi and el <= ep * 1.05 + 1e-4
+    close(g_lo[:, 2 * D:], ref_in.grad[:, 2 * D:], rel=4e-3, what="dv")
+
+
 def test_feature_select(K):
     B, T, D = 2, 17, 128
     a, b = rnd(B * T, D, seed=1), rnd(B * T, D, seed=2)
