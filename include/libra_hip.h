@@ -278,6 +278,24 @@ int libra_conv_gather(const void* x, void* out, int64_t ldo, const float* scale,
 /* x[r, :cols] <- softmax(bf16(x[r, :cols] * scale)), x[r, cols:ld] <- 0  (AttnBlock, model.py:170-196: bmm * c^-0.5, softmax) */
 int libra_softmax_rows(void* x, int64_t rows, int64_t cols, int64_t ld, float scale, void* stream);
 
+/* ---- image input pipeline (decoded uint8 image -> CLIP pixel_values / patch-embed operand) ---------------------------------
+ * The reference's CPU chain: [expand2square] -> PIL BICUBIC resize of the shortest edge -> center crop -> /255 -> normalise -> CHW
+ * (libra/models/clip/image_processing_clip.py:219-337; libra/data/datasets/caption_datasets.py:45-56), then `.to(bfloat16)`.
+ * The resize is Pillow's two-pass 8-bit resampler; bounds [out][2] (first tap, tap count) and coeffs [out][ksize] (fixed point,
+ * 22 fractional bits) are Pillow's `precompute_coeffs` + `normalize_coeffs_8bpc`, computed by the host. */
+/* horizontal pass: canvas rows [row0, row0 + rows) -> out uint8 [rows, out_w, 3].  The canvas is the image [in_h, in_w, 3] at
+ * offset (pad_y, pad_x) on a background of colour (bg_r, bg_g, bg_b) (expand2square); pad 0 = the image itself. */
+int libra_resample_h_u8(const uint8_t* in, int64_t in_h, int64_t in_w, int64_t pad_y, int64_t pad_x, int bg_r, int bg_g, int bg_b,
+                        const int32_t* bounds, const int32_t* coeffs, int64_t ksize, uint8_t* out, int64_t rows, int64_t out_w,
+                        int64_t row0, void* stream);
+/* vertical pass + center crop (window top/left/crop of the resized image) + normalisation through lut bf16 [3][256] (level ->
+ * bf16((level/255 - mean) / std) with the reference's float32 rounding points) + layout: patch == 0 -> out bf16 [3, crop, crop];
+ * patch > 0 -> the patch-embedding GEMM's im2col rows [(crop/patch)^2, kpad], column c*patch^2 + py*patch + px (pad columns
+ * untouched: zero them once). */
+int libra_resample_v_u8_norm(const uint8_t* tmp, int64_t tmp_w, int64_t row0, const int32_t* bounds, const int32_t* coeffs,
+                             int64_t ksize, int64_t top, int64_t left, int64_t crop, const void* lut, void* out, int64_t patch,
+                             int64_t kpad, void* stream);
+
 /* ---- optimizer -----------------------------------------------------------------------------------*/
 /* Fused AdamW on a flat range of n elements (the data-parallel optimizer step of the reference's recipes: AdamW via HF
  * Trainer / DeepSpeed fused Adam with bf16 + fp32 master weights, libra/configs/libra_pretrain.yaml:83-91,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "libra_groupnorm_affine": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, C.c_size_t, _P],
     "libra_conv_gather": [_P, _P, _I64, _P, _P, _I, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _F, _P],
     "libra_softmax_rows": [_P, _I64, _I64, _I64, _F, _P],
+    "libra_resample_h_u8": [_P, _I64, _I64, _I64, _I64, _I, _I, _I, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "libra_resample_v_u8_norm": [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _I64, _P],
     "libra_adamw_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P],
 }
 
