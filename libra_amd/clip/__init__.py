@@ -4,3 +4,4 @@ from transformers import CLIPImageProcessor  # CPU preprocessing is out of scope
 from .modeling_clip import CLIPVisionConfig, CLIPVisionModel
 
 __all__ = ["CLIPVisionModel", "CLIPImageProcessor", "CLIPVisionConfig"]
+from .image_pipeline import CLIPImagePipeline  # noqa: E402,F401

@@ -404,6 +404,28 @@ def softmax_rows_(x: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
     return x
 
 
+# ---- image input pipeline -----------------------------------------------------------------------
+def resample_h_u8(img: torch.Tensor, pad_y: int, pad_x: int, bg, bounds: torch.Tensor, coeffs: torch.Tensor, rows: int, row0: int):
+    """img uint8 [H, W, 3] cuda -> uint8 [rows, out_w, 3]: Pillow's horizontal 8-bit pass over canvas rows [row0, row0 + rows)."""
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous() or not img.is_cuda:
+        raise ValueError("resample_h_u8: a contiguous cuda uint8 [H, W, 3] image is expected")
+    out_w, ksize = coeffs.shape
+    out = torch.empty((rows, out_w, 3), dtype=torch.uint8, device=img.device)
+    rc = _lib.lib().libra_resample_h_u8(img.data_ptr(), img.shape[0], img.shape[1], pad_y, pad_x, int(bg[0]), int(bg[1]), int(bg[2]),
+                                        bounds.data_ptr(), coeffs.data_ptr(), ksize, out.data_ptr(), rows, out_w, row0, _stream())
+    _lib.check(rc, "resample_h_u8")
+    return out
+
+
+def resample_v_u8_norm(tmp: torch.Tensor, row0: int, bounds: torch.Tensor, coeffs: torch.Tensor, top: int, left: int, crop: int,
+                       lut: torch.Tensor, out: torch.Tensor, patch: int = 0, kpad: int = 0):
+    """Pillow's vertical pass + center crop + normalisation LUT + layout (NCHW [3,crop,crop] or im2col rows), into `out`."""
+    rc = _lib.lib().libra_resample_v_u8_norm(tmp.data_ptr(), tmp.shape[1], row0, bounds.data_ptr(), coeffs.data_ptr(), coeffs.shape[1],
+                                             top, left, crop, lut.data_ptr(), out.data_ptr(), patch, kpad, _stream())
+    _lib.check(rc, "resample_v_u8_norm")
+    return out
+
+
 def adamw_step(master, m, v, grad, param, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
                bias_corr1: float, bias_corr2: float, grad_scale: float = 1.0):
     """One fused AdamW update of a flat range: master / m / v fp32 [n], grad / param bf16 [n] (param = bf16(master))."""

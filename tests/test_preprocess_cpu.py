@@ -38,3 +38,14 @@ def test_pipeline_matches_reference_processor_fixture():
         assert sub.shape == want.shape
         assert np.array_equal(sub, want), (i, case, float(np.abs(sub - want).max()))
         assert abs(float(got.astype(np.float64).sum()) - case["sum"]) < 1e-6 * max(1.0, abs(case["sum"]))
+
+
+def test_product_tap_tables_equal_the_oracle():
+    """Host logic of the product pipeline (libra_amd/clip/image_pipeline.py): Pillow's tap tables and the output sizing."""
+    from libra_amd.clip.image_pipeline import _out_size, _taps
+    for a, b in [(53, 31), (80, 420), (375, 336), (400, 336), (64, 64), (700, 336), (77, 40), (1000, 336), (336, 1000)]:
+        b1, c1 = _taps(a, b)
+        b2, c2 = PO.resample_coeffs(a, b)
+        assert np.array_equal(b1, b2) and np.array_equal(c1, c2), (a, b)
+    for h, w in [(480, 640), (640, 480), (333, 1000), (336, 336), (90, 700)]:
+        assert _out_size(h, w, 336) == PO.shortest_edge_size(h, w, 336)
