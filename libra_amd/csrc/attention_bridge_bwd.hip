@@ -102,6 +102,7 @@ constexpr int DQ_STAGE_B = 2 * DQ_VAR;        // same + cross
 constexpr int DQ_LDS_B = 2 * DQ_STAGE_B + 1024;
 constexpr int DQ_BQ = 256;
 
+template <bool CA>        // CA: lane-constant LDS addressing, see bridge_attn_bwd_dkv_kernel
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* kmask = (unsigned*)(smem + 2 * DQ_STAGE_B);
@@ -188,6 +189,14 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
     };
     stage(0, 0);
     int lane_o = lane;                                              // (see the forward kernel: per-tile recomputed LDS offsets)
+    int xr = 0, xt0 = 0, xt1 = 0;
+    if constexpr (CA) {
+        const int pp = lane & 15, g16 = (lane >> 4) & 1;
+        const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
+        xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
+        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
+        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
+    }
 
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -198,7 +207,20 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
         const int kv0 = kt * 64;
         if (kv0 > q0w + 31) continue;
         asm volatile("" : "+v"(lane_o));
+        if constexpr (CA) asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1));
         const int l31o = lane_o & 31, fko = lane_o >> 5;
+        auto rd_row = [&](const char* tile, int ks) -> bf16x8 {
+            if constexpr (CA) return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
+            else return nread_t(tile, l31o, 2 * ks + fko);
+        };
+        auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
+            if constexpr (CA) {
+                union { bf16x8 v; s16x4 h2[2]; } u;
+                u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
+                u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
+                return u.v;
+            } else return tread_t(tile, lane_o, dt, sx);
+        };
 #pragma unroll 1
         for (int kh = 0; kh < 2; ++kh) {
             const int k0 = kv0 + kh * 32;
@@ -214,18 +236,18 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(img1, l31o, 2 * ks + fko), qf[ks], s, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(img1, ks), qf[ks], s, 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(img1 + 16384, l31o, 2 * ks + fko), dof[ks], dp, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(img1 + 16384, ks), dof[ks], dp, 0, 0, 0);
             unsigned crossbits = 0;
             if (mixed) {                                            // both variants present: per-element select
                 f32x16 t, u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { t[r] = 0.f; u[r] = 0.f; }
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(skc, l31o, 2 * ks + fko), qf[ks], t, 0, 0, 0);
+                for (int ks = 0; ks < 8; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(skc, ks), qf[ks], t, 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(skc + 16384, l31o, 2 * ks + fko), dof[ks], u, 0, 0, 0);
+                for (int ks = 0; ks < 8; ++ks) u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(skc + 16384, ks), dof[ks], u, 0, 0, 0);
                 const unsigned km = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + kh]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -264,10 +286,10 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
                     }
                 }
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(img1, lane_o, dt, sx), pk.v, dq[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(img1, dt, sx), pk.v, dq[dt], 0, 0, 0);
                 if (mixed) {
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(skc, lane_o, dt, sx), pk2.v, dq[dt], 0, 0, 0);
+                    for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(skc, dt, sx), pk2.v, dq[dt], 0, 0, 0);
                 }
             }
         }
@@ -332,6 +354,9 @@ __device__ __forceinline__ bf16x8 nfrag(const char* tile, int row, int ks, int f
     return *(const bf16x8*)(tile + sub * sub_bytes + row * 128 + (c << 4));
 }
 
+// CA = lane-constant LDS addressing: every fragment address is a per-lane constant XOR a compile-time constant (one VALU op per
+// read) instead of the swizzle arithmetic rebuilt per read (the round-1 PMC profile counted 12.4 VALU per MFMA in this kernel)
+template <bool CA>
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* res = smem;                                            // Ks, Kc, Vs, Vc
@@ -397,6 +422,16 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
 
     const char* rK = res + kw * 32 * 128;                         // this wave's 32 key rows inside each 64-row sub-tile
     int lane_o = lane;
+    // lane constants of the CA variant (see bridge_attn_bwd_dkv2_kernel for the derivation)
+    int xr = 0, xv = 0, xt0 = 0, xt1 = 0;
+    if constexpr (CA) {
+        const int pp = lane & 15, g16 = (lane >> 4) & 1;
+        const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
+        xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
+        xv = l31 * 128 + ((fk ^ ((l31 >> 1) & 7)) << 4);
+        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
+        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
+    }
     for (int it = it0; it < nqt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -405,7 +440,24 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         const int q0 = it * 64 + qh * 32;
         if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
         asm volatile("" : "+v"(lane_o));
+        if constexpr (CA) asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
         const int l31o = lane_o & 31, fko = lane_o >> 5;
+        auto rd_row = [&](const char* tile, int ks) -> bf16x8 {
+            if constexpr (CA) return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
+            else return nread_t(tile, l31o, 2 * ks + fko);
+        };
+        auto rd_res = [&](const char* tile, int ks) -> bf16x8 {
+            if constexpr (CA) return *(const bf16x8*)(tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5)));
+            else return nfrag(tile, l31o, ks, fko, 8192);
+        };
+        auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
+            if constexpr (CA) {
+                union { bf16x8 v; s16x4 h2[2]; } u;
+                u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
+                u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
+                return u.v;
+            } else return tread_t(tile, lane_o, dt, sx);
+        };
         const char* sq = qd + cur * QD_STAGE + qh * 8192;         // this wave's 32 query rows of the Q image (dO at +16384)
         const float* sL = (const float*)(qd + cur * QD_STAGE + 32768) + qh * 32;
         const float* sD = sL + 64;
@@ -424,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sq, l31o, 2 * ks + fko), nfrag(rk, l31o, ks, fko, 8192), s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq, ks), rd_res(rk, ks), s, 0, 0, 0);
         };
         auto score_dp = [&](const char* rk, f32x16& dp) {
 #pragma unroll
@@ -432,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
             if (role_dk) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks)
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nread_t(sq + 16384, l31o, 2 * ks + fko), nfrag(rk + 32768, l31o, ks, fko, 8192), dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq + 16384, ks), rd_res(rk + 32768, ks), dp, 0, 0, 0);
             }
         };
         // s <- P = exp2(S*sl2 - L) (dV waves) or dS = P (dP - D) (dK waves)
@@ -484,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pk.u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tread_t(st, lane_o, dt, sx), pk.v, acc[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(st, dt, sx), pk.v, acc[dt], 0, 0, 0);
             }
         };
         if (wsame) pass(rK, false, acc_s);
@@ -575,9 +627,6 @@ constexpr int DKV2_KRES = DKV2_VRES + 16384;   // resident K, d 0..63 only: [64 
 constexpr int DKV2_MASK = DKV2_KRES + 8192;
 constexpr int DKV2_LDS_B = DKV2_MASK + 1024;
 
-// DBG (timing experiments only, results are wrong): 1 = no partial-sum exchange / store, 2 = no prefetch of the next tile,
-// 4 = no per-pair compute
-template <int DBG>
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* vres = smem + DKV2_VRES;
@@ -740,14 +789,13 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int nx = next_needed(it + 1, v);
-            if (!(DBG & 2) && nx < nqt) stage_q(buf ^ 1, nx);
+            if (nx < nqt) stage_q(buf ^ 1, nx);
             const int q0 = it * QT2 + qs * 32;
             const char* stg = smem + buf * ST2;
             // the four lane constants are re-materialised per tile: hoisted out of the loop, their XOR-ed variants (24
             // registers) would be kept alive across it and spill
             asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
             it = nx; buf ^= 1;
-            if (DBG & 4) continue;
             // every branch below is wave-uniform and must LOOK uniform to the compiler (MFMA ignores EXEC: under a branch it
             // believes divergent it copies every accumulator it touches) - conditions go through readfirstlane
             if (__builtin_amdgcn_readfirstlane((int)(kbase_w >= S || q0 >= S || q0 + 31 < kbase_w))) continue;   // no (query >= key) pair
@@ -848,7 +896,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
                     }
             }
         };
-        if (!(DBG & 1)) {
         if (qs > 0) give(dV);
         __syncthreads();
         if (qs == 0) take(dV);
@@ -857,8 +904,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv2_kernel(const Brid
         __syncthreads();
         if (qs == 0) take(dK);
         __syncthreads();
-        }
-        if (!(DBG & 1) && qs == 0 && kbase_w < S) {
+        if (qs == 0 && kbase_w < S) {
             // each wave's [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
             char* so = smem + wave * (32 * OROW);
             auto store = [&](const f32x16* acc, float mul, bf16_t* dst) {
@@ -963,32 +1009,32 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.scale = scale; a.sl2 = scale * LOG2E;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
     long nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
+    // LIBRA_ATTN_DKV selects the backward structure (A/B measurements inside one box visit): 1 = round-1 kernels, 3 = the same with
+    // lane-constant LDS addressing (dq and dkv), 2 = the one-variant-per-pass dK/dV kernel; read once, never written again
+    static const int dkv_structure = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 1; }();
+    if (dkv_structure == 3)
+        hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel<true>, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel<false>, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    // LIBRA_ATTN_DKV=1 selects the round-1 structure (A/B measurements inside one box visit); read once, never written again
-    static const int dkv_structure = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 1; }();
     if (dkv_structure == 1)
-        hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
-    else {
-        static const int dbg = [] { const char* e = getenv("LIBRA_DKV2_DBG"); return e ? atoi(e) : 0; }();
-        auto kern = dbg == 1 ? bridge_attn_bwd_dkv2_kernel<1> : dbg == 2 ? bridge_attn_bwd_dkv2_kernel<2>
-                  : dbg == 4 ? bridge_attn_bwd_dkv2_kernel<4> : dbg == 6 ? bridge_attn_bwd_dkv2_kernel<6> : bridge_attn_bwd_dkv2_kernel<0>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), DKV2_LDS_B, (hipStream_t)stream, a);
-    }
+        hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<false>, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    else if (dkv_structure == 3)
+        hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<true>, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(bridge_attn_bwd_dkv2_kernel, dim3((unsigned)nblk), dim3(512), DKV2_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -111,17 +111,19 @@ class PackedOperands:
 
     def refresh(self, sd: Dict[str, torch.Tensor], force: bool = False) -> int:
         """Re-copy stale slices; returns the number of slices copied."""
-        n = 0
+        dsts, srcs = [], []
         with torch.no_grad():
             for k, (dst, name, tr) in enumerate(self._slices):
                 p = sd[name]
                 key = (p.data_ptr(), p._version)
                 if force or p.requires_grad or self._keys.get(k) != key:
                     src = p.detach()
-                    dst.copy_(src.t() if tr else src)
+                    dsts.append(dst)
+                    srcs.append(src.t() if tr else src)
                     self._keys[k] = key
-                    n += 1
-        return n
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)          # a handful of multi-tensor launches instead of ~500 small copies / step
+        return len(dsts)
 
     def __getitem__(self, i: int) -> dict:
         return self.layers[i]
