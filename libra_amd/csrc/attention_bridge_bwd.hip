@@ -1021,7 +1021,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     // LIBRA_ATTN_DKV selects the backward structure (A/B measurements inside one box visit): 1 = round-1 kernels, 3 = the same with
     // lane-constant LDS addressing (dq and dkv), 2 = the one-variant-per-pass dK/dV kernel; read once, never written again
-    static const int dkv_structure = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 1; }();
+    static const int dkv_structure = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 3; }();
     if (dkv_structure == 3)
         hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel<true>, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
     else
