@@ -99,7 +99,7 @@ def make_vit(device, batch, world, mode):
     return w
 
 
-def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recompute=False, accum=1):
+def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recompute=False, accum=1, full_finetune=False):
     """configs[2]/[3]: the reference's real pretraining step (see module docstring)."""
     from libra_amd import decoder_engine as DE
     from libra_amd import dp
@@ -115,7 +115,7 @@ def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recomp
         for n, p in dec.named_parameters():
             if "bridge" in n and n.endswith("weight_B"):
                 p.normal_(0, 0.02)             # zero-initialised upstream; make the bridge path numerically live
-    apply_freeze_policy(dec, frozen_language=True)
+    apply_freeze_policy(dec, frozen_language=not full_finetune)       # configs[4]: the instruction recipe trains all 11 B
     dec.train()
     if recompute:
         dec.gradient_checkpointing_enable()
@@ -337,7 +337,7 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img):
             "whole_step_frac": round(ips_per_gpu * gflop_step_img / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
 
-def gflop_per_image(workload, seq=2048):
+def gflop_per_image(workload, seq=2048, full_finetune=False):
     if workload == "vit":
         return GFLOP_FWD_PER_IMG + 2 * (GFLOP_FWD_PER_IMG - GFLOP_LAYER)   # bwd skips the unused last layer
     # ViT fwd + decoder fwd (25.44 T at S=2048) + decoder bwd: dgrad everywhere, wgrad for the vision weights only (frozen
@@ -350,7 +350,8 @@ def gflop_per_image(workload, seq=2048):
     attn = 2 * seq * seq * H
     heads = 2 * Nl * H * V + 4 * Nv * H * 514
     fwd = 32 * (text + vis + bridge + attn) + heads
-    bwd = 32 * (text + 2 * vis + 2 * bridge + 2.5 * attn) + 2 * Nl * H * V + 2 * 4 * Nv * H * 514
+    tw = 2 if full_finetune else 1                       # frozen text weights need no weight gradient
+    bwd = 32 * (tw * text + 2 * vis + 2 * bridge + 2.5 * attn) + tw * 2 * Nl * H * V + 2 * 4 * Nv * H * 514
     return GFLOP_FWD_PER_IMG + (fwd + bwd) / 1e9
 
 
@@ -367,6 +368,8 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true", help="include the fused AdamW update in the step (configs[3])")
     ap.add_argument("--recompute", action="store_true", help="gradient checkpointing per decoder layer (the recipes' setting)")
     ap.add_argument("--accum", type=int, default=1, help="gradient-accumulation micro-steps per step")
+    ap.add_argument("--full-finetune", action="store_true",
+                    help="configs[4]: every parameter trainable (instruction recipe) instead of the frozen-language pretraining policy")
     ap.add_argument("--exchange", choices=["auto", "allreduce", "rs_ag", "zero1"], default="auto",
                     help="N>1 gradient exchange; auto = probe allreduce and rs_ag during warm-up and keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -409,7 +412,7 @@ def main():
         if args.workload == "vit":
             return make_vit(device, args.batch, world, mode_)
         return make_bridge(device, args.batch, args.seq, world, mode_, with_optimizer=args.with_optimizer,
-                           recompute=args.recompute, accum=args.accum)
+                           recompute=args.recompute, accum=args.accum, full_finetune=args.full_finetune)
     w = make(mode)
     note(f"built {args.workload}; world={world} batch={args.batch} exchange={mode if world > 1 else None}")
 
@@ -443,10 +446,10 @@ def main():
                                                   * len(w.buckets.buckets)),
                      grad_bucket_bytes=w.buckets.total_bytes, buckets=len(w.buckets.buckets))
 
-    gpi = gflop_per_image(args.workload, args.seq)
+    gpi = gflop_per_image(args.workload, args.seq, args.full_finetune)
     roof = roofline(w, args.workload, ips / world, gpi)
     names = {"bridge": f"configs[2]: ViT-L/14@336 + VQ encode (no grad) -> tensor assembly -> Libra-11B routed-bridge decoder "
-                       f"fwd+bwd, LLaMA-2-7B text stream frozen (4.27 B trainable), bs={args.batch}/GPU, seq {args.seq}, one "
+                       f"fwd+bwd, {'all 11.0 B parameters trainable' if args.full_finetune else 'LLaMA-2-7B text stream frozen (4.27 B trainable)'}, bs={args.batch}/GPU, seq {args.seq}, one "
                        "336px image per sequence, random-init",
              "vit": f"configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs={args.batch}/GPU (LLM frozen)"}
     out = {"metric": METRIC, "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -456,10 +459,12 @@ def main():
                       "seq_len": args.seq if args.workload == "bridge" else 577, "parallelism": f"dp{world}",
                       "algorithmic_gflop_per_image": round(gpi, 1), "value_per_gpu": round(ips / world, 3),
                       "optimizer_in_step": bool(args.with_optimizer), "recompute": bool(args.recompute),
+                      "full_finetune": bool(args.full_finetune),
                       "grad_accum": args.accum},
            "roofline": roof}
 
-    if world == 1 and rank == 0 and not args.no_extra and args.workload == "bridge" and not args.with_optimizer:
+    if world == 1 and rank == 0 and not args.no_extra and args.workload == "bridge" and not args.with_optimizer \
+            and not args.full_finetune:
         # ---- optimizer leg: the same step + fused AdamW on the 4.27 B trainable parameters (configs[3] names AdamW)
         try:
             del w

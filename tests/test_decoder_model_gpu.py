@@ -283,3 +283,54 @@ def test_libra_tiny_cached_decode_vs_reference_fixture():
         assert e_self < max(1.5 * theirs, 6e-3), report
         assert e_oracle < max(2.0 * theirs, 6e-3), report            # the forward test's criterion
         assert e_fix < max(3.0 * theirs, 3e-2), report               # vs the reference's fp32-weight run: + weight rounding
+
+
+def test_libra_model_path_at_seq_4096_vs_oracle():
+    """BASELINE configs[4] sequence length (4096 > the reference's 2048-entry RoPE cache, which it extends on demand): the whole
+    model path - embeddings, 2 routed layers, heads, CE, backward - at S = 4096 with libra_tiny's width and weights, against
+    autograd through the fp32 oracle (loss, final hidden state, gradients of every parameter family)."""
+    from libra_amd.libra import LibraConfig, LibraForCausalLM
+    from oracle import libra_oracle as LO
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = dict(meta["cfg"], max_position_embeddings=4096)
+    m = LibraForCausalLM(LibraConfig(**c))
+    m.load_state_dict(sub(t, "w."), strict=True)
+    m = m.to(BF).cuda()
+    m.requires_grad_(True)
+    V, L, S = c["vocab_size"], c["max_vision_token_length"], 4096
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, V, (1, 1, S), generator=g).repeat(2, 1, 1)
+    ids[:, 0, 0] = 1
+    vi = torch.full((1, S), L, dtype=torch.long)
+    for start in (5, 2000):                                          # two images inside the sequence
+        ids[0, 0, start:start + L] = torch.cat([torch.tensor([meta["boi"]]), V + torch.randint(0, 16, (L - 2,), generator=g), torch.tensor([meta["eoi"]])])
+        ids[1, 0, start:start + L] = torch.cat([torch.tensor([meta["boi"]]), V + torch.randint(0, 16, (L - 2,), generator=g), torch.tensor([meta["eoi"]])])
+        vi[0, start:start + L] = torch.arange(L)
+    am = torch.ones(1, S, dtype=torch.long); am[0, 3900:] = 0
+    sig = torch.zeros(1, S, c["contiguous_signal_size"])
+    sig[0, 6:6 + L - 2] = torch.randn(L - 2, c["contiguous_signal_size"], generator=g)
+    labels = LO.get_labels(ids, am, [[(5 + L, 6 + L), (2000 + L, 2001 + L)]], boi_token_id=meta["boi"], bos_token_id=1)
+    out = m(input_ids=ids.cuda(), attention_mask=am.cuda(), vision_indices=vi.cuda(), contiguous_signal=sig.to(BF).cuda(),
+            labels=labels.cuda(), output_hidden_states=True)
+    out.loss.backward()
+    sdf = {k: v.to(BF).float().requires_grad_(True) for k, v in sub(t, "w.").items()}
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=V, max_vision_token_length=L, eps=c["rms_norm_eps"],
+              max_pos=4096)
+    hid, flag = LO.model_forward(sdf, ids, am, vi, sig.to(BF).float(), **kw)
+    ref_loss = LO.causal_lm_loss(LO.vl_logits(sdf, hid, flag, 2), labels)
+    ref_loss.backward()
+    valid = am.bool()
+    e_h = rel_err(out.hidden_states[-1].float().cpu()[valid], hid.detach()[valid])
+    assert e_h < 2e-2, e_h
+    assert abs(float(out.loss) - float(ref_loss)) < 2e-2 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        if name == "vision_hidden_placeholder":
+            continue
+        ref = sdf[name].grad
+        e = rel_err(p.grad.float().cpu(), ref)
+        worst = max(worst, (name, e), key=lambda x: x[1])
+        assert e < 6e-2, (name, e)
+    from helpers import parity_report
+    parity_report(f"[configs[4] sequence length, tiny width] S=4096 model path: hidden {e_h:.3e}, loss {float(out.loss):.4f} vs {float(ref_loss):.4f}, "
+                  f"worst parameter gradient {worst[1]:.3e} at {worst[0]}")
