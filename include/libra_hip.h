@@ -170,12 +170,14 @@ int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t ldt, const 
                       const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                       int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S, int64_t H,
                       void* stream);
-/* The same with an explicit RoPE position per token (positions [N] int32, each < max_pos) instead of n % S: the cached
- * decode step, where the N = B new tokens sit at position_ids[b] (prepare_inputs_for_generation, modeling_libra.py:1196-1209). */
+/* The same with explicit RoPE positions (int32 [N, pos_stride], clamped into [0, max_pos)) instead of n % S: the cached decode
+ * step and left-padded prompts (position_ids = attention_mask.cumsum - 1, prepare_inputs_for_generation, modeling_libra.py:
+ * 1196-1209), and - pos_stride = 2 - `use_2d_rope` (:43-49, :663-678): even heads rotate by column 0 (the row position), odd heads
+ * by column 1 (the column position). */
 int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
                           const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                           int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, const int* positions,
-                          int64_t H, void* stream);
+                          int64_t pos_stride, int64_t H, void* stream);
 /* Routed-bridge attention of ONE new query token per sequence against the KV cache (LibraAttention.forward with
  * past_key_value, modeling_libra.py:344-391, at q_len = 1).  The reference's cache ([K_for_vision, K_for_language], V,
  * V_bridge, flag) is held as the four row buffers the training path produces - K_same, K_cross, V_same, V_cross
@@ -249,7 +251,7 @@ int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const void* dk_cr
                           const void* dv_cross, int64_t ld, const void* cos, const void* sin, int64_t max_pos,
                           void* dqkv, int64_t ldo, void* dkb, int64_t ldb, const void* bk_l, const void* bk_v,
                           const void* bv_l, const void* bv_v, const uint8_t* flag, void* dtb, int64_t ldt, int64_t N,
-                          int64_t S, int64_t H, void* stream);
+                          int64_t S, int64_t H, const int* positions, int64_t pos_stride, void* stream);
 
 /* ---- small elementwise helpers -------------------------------------------------------------------*/
 /* out_bf16[i] = bf16(in_f32[i])  (parameter-gradient accumulators -> bf16 .grad) */

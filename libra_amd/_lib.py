@@ -42,7 +42,7 @@ SIGNATURES = {
     "libra_lfq_encode": [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "libra_rmsnorm_routed_fwd": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _F, _P],
     "libra_rope_bridge": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
-    "libra_rope_bridge_pos": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _P],
+    "libra_rope_bridge_pos": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, _P],
     "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
     "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _P],
     "libra_bridge_attn_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
@@ -57,7 +57,7 @@ SIGNATURES = {
     "libra_rmsnorm_routed_wgrad": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
     "libra_swiglu_bwd": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P],
     "libra_rope_bridge_bwd": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64,
-                              _I64, _I64, _I64, _P],
+                              _I64, _I64, _I64, _P, _I64, _P],
     "libra_f32_to_bf16": [_P, _P, _I64, _P],
     "libra_add_bf16": [_P, _P, _P, _I64, _P],
     "libra_lfq_codes": [_P, _P, _I64, _I64, _I64, _I64, _P],

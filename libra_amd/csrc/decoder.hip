@@ -67,7 +67,8 @@ struct RopeArgs {
     const bf16_t* cos; const bf16_t* sin;         // [max_pos, 128] bf16 (the reference casts its fp32 cache to x.dtype)
     bf16_t* k_cross; bf16_t* v_cross; long ldc;   // [N, H*128]
     long N; int S;
-    const int* positions;                         // optional [N]: RoPE position of token n (NULL: n % S)
+    const int* positions;                         // optional [N, pos_stride]: RoPE position of token n (NULL: n % S)
+    int pos_stride;                               // 1, or 2 = use_2d_rope: even heads take column 0 (row position), odd heads column 1
     int max_pos;                                  // rows of cos / sin: explicit positions are clamped into the table
 };
 
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
         const long n = n_first + (long)j * tpb;
         if (n >= p.N) break;
         while (s >= p.S) s -= p.S;
-        const int pos = p.positions ? min(max(p.positions[n], 0), p.max_pos - 1) : s;
+        const int pos = p.positions ? min(max(p.positions[n * p.pos_stride + (p.pos_stride == 2 ? (h & 1) : 0)], 0), p.max_pos - 1) : s;
         const int vis = p.flag[n] != 0;
         if (vis != cur_mod) {
             const bf16_t* bk = vis ? p.bk_v : p.bk_l;
@@ -287,8 +288,9 @@ extern "C" int libra_rmsnorm_routed_fwd(const void* x, int64_t ldx, const void* 
 static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
                            const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                            int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
-                           int64_t H, const int* positions, void* stream) {
+                           int64_t H, const int* positions, int64_t pos_stride, void* stream) {
     if (N <= 0) return LIBRA_OK;
+    if (positions && pos_stride != 1 && pos_stride != 2) return LIBRA_ERR_SHAPE;
     if (H <= 0 || S <= 0 || S > max_pos || ld < 3 * H * 128 || ldt < 16 || ldc < H * 128) return LIBRA_ERR_SHAPE;
     if ((ld % 8) || (ldt % 8) || (ldc % 8)) return LIBRA_ERR_ALIGN;
     if (!qkv || !tb || !bk_l || !bk_v || !bv_l || !bv_v || !flag || !cos || !sin || !k_cross || !v_cross) return LIBRA_ERR_ALIGN;
@@ -299,7 +301,7 @@ static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, c
     a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
     a.flag = flag; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
     a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
-    a.positions = positions; a.max_pos = (int)max_pos;
+    a.positions = positions; a.pos_stride = (int)pos_stride; a.max_pos = (int)max_pos;
     const long LT = H * 16, tpb = LT >= 256 ? 1 : 256 / LT;
     const long gx = (N + ROPE_TOK * tpb - 1) / (ROPE_TOK * tpb), gy = LT >= 256 ? (LT + 255) / 256 : 1;
     if (gx > 0x7fffffffL || gy > 65535) return LIBRA_ERR_SHAPE;
@@ -312,16 +314,16 @@ extern "C" int libra_rope_bridge(void* qkv, int64_t ld, const void* tb, int64_t 
                                  int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
                                  int64_t H, void* stream) {
     return rope_bridge_run(qkv, ld, tb, ldt, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, max_pos, k_cross, v_cross, ldc, N, S, H,
-                           nullptr, stream);
+                           nullptr, 1, stream);
 }
 
 extern "C" int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
                                      const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                                      int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N,
-                                     const int* positions, int64_t H, void* stream) {
+                                     const int* positions, int64_t pos_stride, int64_t H, void* stream) {
     if (!positions) return LIBRA_ERR_ALIGN;
     return rope_bridge_run(qkv, ld, tb, ldt, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, max_pos, k_cross, v_cross, ldc, N, max_pos,
-                           H, positions, stream);
+                           H, positions, pos_stride, stream);
 }
 
 extern "C" int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows,

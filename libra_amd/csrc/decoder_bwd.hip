@@ -197,6 +197,7 @@ struct RopeBwdArgs {
     const unsigned char* flag;
     bf16_t* dtb; long ldt;       // [N, >= 16]: cols 0..7 = dt_k, 8..15 = dt_v
     long N; int S, H;
+    const int* positions; int pos_stride, max_pos;   // optional explicit positions [N, pos_stride] (see libra_rope_bridge_pos)
 };
 constexpr int ROPE_BWD_TOK = 16;
 
@@ -251,8 +252,9 @@ __global__ __launch_bounds__(512) void rope_bridge_bwd_kernel(const RopeBwdArgs 
                 cur_mod = vis;
             }
             float cs[4], sn[4];
-            unpack4b(*(const u32x2*)(p.cos + (long)s * 128 + c * 4), cs);
-            unpack4b(*(const u32x2*)(p.sin + (long)s * 128 + c * 4), sn);
+            const int pos = p.positions ? min(max(p.positions[n * p.pos_stride + (p.pos_stride == 2 ? (h & 1) : 0)], 0), p.max_pos - 1) : s;
+            unpack4b(*(const u32x2*)(p.cos + (long)pos * 128 + c * 4), cs);
+            unpack4b(*(const u32x2*)(p.sin + (long)pos * 128 + c * 4), sn);
             auto ld2 = [&](const bf16_t* t, float* a, float* b) {
                 unpack4b(*(const u32x2*)(t + n * p.ld + col0), a);
                 unpack4b(*(const u32x2*)(t + n * p.ld + col1), b);
@@ -386,8 +388,10 @@ extern "C" int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const 
                                      const void* dv_cross, int64_t ld, const void* cos, const void* sin, int64_t max_pos,
                                      void* dqkv, int64_t ldo, void* dkb, int64_t ldb, const void* bk_l, const void* bk_v,
                                      const void* bv_l, const void* bv_v, const uint8_t* flag, void* dtb, int64_t ldt,
-                                     int64_t N, int64_t S, int64_t H, void* stream) {
+                                     int64_t N, int64_t S, int64_t H, const int* positions, int64_t pos_stride, void* stream) {
     if (N <= 0) return LIBRA_OK;
+    if (positions && pos_stride != 1 && pos_stride != 2) return LIBRA_ERR_SHAPE;
+    if (positions) S = S > max_pos ? max_pos : S;                      // (S only paces the implicit positions)
     if (H <= 0 || H > 32 || S <= 0 || S > max_pos || ld < H * 128 || ldo < 3 * H * 128 || ldb < H * 128) return LIBRA_ERR_SHAPE;
     if ((ld % 8) || (ldo % 8) || (ldb % 8)) return LIBRA_ERR_ALIGN;
     if (!dq || !dk_same || !dk_cross || !dv_same || !dv_cross || !cos || !sin || !dqkv || !dkb) return LIBRA_ERR_ALIGN;
@@ -400,6 +404,7 @@ extern "C" int libra_rope_bridge_bwd(const void* dq, const void* dk_same, const 
     a.dqkv = (bf16_t*)dqkv; a.ldo = ldo; a.dkb = (bf16_t*)dkb; a.ldb = ldb;
     a.bk_l = (const bf16_t*)bk_l; a.bk_v = (const bf16_t*)bk_v; a.bv_l = (const bf16_t*)bv_l; a.bv_v = (const bf16_t*)bv_v;
     a.flag = flag; a.dtb = (bf16_t*)dtb; a.ldt = ldt; a.N = N; a.S = (int)S; a.H = (int)H;
+    a.positions = positions; a.pos_stride = (int)pos_stride; a.max_pos = (int)max_pos;
     const int threads = (int)((H * 16 + 63) / 64 * 64);
     const long grid = (N + ROPE_BWD_TOK - 1) / ROPE_BWD_TOK;
     if (grid > 0x7fffffffL) return LIBRA_ERR_SHAPE;

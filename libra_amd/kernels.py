@@ -521,17 +521,19 @@ def rope_bridge(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, S: int, H: int)
 
 
 def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, H: int):
-    """rope_bridge with an explicit int32 position per token (the cached decode step)."""
+    """rope_bridge with explicit int32 positions: [N] (cached decode step, left-padded prompts) or [N, 2] (use_2d_rope: even heads
+    rotate by column 0, odd heads by column 1)."""
     _chk2d(qkv, "qkv"); _chk2d(tb, "tb")
     N = qkv.shape[0]
-    if positions.dtype != torch.int32 or positions.numel() != N:
-        raise ValueError("rope_bridge_pos: positions must be int32 [N]")
+    if positions.dtype != torch.int32 or positions.numel() not in (N, 2 * N) or not positions.is_contiguous():
+        raise ValueError("rope_bridge_pos: positions must be contiguous int32 [N] or [N, 2]")
+    pstride = positions.numel() // N
     kc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
     vc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
     rc = _lib.lib().libra_rope_bridge_pos(qkv.data_ptr(), qkv.stride(0), tb.data_ptr(), tb.stride(0), bk_l.data_ptr(),
                                           bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), cos.data_ptr(),
                                           sin.data_ptr(), cos.shape[0], kc.data_ptr(), vc.data_ptr(), kc.stride(0), N,
-                                          positions.data_ptr(), H, _stream())
+                                          positions.data_ptr(), pstride, H, _stream())
     _lib.check(rc, "rope_bridge_pos")
     return kc, vc
 
@@ -673,7 +675,8 @@ def swiglu_bwd(dy, gate, up, dgate, dup):
     _lib.check(rc, "swiglu_bwd")
 
 
-def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb, *, bridge_b=None, flag=None, dtb=None):
+def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb, *, bridge_b=None, flag=None, dtb=None,
+                    positions=None):
     """bridge_b = (bk_l, bk_v, bv_l, bv_v) as weight_B^T [8, H*128] + flag + dtb [N, >=16]: also writes the rank-8 bridge
     activation gradients."""
     N = dq.shape[0]
@@ -686,7 +689,13 @@ def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb,
         extra = (bk_l.data_ptr(), bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), dtb.data_ptr(), dtb.stride(0))
     else:
         extra = (None, None, None, None, None, None, 0)
+    pstride = 1
+    if positions is not None:
+        if positions.dtype != torch.int32 or positions.numel() not in (N, 2 * N) or not positions.is_contiguous():
+            raise ValueError("rope_bridge_bwd: positions must be contiguous int32 [N] or [N, 2]")
+        pstride = positions.numel() // N
     rc = _lib.lib().libra_rope_bridge_bwd(dq.data_ptr(), dks.data_ptr(), dkc.data_ptr(), dvs.data_ptr(), dvc.data_ptr(),
                                           dq.stride(0), cos.data_ptr(), sin.data_ptr(), cos.shape[0], dqkv.data_ptr(),
-                                          dqkv.stride(0), dkb.data_ptr(), dkb.stride(0), *extra, N, S, H, _stream())
+                                          dqkv.stride(0), dkb.data_ptr(), dkb.stride(0), *extra, N, S, H, _ptr(positions), pstride,
+                                          _stream())
     _lib.check(rc, "rope_bridge_bwd")

@@ -67,9 +67,36 @@ def rotate_half(x):
 
 
 def apply_rope(x, cos, sin, position_ids):
-    c = cos[position_ids].unsqueeze(1)      # [B,1,S,d]
-    s = sin[position_ids].unsqueeze(1)
+    """position_ids [B,S] (1d) or [B,2,S] (use_2d_rope, modeling_libra.py:43-49: heads alternate between the row and the column
+    position, `cos[position_ids].repeat(1, heads // 2, 1, 1)`)."""
+    if position_ids.dim() == 3:
+        rep_ = x.shape[1] // 2
+        c = cos[position_ids].repeat(1, rep_, 1, 1)         # [B, heads, S, d]
+        s = sin[position_ids].repeat(1, rep_, 1, 1)
+    else:
+        c = cos[position_ids].unsqueeze(1)      # [B,1,S,d]
+        s = sin[position_ids].unsqueeze(1)
     return x * c + rotate_half(x) * s
+
+
+def position_ids_2d(vision_indices: torch.Tensor, max_vision_token_length: int, res: int, attention_mask=None) -> torch.Tensor:
+    """LibraModel.get_2d_position_ids (modeling_libra.py:663-678) -> [B, 2, S]: text / BOI tokens advance a running position by
+    one, EOI by res + 1, grid tokens sit at (running position of their BOI) + (row, column) in 1..res."""
+    L = max_vision_token_length
+    m = (vision_indices == L) | (vision_indices == 0)
+    if attention_mask is not None:
+        m = m & (attention_mask != 0)
+    m = m.long()
+    m[vision_indices == L - 1] = res + 1
+    pos = (m.cumsum(-1) - 1)[..., None].expand(-1, -1, 2)
+    hh = torch.arange(1, res + 1)[:, None].expand(-1, res)
+    ww = torch.arange(1, res + 1)[None, :].expand(res, -1)
+    off = torch.cat([torch.zeros(1, 2, dtype=torch.long), torch.stack([hh, ww], -1).reshape(-1, 2), torch.zeros(2, 2, dtype=torch.long)], 0)
+    pos = pos + off[vision_indices]
+    if attention_mask is not None:
+        pos = pos.clone()
+        pos[attention_mask == 0] = 1
+    return pos.permute(0, 2, 1)
 
 
 def additive_mask(attention_mask: torch.Tensor, S: int, dtype) -> torch.Tensor:
@@ -155,15 +182,20 @@ def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Option
 
 
 def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, layers: int, heads: int, vocab: int,
-                  max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048):
-    """LibraForCausalLM up to the final routed norm: -> hidden [B,S,H], vision_flag."""
+                  max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048, rope_2d_res: Optional[int] = None):
+    """LibraForCausalLM up to the final routed norm: -> hidden [B,S,H], vision_flag.  `rope_2d_res` = image_feature_resolution
+    switches on use_2d_rope (position ids from `position_ids_2d`, :731-733)."""
     flag = vision_indices < max_vision_token_length                      # :1118
     assert torch.equal(flag, input_ids[0] >= vocab)                        # :707-710
     B, S = input_ids.shape[1:]
     x = input_embeds(sd, input_ids, flag, signal, vocab, eps)
     d = x.shape[-1] // heads
-    cos, sin = rope_tables(d, max(max_pos, S), dtype=x.dtype)
-    pos = torch.arange(S).unsqueeze(0).expand(B, S)
+    if rope_2d_res is not None:
+        pos = position_ids_2d(vision_indices, max_vision_token_length, rope_2d_res)
+        cos, sin = rope_tables(d, max(max_pos, int(pos.max()) + 1), dtype=x.dtype)
+    else:
+        cos, sin = rope_tables(d, max(max_pos, S), dtype=x.dtype)
+        pos = torch.arange(S).unsqueeze(0).expand(B, S)
     mask = additive_mask(attention_mask, S, x.dtype)
     for i in range(layers):
         x = decoder_layer(sd, i, x, flag, mask, pos, heads, eps, cos, sin)
@@ -185,6 +217,51 @@ def vl_logits(sd, hidden, flag, Q: int):
         row_l = torch.cat([lang, neg_v], -1)
         row_v = torch.cat([neg_l, vis], -1)
         outs.append(torch.where(flag.unsqueeze(-1), row_v, row_l))
+    return torch.stack(outs)
+
+
+def vl_logits_unified(sd, hidden, Q: int):
+    """cal_vl_logits with unified_head (modeling_libra.py:1054-1064, training / uncached): every row gets [lm_head | head_q]."""
+    lang = F.linear(hidden, sd["lm_head.weight"])
+    return torch.stack([torch.cat([lang, F.linear(hidden, sd[f"vision_lm_head.heads.{q}.weight"])], -1) for q in range(Q)])
+
+
+def vision_features_2d(sd, hidden, flag, max_vision_token_length: int, res: int):
+    """cal_vision_logits_train (modeling_libra.py:942-1014), complete images only: the input of the vision heads in
+    vision_prediction_mode="2d".  The row at the position that PREDICTS grid cell (i, j) is cat(up, left) = (hidden of cell
+    (i-1, j) | hidden of cell (i, j-1)), the learned placeholder where there is none - except left of cell (0, 0), which is BOI;
+    the last grid token's row (predicting EOI) is (itself | placeholder), the EOI row (no loss) likewise. -> [n_vision, 2C]."""
+    L, C = max_vision_token_length, hidden.shape[-1]
+    vis = hidden[flag]
+    assert vis.shape[0] % L == 0, "vision_prediction_mode='2d' assumes complete images"
+    n = vis.shape[0] // L
+    vis = vis.view(n, L, C)
+    ph = sd["vision_hidden_placeholder"].to(hidden.dtype)
+    amap = ph[None, None, None, :].repeat(n, res + 1, res + 1, 1)
+    amap[:, 1, 0, :] = vis[:, 0, :]
+    amap[:, 1:, 1:, :] = vis[:, 1:-1, :].reshape(n, res, res, C)
+    grid = torch.cat([amap[:, :-1, 1:, :], amap[:, 1:, :-1, :]], -1).reshape(n, L - 2, 2 * C)
+    phn = ph[None, None, :].expand(n, 1, C)
+    to_eoi = torch.cat([vis[:, -2:-1, :], phn], -1)
+    eoi = torch.cat([vis[:, -1:, :], phn], -1)
+    return torch.cat([grid, to_eoi, eoi], 1).reshape(-1, 2 * C)
+
+
+def vl_logits_2d(sd, hidden, flag, Q: int, max_vision_token_length: int, res: int):
+    """cal_vl_logits with vision_prediction_mode="2d": text rows as in 1d; vision rows = head_q(cat(up, left)), heads [Vv, 2C]."""
+    lang = F.linear(hidden, sd["lm_head.weight"])
+    V = lang.shape[-1]
+    feats = vision_features_2d(sd, hidden, flag, max_vision_token_length, res)
+    outs = []
+    for q in range(Q):
+        vis = F.linear(feats, sd[f"vision_lm_head.heads.{q}.weight"])
+        Vv = vis.shape[-1]
+        full = torch.full(hidden.shape[:-1] + (V + Vv,), float("-inf"), dtype=lang.dtype)
+        full[..., :V] = torch.where(flag.unsqueeze(-1), torch.full_like(lang, float("-inf")), lang)
+        row_v = torch.cat([torch.full((vis.shape[0], V), float("-inf"), dtype=lang.dtype), vis], -1)
+        full = full.clone()
+        full[flag] = row_v
+        outs.append(full)
     return torch.stack(outs)
 
 

@@ -36,16 +36,16 @@ def test_row_kernels_argument_validation(L):
     assert L.libra_vit_attn_fwd(FAKE, 3072, FAKE, 1024, None, None, 1, 577, 0, 0.125, None) == ERR_SHAPE          # no heads
     # rope_bridge_bwd: the 512-thread token group covers H <= 32 heads (Libra-7B / 11B); more is refused, not mis-computed
     args = [FAKE] * 5 + [8192, FAKE, FAKE, 4096, FAKE, 3 * 8192, FAKE, 8192] + [None] * 6 + [0, 10, 10]
-    assert L.libra_rope_bridge_bwd(*args, 64, None) == ERR_SHAPE
+    assert L.libra_rope_bridge_bwd(*args, 64, None, 1, None) == ERR_SHAPE
     # with the bridge-gradient output requested, its operands are mandatory
     args2 = [FAKE] * 5 + [4096, FAKE, FAKE, 4096, FAKE, 3 * 4096, FAKE, 4096, None, None, None, None, None, FAKE, 64, 10, 10]
-    assert L.libra_rope_bridge_bwd(*args2, 32, None) == ERR_ALIGN
+    assert L.libra_rope_bridge_bwd(*args2, 32, None, 1, None) == ERR_ALIGN
 
 
 def test_generation_entry_points_argument_validation(L):
     # rope with explicit positions: the position operand is mandatory
     args = [FAKE, 3 * 256, FAKE, 64, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, 64, FAKE, FAKE, 256, 4]
-    assert L.libra_rope_bridge_pos(*args, None, 2, None) == ERR_ALIGN
+    assert L.libra_rope_bridge_pos(*args, None, 1, 2, None) == ERR_ALIGN
     # decode attention: cache row stride shorter than H*128, batch stride shorter than a row, null cache
     ok = dict(q=FAKE, ldq=256, ks=FAKE, kc=FAKE, vs=FAKE, vc=FAKE, ldc=256, bs=256 * 64, kf=FAKE, fs=64, qf=FAKE, kl=FAKE, out=FAKE,
               ldo=256, B=2, H=2)

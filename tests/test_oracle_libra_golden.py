@@ -143,3 +143,43 @@ def test_greedy_generation_matches_reference_greedy_search():
     assert torch.equal(torch.isfinite(scores), torch.isfinite(ref)) and torch.equal(torch.isposinf(scores), torch.isposinf(ref))
     fin = torch.isfinite(ref)
     assert rel_err(scores[fin], ref[fin]) < 2e-5
+
+
+def test_f4_variants_match_reference():
+    """§8f-4: use_2d_rope, unified_head, vision_prediction_mode='2d' (and 2d rope + 2d prediction together) - the oracle's
+    restatements against the reference's own forward + autograd (tests/golden/make_golden_libra_f4.py)."""
+    t, meta = load_golden("libra_tiny_f4.safetensors")
+    t0, _ = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    L, res, Q = c["max_vision_token_length"], c["image_feature_resolution"], c["vision_codebook_num"]
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"], max_vision_token_length=L,
+              eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    ids, am, vi, sig, labels = t0["in.input_ids"], t0["in.attention_mask"], t0["in.vision_indices"], t0["in.signal"], t0["in.labels"]
+    for name, over in meta["variants"].items():
+        sd = {k: v.clone() for k, v in sub(t0, "w.").items()}
+        for k, v in sub(t, f"{name}.w.").items():
+            sd[k] = v.clone()
+        sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+        hid, flag = LO.model_forward(sd, ids, am, vi, sig, rope_2d_res=res if over.get("use_2d_rope") else None, **kw)
+        if over.get("use_2d_rope"):
+            assert torch.equal(LO.position_ids_2d(vi, L, res), t[f"{name}.position_ids"])
+        if over.get("unified_head"):
+            z = LO.vl_logits_unified(sd, hid, Q)
+        elif over.get("vision_prediction_mode") == "2d":
+            z = LO.vl_logits_2d(sd, hid, flag, Q, L, res)
+        else:
+            z = LO.vl_logits(sd, hid, flag, Q)
+        loss = LO.causal_lm_loss(z, labels)
+        loss.backward()
+        assert rel_err(hid.detach(), t[f"{name}.hidden"]) < 2e-5, name
+        ref = t[f"{name}.logits"]
+        assert torch.equal(torch.isfinite(z), torch.isfinite(ref)), name
+        fin = torch.isfinite(ref)
+        assert rel_err(z.detach()[fin], ref[fin]) < 2e-5, name
+        assert abs(float(loss) - float(t[f"{name}.loss"])) < 1e-5 * abs(float(t[f"{name}.loss"])), name
+        n = 0
+        for k, g in sub(t, f"{name}.grad.").items():
+            assert sd[k].grad is not None, (name, k)
+            assert rel_err(sd[k].grad, g) < 2e-4, (name, k, rel_err(sd[k].grad, g))
+            n += 1
+        assert n >= 11, (name, n)
