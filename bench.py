@@ -448,7 +448,13 @@ def main():
 
     gpi = gflop_per_image(args.workload, args.seq, args.full_finetune)
     roof = roofline(w, args.workload, ips / world, gpi)
-    names = {"bridge": f"configs[2]: ViT-L/14@336 + VQ encode (no grad) -> tensor assembly -> Libra-11B routed-bridge decoder "
+    if args.full_finetune or args.seq > 2048:
+        cfg_name = "configs[4]-shaped (instruction tuning)"
+    elif args.seq != 2048 or args.with_optimizer:
+        cfg_name = "configs[3]-shaped (pretraining step)"
+    else:
+        cfg_name = "configs[2]"
+    names = {"bridge": f"{cfg_name}: ViT-L/14@336 + VQ encode (no grad) -> tensor assembly -> Libra-11B routed-bridge decoder "
                        f"fwd+bwd, {'all 11.0 B parameters trainable' if args.full_finetune else 'LLaMA-2-7B text stream frozen (4.27 B trainable)'}, bs={args.batch}/GPU, seq {args.seq}, one "
                        "336px image per sequence, random-init",
              "vit": f"configs[1]: ViT-L/14@336 + VQ encode fwd/bwd bf16, bs={args.batch}/GPU (LLM frozen)"}

@@ -36,6 +36,10 @@ class DecDims:
     down_ratio: int = 4
     eps: float = 1e-6
     max_pos: int = 2048
+    rope_2d: bool = False          # config.use_2d_rope (modeling_libra.py:43-49, :663-678)
+    unified_head: bool = False     # config.unified_head (:1054-1064)
+    pred_2d: bool = False          # config.vision_prediction_mode == "2d" (:942-1014)
+    res: int = 0                   # config.image_feature_resolution (max_vision_len == res * res + 2)
 
     @property
     def r(self):
@@ -56,6 +60,11 @@ def rope_tables(dim: int, n_pos: int, device, base: float = 10000.0):
     if key not in _ROPE_TABLES:
         _ROPE_TABLES[key] = _rope_tables(dim, n_pos, device, base)
     return _ROPE_TABLES[key]
+
+
+def rope_rows(d: "DecDims", n_tokens: int) -> int:
+    """Rows of the cos / sin tables: every position a sequence of n_tokens can reach (2d positions run at most res ahead)."""
+    return max(d.max_pos, n_tokens + (d.res + 2 if d.rope_2d else 0))
 
 
 def _rope_tables(dim: int, n_pos: int, device, base: float):
@@ -198,6 +207,46 @@ def _rows(n: int, c: int, dev, save: bool):
     return K.alloc_rows(n, c, dev)[:n] if save else torch.empty((n, c), dtype=BF16, device=dev)
 
 
+def positions_2d(vision_indices: torch.Tensor, d: DecDims, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LibraModel.get_2d_position_ids (modeling_libra.py:663-678) -> int32 [B, S, 2] (row, column): text and <img> tokens advance
+    a running position by one, </img> by res + 1, a grid token sits at (running position) + (its row, its column) in 1..res;
+    with `attention_mask` (generation, left padding) masked tokens do not advance it and sit at position 1."""
+    L, res = d.max_vision_len, d.res
+    vi = vision_indices.long()
+    step = (vi == L) | (vi == 0)
+    if attention_mask is not None:
+        step = step & (attention_mask != 0)
+    step = step.long()
+    step = torch.where(vi == L - 1, torch.full_like(step, res + 1), step)
+    run = step.cumsum(-1) - 1
+    grid = (vi >= 1) & (vi <= L - 2)
+    cell = (vi - 1).clamp_(0, max(res * res - 1, 0))
+    row = torch.where(grid, cell // max(res, 1) + 1, torch.zeros_like(vi))
+    col = torch.where(grid, cell % max(res, 1) + 1, torch.zeros_like(vi))
+    pos = torch.stack((run + row, run + col), -1)
+    if attention_mask is not None:
+        pos = pos.masked_fill((attention_mask == 0).unsqueeze(-1), 1)
+    return pos.to(torch.int32).contiguous()
+
+
+def pred2d_sources(vision_indices_flat: torch.Tensor, vis_idx: torch.Tensor, d: DecDims, none_row: int):
+    """vision_prediction_mode="2d" (cal_vision_logits_train, modeling_libra.py:942-1014) in closed form.  The head input of the
+    vision row at flat position p whose in-image index is k (0 = <img>, 1..res^2 = grid cells in raster order, L-1 = </img>) is
+    cat(hidden[src_a], hidden[src_b]); rows k < L-2 predict grid cell k = (i, j): src_a = the cell above (p + 1 - res, exists
+    when i >= 1), src_b = the cell to the left (p itself, when j >= 1; <img> itself for cell (0,0)); rows L-2 and L-1:
+    (p, none).  `none_row` = the row of the learned placeholder.  Every source is at or before p (causal), so the same
+    formula serves truncated images and token-by-token generation (the reference pads to complete images instead, :944-966,
+    :905-938).  -> (src_a, src_b) int32 [n_v]."""
+    L, res = d.max_vision_len, d.res
+    p = vis_idx.long()
+    k = vision_indices_flat.long().index_select(0, p)
+    none = torch.full_like(p, none_row)
+    tail = k >= L - 2
+    src_a = torch.where(tail, p, torch.where(k >= res, p + 1 - res, none))
+    src_b = torch.where(tail, none, torch.where((k % res >= 1) | (k == 0), p, none))
+    return src_a.to(torch.int32).contiguous(), src_b.to(torch.int32).contiguous()
+
+
 class KVCache:
     """Per-layer key / value cache of the generation path (the reference's 4-tuple ([K_for_vision, K_for_language], V,
     V_bridge, vision_flag), modeling_libra.py:344-361), held as the four row buffers the kernels produce anyway:
@@ -211,6 +260,8 @@ class KVCache:
         self.start: Optional[torch.Tensor] = None          # int32 [B] first valid slot of each sequence (left-padded prompts)
         self.graphs: Dict[tuple, tuple] = {}               # routing pattern of a decode step -> (hipGraph, static buffers, outputs)
         self.pack_key = None                               # version of the packed weights the graphs were captured against
+        self.run2d: Optional[torch.Tensor] = None          # use_2d_rope: int64 [B] running position (get_2d_position_ids' cumsum) at the last token
+        self.hid: Optional[torch.Tensor] = None            # vision_prediction_mode="2d": final hidden state of every cached token [B, capacity, H]
 
     def get_seq_length(self) -> int:
         return self.length
@@ -320,6 +371,48 @@ def check_ids(input_ids, flag_bs, d: DecDims):
         raise IndexError(f"a vision token id lies outside [{V}, {V + Vv}) in one of the codebooks")
 
 
+def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, unified: bool = False, src2d=None, hidden_src=None):
+    """cal_vl_logits (modeling_libra.py:1018-1064) without the -inf padding: -> (z_lang [n_l, V] or None, z_vis list of
+    [n_v, Vv] or None, z_all list of [N, V+Vv] or None, feats or None).
+    default: text rows through lm_head, vision rows through head_q.
+    unified (unified_head, uncached forward :1054-1064): EVERY row gets [lm_head | head_q] - one GEMM per codebook against the
+    row-concatenated weight.
+    src2d = (src_a, src_b) (vision_prediction_mode "2d"): vision rows = head_q(cat(hidden_src[src_a], hidden_src[src_b])), head_q
+    [Vv, 2H]; `hidden_src` = the hidden states + the placeholder row the sources index into."""
+    dev = hidden.device
+    N, H = hidden.shape
+    n_l, n_v = lang_idx.numel(), vis_idx.numel()
+    if unified:
+        z_all = []
+        ld = K.round_up(d.vocab + d.vision_vocab, 8)
+        for q in range(Q):
+            wcat = torch.cat([sd["lm_head.weight"], sd[f"vision_lm_head.heads.{q}.weight"]], 0)
+            buf = torch.empty((N, ld), dtype=BF16, device=dev)
+            z_all.append(K.gemm_nt(hidden, wcat, out=buf[:, :d.vocab + d.vision_vocab]))
+        return None, [None] * Q, z_all, None
+    z_lang = None
+    if n_l:                                                   # (row stride padded to 8 elements: any vocabulary size)
+        zl = torch.empty((n_l, K.round_up(d.vocab, 8)), dtype=BF16, device=dev)
+        z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx, out=zl[:, :d.vocab])
+    z_vis, feats = [], None
+    vv_ld = K.round_up(d.vision_vocab, 8)
+    if n_v and src2d is not None:
+        feats = K.alloc_rows(n_v, 2 * H, dev)[:n_v]
+        K.copy_rows(hidden_src, src2d[0], n_v, feats, 0)
+        K.copy_rows(hidden_src, src2d[1], n_v, feats, H)
+    for q in range(Q):
+        if n_v:
+            buf = torch.empty((n_v, vv_ld), dtype=BF16, device=dev)
+            wq = sd[f"vision_lm_head.heads.{q}.weight"]
+            if feats is not None:
+                z_vis.append(K.gemm_nt(feats, wq, out=buf[:, :d.vision_vocab]))
+            else:
+                z_vis.append(K.gemm_nt(hidden, wq, a_rows=vis_idx, out=buf[:, :d.vision_vocab]))
+        else:
+            z_vis.append(None)
+    return z_lang, z_vis, None, feats
+
+
 def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, signal, labels=None, *,
             want_hidden_states: bool = False, save: bool = False, cache: Optional[KVCache] = None,
             recompute: bool = False):
@@ -333,7 +426,10 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         raise TypeError(f"labels must be int64 (torch.long), got {labels.dtype}")
     flag, lang_idx, vis_idx, lens, starts = route(vision_indices, attention_mask, d, allow_left=not save)
     positions = None
-    if starts is not None:                      # left padding: position_ids = attention_mask.cumsum(-1) - 1, pads -> 1 (:1204-1207)
+    if d.rope_2d:                               # (row, column) positions; the mask only matters for left-padded generation prompts
+        pos2 = positions_2d(vision_indices, d, attention_mask if starts is not None else None)
+        positions = pos2.view(-1, 2)
+    elif starts is not None:                    # left padding: position_ids = attention_mask.cumsum(-1) - 1, pads -> 1 (:1204-1207)
         am = attention_mask.to(torch.long)
         positions = (am.cumsum(-1) - 1).masked_fill(am == 0, 1).reshape(-1).to(torch.int32).contiguous()
     if cache is not None:
@@ -343,8 +439,13 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
             raise NotImplementedError("cached generation continues every sequence at slot S: pad the prompts on the LEFT "
                                       "(tokenizer.padding_side = 'left', as the reference demo does); got right padding")
         cache.start = starts
+        if d.rope_2d:                           # the running position after the prompt's last token: decode steps advance it
+            vl = vision_indices[:, -1].long()
+            cell = (vl - 1).clamp(0, max(d.res * d.res - 1, 0))
+            row = torch.where((vl >= 1) & (vl <= d.max_vision_len - 2), cell // d.res + 1, torch.zeros_like(vl))
+            cache.run2d = pos2[:, -1, 0].long() - row
     check_ids(input_ids, flag.view(B, S).bool(), d)
-    cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, S), dev)
+    cos, sin = rope_tables(d.hidden // d.heads, rope_rows(d, S), dev)
     saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
     x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None)
     hs = [x] if want_hidden_states else None
@@ -362,43 +463,46 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         cache.length = S
     hidden, rstd_f = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
-    z_lang = None
-    if n_l:                                                   # (row stride padded to 8 elements: any vocabulary size)
-        zl = torch.empty((n_l, K.round_up(d.vocab, 8)), dtype=BF16, device=dev)
-        z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx, out=zl[:, :d.vocab])
-    z_vis = []
-    vv_ld = K.round_up(d.vision_vocab, 8)
-    for q in range(Q):
+    N = B * S
+    unified = d.unified_head and cache is None           # with use_cache the reference masks the foreign half: the routed heads
+    src2d = hidden_src = None
+    if d.pred_2d:
+        if cache is not None:
+            cache.hid = torch.zeros((B, cache.capacity, d.hidden), dtype=BF16, device=dev)
+            cache.hid[:, :S] = hidden.view(B, S, d.hidden)
         if n_v:
-            buf = torch.empty((n_v, vv_ld), dtype=BF16, device=dev)
-            z_vis.append(K.gemm_nt(hidden, sd[f"vision_lm_head.heads.{q}.weight"], a_rows=vis_idx, out=buf[:, :d.vision_vocab]))
-        else:
-            z_vis.append(None)
+            hidden_src = torch.cat([hidden, sd["vision_hidden_placeholder"].to(BF16).view(1, -1)], 0)      # row N = the placeholder
+            src2d = pred2d_sources(vision_indices.reshape(-1), vis_idx, d, N)
+    z_lang, z_vis, z_all, feats = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, unified=unified, src2d=src2d,
+                                                hidden_src=hidden_src)
     loss = None
     tgts, counts = [], []
     if labels is not None:
-        N = B * S
         loss = torch.zeros((), dtype=torch.float32, device=dev)
         for q in range(Q):
             tgt = torch.full((B, S), -100, dtype=torch.int64, device=dev)
             tgt[:, :-1] = labels[q][:, 1:]                                             # shift so that tokens < n predict n
-            tgt = tgt.reshape(N)
+            tgt = tgt.reshape(N).contiguous()
             tl = tgt.index_select(0, lang_idx.long()).contiguous() if n_l else None
             tv = tgt.index_select(0, vis_idx.long()).contiguous() if n_v else None
             tot = torch.zeros((), dtype=torch.float32, device=dev)
-            if n_l:
-                tot = tot + K.ce_rows(z_lang, tl, 0).sum()
-            if n_v:
-                tot = tot + K.ce_rows(z_vis[q], tv, d.vocab).sum()
+            if unified:
+                tl = tgt                                                               # one softmax over [V | Vv] on every row
+                tot = tot + K.ce_rows(z_all[q], tgt, 0).sum()
+            else:
+                if n_l:
+                    tot = tot + K.ce_rows(z_lang, tl, 0).sum()
+                if n_v:
+                    tot = tot + K.ce_rows(z_vis[q], tv, d.vocab).sum()
             cnt = (tgt >= 0).sum().clamp_min(1)
             loss = loss + tot / cnt
             tgts.append((tl, tv)); counts.append(cnt)
         loss = loss / Q
     if save:
         saved.update(x_last=x, rstd_f=rstd_f, hidden=hidden, tgts=tgts, counts=counts, cos=cos, sin=sin, lens=lens, B=B, S=S,
-                     Q=Q, input_ids=input_ids)
+                     Q=Q, input_ids=input_ids, positions=positions, unified=unified, src2d=src2d, feats=feats)
     return dict(hidden=hidden.view(B, S, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang,
-                z_vis=z_vis, loss=loss, hidden_states=hs, saved=saved)
+                z_vis=z_vis, z_all=z_all, loss=loss, hidden_states=hs, saved=saved)
 
 
 def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
@@ -571,14 +675,35 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
 
     if Q > 2:
         raise NotImplementedError("more than two codebooks")
-    if n_l:
+    if sv["unified"]:
+        # unified_head: per codebook one head [V + Vv, H] = [lm_head; head_q] over every row (modeling_libra.py:1054-1064)
+        V, Vv = d.vocab, d.vision_vocab
+        Vp = K.round_up(V + Vv, 64)
+        hid_c = _compact(hidden, torch.arange(N, dtype=torch.int32, device=dev))       # 64-row padded: the wgrad's reduction axis
+        gl = None
+        for q in range(Q):
+            name = f"vision_lm_head.heads.{q}.weight"
+            wcat = torch.zeros((Vp, H), dtype=BF16, device=dev)
+            wcat[:V] = sd["lm_head.weight"]
+            wcat[V:V + Vv] = sd[name]
+            dzf = dlogits(out["z_all"][q], sv["tgts"][q][0], None, 0, coef[q], 0.0, Vp)
+            K.gemm_nt(dzf[:N], wcat, b_t=True, out=dhid, resid=dhid if q > 0 else None)
+            if w(name) or w("lm_head.weight"):
+                gw = K.gemm_nt(dzf, _full(hid_c), a_t=True, b_t=True)
+                if w(name):
+                    g[name] = gw[V:V + Vv].contiguous()
+                if w("lm_head.weight"):
+                    gl = gw[:V].float() if gl is None else gl + gw[:V].float()
+        if gl is not None:
+            g["lm_head.weight"] = gl.to(BF16)
+    if n_l and not sv["unified"]:
         tl = [sv["tgts"][q][0] for q in range(Q)]
         wl, V, Vp = head_pad("lm_head.weight")
         dzf = dlogits(out["z_lang"], tl[0], tl[1] if Q > 1 else None, 0, coef[0], coef[1] if Q > 1 else 0.0, Vp)
         K.gemm_nt(dzf[:n_l], wl, b_t=True, out=dhid, c_rows=lang_idx)
         if w("lm_head.weight"):
             g["lm_head.weight"] = K.gemm_nt(dzf, _full(_compact(hidden, lang_idx)), a_t=True, b_t=True)[:V]
-    if n_v:
+    if n_v and not sv["unified"] and sv["src2d"] is None:
         hv = None
         for q in range(Q):
             name = f"vision_lm_head.heads.{q}.weight"
@@ -588,6 +713,26 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
             if w(name):
                 hv = _compact(hidden, vis_idx) if hv is None else hv
                 g[name] = K.gemm_nt(dzf, _full(hv), a_t=True, b_t=True)[:V]
+    if n_v and sv["src2d"] is not None:
+        # vision_prediction_mode "2d": z = head_q(cat(hidden[src_a], hidden[src_b])); dfeat scatters back onto its two sources
+        feats, (src_a, src_b) = sv["feats"], sv["src2d"]
+        dfeat = torch.empty((n_v, 2 * H), dtype=BF16, device=dev)
+        for q in range(Q):
+            name = f"vision_lm_head.heads.{q}.weight"
+            wq, V, Vp = head_pad(name)
+            dzf = dlogits(out["z_vis"][q], sv["tgts"][q][1], None, d.vocab, coef[q], 0.0, Vp)
+            K.gemm_nt(dzf[:n_v], wq, b_t=True, out=dfeat, resid=dfeat if q > 0 else None)
+            if w(name):
+                g[name] = K.gemm_nt(dzf, _full(feats), a_t=True, b_t=True)[:V]
+        # each hidden row is a source at most twice (left of its own row, above of the row res - 1 further): bf16 index_add of
+        # two terms onto zeros is order-independent; the placeholder collects thousands of rows -> fp32 masked sum.  (plumbing)
+        ph = torch.zeros(H, dtype=torch.float32, device=dev)
+        for src, half in ((src_a, dfeat[:, :H]), (src_b, dfeat[:, H:])):
+            real = src < N
+            dhid.index_add_(0, src[real].long(), half[real])
+            ph += (half.float() * (~real).unsqueeze(1)).sum(0)
+        if w("vision_hidden_placeholder"):
+            g["vision_hidden_placeholder"] = ph.to(BF16)
     dx = K.rmsnorm_routed_bwd(dhid, sv["x_last"], sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, sv["rstd_f"])
     if w("model.norm.weight") or w("model.vision_norm.weight"):
         dl, dv = f32(H), f32(H)
@@ -595,15 +740,17 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         g["model.norm.weight"], g["model.vision_norm.weight"] = K.f32_to_bf16(dl), K.f32_to_bf16(dv)
 
     emitted: set = set()
-    groups = want_groups(want, d.layers)
+    groups = want_groups(want, d.layers, () if d.pred_2d else _NO_GRAD_NAMES)
     _zero_fill(g, groups[0], sd)               # a head whose modality is absent from this batch still gets a (zero) gradient
     dp.emit_new(g, emitted)                    # heads + final norm
     for i in range(d.layers - 1, -1, -1):
         svi = sv["layers"][i]
         if sv["recompute"]:                    # gradient checkpointing: rebuild this layer's activations from its input
             x_in, svi = svi["x"], {}
-            layer_forward(sd, packed[i], i, d, x_in, flag, lang_idx, vis_idx, lens, cos, sin, B, S, svi, need_out=False)
-        dx = layer_backward(sd, packed[i], i, d, svi, dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w)
+            layer_forward(sd, packed[i], i, d, x_in, flag, lang_idx, vis_idx, lens, cos, sin, B, S, svi, need_out=False,
+                          positions=sv["positions"])
+        dx = layer_backward(sd, packed[i], i, d, svi, dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w,
+                            positions=sv["positions"])
         svi.clear()
         sv["layers"][i] = None
         _zero_fill(g, groups[1 + (d.layers - 1 - i)], sd)
@@ -640,7 +787,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     return g
 
 
-_NO_GRAD_NAMES = ("vision_hidden_placeholder",)       # only read by the 2d prediction mode: no gradient upstream either
+_NO_GRAD_NAMES = ("vision_hidden_placeholder",)       # read only by vision_prediction_mode="2d" (d.pred_2d): no gradient otherwise
 
 
 def emit_group(name: str, n_layers: int) -> int:
@@ -648,15 +795,16 @@ def emit_group(name: str, n_layers: int) -> int:
     Rank-independent: the data-parallel buckets (dp.GradBuckets) are laid out by it."""
     if name.startswith("model.layers."):
         return 1 + (n_layers - 1 - int(name.split(".")[2]))
-    if name in ("model.norm.weight", "model.vision_norm.weight") or name.startswith(("lm_head.", "vision_lm_head.")):
+    if name in ("model.norm.weight", "model.vision_norm.weight", "vision_hidden_placeholder") or \
+            name.startswith(("lm_head.", "vision_lm_head.")):
         return 0
     return n_layers + 1
 
 
-def want_groups(want, n_layers: int):
+def want_groups(want, n_layers: int, skip=_NO_GRAD_NAMES):
     groups = [[] for _ in range(n_layers + 2)]
     for n in sorted(want):
-        if n not in _NO_GRAD_NAMES:
+        if n not in skip:
             groups[emit_group(n, n_layers)].append(n)
     return groups
 
@@ -670,7 +818,7 @@ def _zero_fill(g, names, sd):
             g[n] = buf.zero_() if buf is not None else torch.zeros_like(sd[n], dtype=BF16)
 
 
-def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w):
+def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w, positions=None):
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S
     dev = dx_out.device
@@ -747,7 +895,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     dkb = torch.empty((N, H), dtype=BF16, device=dev)
     # (dt_k = B_k^T dkb, dt_v = B_v^T dvb land in dtb[:, 0:16] from the same kernel: no skinny GEMMs re-reading dkb / dvb)
     K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb,
-                      bridge_b=(pk["bkT_l"], pk["bkT_v"], pk["bvT_l"], pk["bvT_v"]), flag=flag, dtb=dtb)
+                      bridge_b=(pk["bkT_l"], pk["bkT_v"], pk["bvT_l"], pk["bvT_v"]), flag=flag, dtb=dtb, positions=positions)
     dvb = dvc
     # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
     h = sv["h"]

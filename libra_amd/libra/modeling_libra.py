@@ -152,10 +152,18 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
     def __init__(self, config: LibraConfig):
         super().__init__(config)
         c = config
-        if (not c.use_bridge or not c.concat_signals or not c.norm_signals or c.addition_mode or c.use_2d_rope or c.unified_head
-                or c.use_vision_position_embedding or c.vision_prediction_mode != "1d"):
-            raise NotImplementedError("only the configuration used by both Libra recipes is built "
-                                      "(bridge on, concat+norm signals, 1d prediction; SURVEY §8f-4 lists the rest)")
+        if (not c.use_bridge or not c.concat_signals or not c.norm_signals or c.addition_mode
+                or c.use_vision_position_embedding or c.vision_prediction_mode not in ("1d", "2d")):
+            raise NotImplementedError("built: bridge on, concat + norm signals, 1d / 2d prediction, 1d / 2d RoPE, routed / unified "
+                                      "heads; not built: use_bridge=False, addition_mode, un-normed / un-concatenated signals, "
+                                      "use_vision_position_embedding (DESIGN.md §7 row f4)")
+        pred_2d = c.vision_prediction_mode == "2d"
+        if pred_2d and c.unified_head:
+            raise NotImplementedError("unified_head with vision_prediction_mode='2d' (the reference asserts it away, :1055)")
+        if (pred_2d or c.use_2d_rope) and c.image_feature_resolution ** 2 + 2 != c.max_vision_token_length:
+            raise ValueError("max_vision_token_length must be image_feature_resolution ** 2 + 2 (modeling_libra.py:572, :866)")
+        if c.use_2d_rope and c.num_attention_heads % 2:
+            raise ValueError("use_2d_rope alternates (row, column) over the heads: the head count must be even (:47-48)")
         for nm in ("resid_pdrop", "attn_pdrop", "embd_pdrop", "vision_resid_pdrop", "vision_embd_pdrop"):
             if getattr(c, nm, 0.0):
                 raise NotImplementedError(f"{nm}={getattr(c, nm)}: dropout is 0 in both Libra recipes and is not built into "
@@ -164,7 +172,7 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
             raise NotImplementedError("the fused bridge attention kernel is specialised for head_dim 128 (LLaMA-2-7B)")
         self.model = LibraModel(c)
         self.lm_head = nn.Linear(c.hidden_size, c.vocab_size, bias=False)
-        self.vision_lm_head = MultiLMHead(c.vision_codebook_num, c.hidden_size, c.vision_vocab_size)
+        self.vision_lm_head = MultiLMHead(c.vision_codebook_num, c.hidden_size * (2 if pred_2d else 1), c.vision_vocab_size)   # :858-861
         self.vision_hidden_placeholder = nn.Parameter(torch.empty(c.hidden_size))
         self.vision_hidden_placeholder.data.normal_(mean=0.0, std=c.initializer_range)
         self.max_vision_token_length = c.max_vision_token_length
@@ -172,7 +180,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                                 heads=c.num_attention_heads, vocab=c.vocab_size, vision_vocab=c.vision_vocab_size,
                                 codebooks=c.vision_codebook_num, max_vision_len=c.max_vision_token_length,
                                 signal=c.contiguous_signal_size, rank=c.bridge_rank, down_ratio=c.vision_down_ratio,
-                                eps=c.rms_norm_eps, max_pos=c.max_position_embeddings)
+                                eps=c.rms_norm_eps, max_pos=c.max_position_embeddings, rope_2d=bool(c.use_2d_rope),
+                                unified_head=bool(c.unified_head), pred_2d=pred_2d, res=int(c.image_feature_resolution))
         self._packed: Optional[DE.PackedOperands] = None
         self.post_init()
 

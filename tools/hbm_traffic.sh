@@ -10,3 +10,4 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/hbm_${WL}_wr -- python $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $R/gpurun_out/hbm_${WL}_wr.log 2>&1
 cd $R
 python tools/hbm_traffic.py $WL | tee gpurun_out/hbm_${WL}.txt
+rm -rf gpurun_out/hbm_${WL}_rd gpurun_out/hbm_${WL}_wr      # raw traces are scratch; gpurun merges back at most 64 MiB
