@@ -371,14 +371,13 @@ def check_ids(input_ids, flag_bs, d: DecDims):
         raise IndexError(f"a vision token id lies outside [{V}, {V + Vv}) in one of the codebooks")
 
 
-def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, unified: bool = False, src2d=None, hidden_src=None):
+def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, unified: bool = False, feats=None):
     """cal_vl_logits (modeling_libra.py:1018-1064) without the -inf padding: -> (z_lang [n_l, V] or None, z_vis list of
-    [n_v, Vv] or None, z_all list of [N, V+Vv] or None, feats or None).
+    [n_v, Vv] or None, z_all list of [N, V+Vv] or None).
     default: text rows through lm_head, vision rows through head_q.
     unified (unified_head, uncached forward :1054-1064): EVERY row gets [lm_head | head_q] - one GEMM per codebook against the
     row-concatenated weight.
-    src2d = (src_a, src_b) (vision_prediction_mode "2d"): vision rows = head_q(cat(hidden_src[src_a], hidden_src[src_b])), head_q
-    [Vv, 2H]; `hidden_src` = the hidden states + the placeholder row the sources index into."""
+    feats [n_v, 2H] (vision_prediction_mode "2d"): the vision rows' head input cat(up, left); head_q is [Vv, 2H]."""
     dev = hidden.device
     N, H = hidden.shape
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
@@ -389,17 +388,13 @@ def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, un
             wcat = torch.cat([sd["lm_head.weight"], sd[f"vision_lm_head.heads.{q}.weight"]], 0)
             buf = torch.empty((N, ld), dtype=BF16, device=dev)
             z_all.append(K.gemm_nt(hidden, wcat, out=buf[:, :d.vocab + d.vision_vocab]))
-        return None, [None] * Q, z_all, None
+        return None, [None] * Q, z_all
     z_lang = None
     if n_l:                                                   # (row stride padded to 8 elements: any vocabulary size)
         zl = torch.empty((n_l, K.round_up(d.vocab, 8)), dtype=BF16, device=dev)
         z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx, out=zl[:, :d.vocab])
-    z_vis, feats = [], None
+    z_vis = []
     vv_ld = K.round_up(d.vision_vocab, 8)
-    if n_v and src2d is not None:
-        feats = K.alloc_rows(n_v, 2 * H, dev)[:n_v]
-        K.copy_rows(hidden_src, src2d[0], n_v, feats, 0)
-        K.copy_rows(hidden_src, src2d[1], n_v, feats, H)
     for q in range(Q):
         if n_v:
             buf = torch.empty((n_v, vv_ld), dtype=BF16, device=dev)
@@ -410,7 +405,7 @@ def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, un
                 z_vis.append(K.gemm_nt(hidden, wq, a_rows=vis_idx, out=buf[:, :d.vision_vocab]))
         else:
             z_vis.append(None)
-    return z_lang, z_vis, None, feats
+    return z_lang, z_vis, None
 
 
 def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, signal, labels=None, *,
@@ -465,7 +460,7 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
     N = B * S
     unified = d.unified_head and cache is None           # with use_cache the reference masks the foreign half: the routed heads
-    src2d = hidden_src = None
+    src2d = feats = None
     if d.pred_2d:
         if cache is not None:
             cache.hid = torch.zeros((B, cache.capacity, d.hidden), dtype=BF16, device=dev)
@@ -473,8 +468,10 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         if n_v:
             hidden_src = torch.cat([hidden, sd["vision_hidden_placeholder"].to(BF16).view(1, -1)], 0)      # row N = the placeholder
             src2d = pred2d_sources(vision_indices.reshape(-1), vis_idx, d, N)
-    z_lang, z_vis, z_all, feats = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, unified=unified, src2d=src2d,
-                                                hidden_src=hidden_src)
+            feats = K.alloc_rows(n_v, 2 * d.hidden, dev)[:n_v]          # 64-row padded: the head wgrad's reduction operand
+            K.copy_rows(hidden_src, src2d[0], n_v, feats, 0)
+            K.copy_rows(hidden_src, src2d[1], n_v, feats, d.hidden)
+    z_lang, z_vis, z_all = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, unified=unified, feats=feats)
     loss = None
     tgts, counts = [], []
     if labels is not None:
@@ -511,28 +508,30 @@ def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
     Q, B = st["ids"].shape[0], st["ids"].shape[1]
     flag, lang_idx, vis_idx = st["flag"], st["lang_idx"], st["vis_idx"]
     dev = flag.device
-    cos, sin = rope_tables(d.hidden // d.heads, max(d.max_pos, cache.capacity), dev)
+    cos, sin = rope_tables(d.hidden // d.heads, rope_rows(d, cache.capacity), dev)
     cache.flag.index_copy_(1, st["slot"], flag.view(B, 1))
     x = embed(sd, d, st["ids"], flag, lang_idx, vis_idx, None)
     for i in range(d.layers):
         x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, st["kv_len"], cos, sin, B, 1, None, cache=cache,
                           positions=st["positions"], slot=st["slot"], kv_start=cache.start)
     hidden, _ = K.rmsnorm_routed(x, sd["model.norm.weight"], sd["model.vision_norm.weight"], flag, d.eps, save_rstd=True)
-    n_l, n_v = lang_idx.numel(), vis_idx.numel()
-    z_lang = None
-    if n_l:                                                   # (row stride padded to 8 elements: any vocabulary size)
-        zl = torch.empty((n_l, K.round_up(d.vocab, 8)), dtype=BF16, device=dev)
-        z_lang = K.gemm_nt(hidden, sd["lm_head.weight"], a_rows=lang_idx, out=zl[:, :d.vocab])
-    z_vis = []
-    vv_ld = K.round_up(d.vision_vocab, 8)
-    for q in range(Q):
-        if n_v:
-            buf = torch.empty((n_v, vv_ld), dtype=BF16, device=dev)
-            z_vis.append(K.gemm_nt(hidden, sd[f"vision_lm_head.heads.{q}.weight"], a_rows=vis_idx, out=buf[:, :d.vision_vocab]))
-        else:
-            z_vis.append(None)
+    feats = None
+    if d.pred_2d:                                           # cal_vision_logits_inference (:905-938) through pred2d_sources' formula
+        Hd, L, res = d.hidden, d.max_vision_len, d.res
+        cache.hid.index_copy_(1, st["slot"], hidden.view(B, 1, Hd))
+        if vis_idx.numel():
+            rows = vis_idx.long()
+            k = st["vi"].index_select(0, rows)
+            own = hidden.index_select(0, rows)
+            up = cache.hid[rows, (st["slot"] + 1 - res).clamp_min(0).expand(rows.numel())]      # the cell above: res - 1 tokens back
+            ph = sd["vision_hidden_placeholder"].to(BF16).view(1, Hd).expand_as(own)
+            tail = (k >= L - 2).unsqueeze(1)
+            a = torch.where(tail, own, torch.where((k >= res).unsqueeze(1), up, ph))
+            b = torch.where(tail, ph, torch.where(((k % res >= 1) | (k == 0)).unsqueeze(1), own, ph))
+            feats = torch.cat([a, b], 1)
+    z_lang, z_vis, _ = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, feats=feats)
     return dict(hidden=hidden.view(B, 1, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang, z_vis=z_vis,
-                loss=None, hidden_states=None, saved=None)
+                z_all=None, loss=None, hidden_states=None, saved=None)
 
 
 MAX_DECODE_GRAPHS = 8       # routing patterns kept per cache (in practice 2: "all text" and "all inside an image")
@@ -541,7 +540,8 @@ MAX_DECODE_GRAPHS = 8       # routing patterns kept per cache (in practice 2: "a
 @torch.no_grad()
 def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indices, position_ids, *, use_graph: bool = True):
     """One cached generation step (LibraForCausalLM.forward with past_key_values, modeling_libra.py:1118-1144): input_ids
-    [Q,B,1] are the NEW tokens, position_ids [B] their RoPE positions; decoded vision tokens have no encoder signal
+    [Q,B,1] are the NEW tokens, position_ids [B] their RoPE positions ([B,2] (row, column) with use_2d_rope; None = continue from
+    the cache's running 2d position); decoded vision tokens have no encoder signal
     (prepare_inputs_for_generation, :1216-1218 -> zeros, :646-653).  Appends to `cache`.  Same return dict as forward().
 
     A step is ~40 small launches per layer on B rows - launch-bound by two orders of magnitude against its HBM floor - so it
@@ -568,12 +568,27 @@ def decode_step(sd, packed, d: DecDims, cache: KVCache, input_ids, vision_indice
         st = dict(ids=input_ids.clone(), flag=flagb.to(torch.uint8).contiguous(),
                   lang_idx=torch.nonzero(~flagb).squeeze(1).to(torch.int32).contiguous(),
                   vis_idx=torch.nonzero(flagb).squeeze(1).to(torch.int32).contiguous(),
-                  positions=torch.empty(B, dtype=torch.int32, device=dev), slot=torch.empty(1, dtype=torch.int64, device=dev),
-                  kv_len=torch.empty(B, dtype=torch.int32, device=dev))
+                  positions=torch.empty((B, 2) if d.rope_2d else (B,), dtype=torch.int32, device=dev),
+                  slot=torch.empty(1, dtype=torch.int64, device=dev), kv_len=torch.empty(B, dtype=torch.int32, device=dev),
+                  vi=torch.empty(B, dtype=torch.int64, device=dev))
     else:
         graph, st, out = entry
         st["ids"].copy_(input_ids)
-    st["positions"].copy_(position_ids.reshape(B))
+    vi_new = vision_indices.reshape(B).long()
+    st["vi"].copy_(vi_new)
+    if d.rope_2d:                            # get_2d_position_ids (:663-678) one token on: advance the running position
+        L, res = d.max_vision_len, d.res
+        step = ((vi_new == L) | (vi_new == 0)).long()
+        cache.run2d = cache.run2d + torch.where(vi_new == L - 1, torch.full_like(step, res + 1), step)
+        if position_ids is None:
+            grid = (vi_new >= 1) & (vi_new <= L - 2)
+            cell = (vi_new - 1).clamp(0, res * res - 1)
+            zero = torch.zeros_like(vi_new)
+            position_ids = torch.stack((cache.run2d + torch.where(grid, cell // res + 1, zero),
+                                        cache.run2d + torch.where(grid, cell % res + 1, zero)), -1)
+        st["positions"].copy_(position_ids.reshape(B, 2))
+    else:
+        st["positions"].copy_(position_ids.reshape(B))
     st["slot"].fill_(cache.length)
     st["kv_len"].fill_(cache.length + 1)
     if not use_graph:
@@ -603,6 +618,8 @@ def dense_logits(out, d: DecDims, B: int, S: int):
     Q = len(out["z_vis"])
     V, Vv = d.vocab, d.vision_vocab
     dev = out["hidden"].device
+    if out.get("z_all") is not None:                         # unified head, uncached: every row is dense already (:1054-1064)
+        return torch.stack([z.contiguous() for z in out["z_all"]]).view(Q, B, S, V + Vv)
     res = torch.full((Q, B * S, V + Vv), float("-inf"), dtype=BF16, device=dev)
     for q in range(Q):
         if out["z_lang"] is not None:
@@ -663,7 +680,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         Vp = K.round_up(V, 64)
         if Vp == V:
             return W, V, Vp
-        wp = torch.zeros((Vp, H), dtype=BF16, device=dev)
+        wp = torch.zeros((Vp, W.shape[1]), dtype=BF16, device=dev)
         wp[:V] = W
         return wp, V, Vp
 

@@ -5,8 +5,9 @@ LibraDecoderLayer :416-435, LibraModel :524-600, MultiLMHead :834-843, LibraForC
 The sub-modules only own the parameters (same names and shapes as the reference checkpoints: SURVEY §8b); the
 compute is the kernel schedule in ``libra_amd/decoder_engine.py`` (forward and hand-written backward, exposed to
 autograd through one ``torch.autograd.Function``), parity-tested against the reference fixtures.
-Only the configuration both recipes use is supported (use_bridge, concat+norm signals, 1d prediction, no 2d RoPE,
-no unified head, dropout 0); anything else raises NotImplementedError rather than silently diverging.
+Built: use_bridge, concat + norm signals, dropout 0, with 1d or 2d RoPE (`use_2d_rope`), routed or unified heads
+(`unified_head`), 1d or 2d vision prediction (`vision_prediction_mode`); anything else raises NotImplementedError rather
+than silently diverging.
 """
 from __future__ import annotations
 
@@ -291,7 +292,11 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         if past is None:
             if attention_mask is None:
                 attention_mask = torch.ones((B, S), dtype=torch.bool, device=dev)
-            if position_ids is not None:
+            if position_ids is not None and dims.rope_2d:
+                want = DE.positions_2d(vision_indices, dims, attention_mask).permute(0, 2, 1)
+                if not torch.equal(position_ids.reshape(B, 2, S).to(dev).to(want.dtype), want):
+                    raise NotImplementedError("prefill positions other than get_2d_position_ids(vision_indices, attention_mask)")
+            elif position_ids is not None:
                 am = attention_mask.to(torch.long)
                 want = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
                 if not torch.equal(position_ids.reshape(B, S).to(dev), want):
@@ -311,7 +316,10 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
             if getattr(cache, "pack_key", None) != self._ptr_key():     # parameter storage moved since the graphs were captured
                 cache.graphs.clear()                                     # (values may change freely: operands are refreshed in place)
                 cache.pack_key = self._ptr_key()
-            if position_ids is None:                                                    # attention_mask.cumsum(-1) - 1, :1207
+            if dims.rope_2d:
+                if position_ids is not None:                                            # [B, 2, 1] (:1199-1201) -> [B, 2]
+                    position_ids = position_ids.reshape(B, 2)
+            elif position_ids is None:                                                  # attention_mask.cumsum(-1) - 1, :1207
                 position_ids = torch.full((B, 1), cache.length, dtype=torch.long, device=dev)
                 if cache.start is not None:
                     position_ids = position_ids - cache.start.long()[:, None]
@@ -336,7 +344,13 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         if past_key_values:
             input_ids = input_ids[:, :, -1:]
         position_ids = kwargs.get("position_ids", None)
-        if attention_mask is not None and position_ids is None:
+        dims = getattr(self, "_dims", None)
+        if attention_mask is not None and position_ids is None and dims is not None and dims.rope_2d:
+            # :1199-1201.  A cached step passes None: the cache carries get_2d_position_ids' running position, so the step's
+            # (row, column) comes out in O(1) instead of a cumsum over the whole sequence - same values.
+            if not past_key_values:
+                position_ids = DE.positions_2d(vision_indices, dims, attention_mask).permute(0, 2, 1).long()
+        elif attention_mask is not None and position_ids is None:
             position_ids = attention_mask.long().cumsum(-1) - 1
             position_ids.masked_fill_(attention_mask == 0, 1)
             if past_key_values:
@@ -370,6 +384,10 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         """modeling_libra.py:1284-1289 for the KVCache container (beam search re-gathers the batch dimension)."""
         past_key_values.layers = [tuple(t.index_select(0, beam_idx) for t in layer) for layer in past_key_values.layers]
         past_key_values.flag = past_key_values.flag.index_select(0, beam_idx)
+        for nm in ("start", "run2d", "hid"):
+            t = getattr(past_key_values, nm, None)
+            if t is not None:
+                setattr(past_key_values, nm, t.index_select(0, beam_idx))
         past_key_values.B = int(beam_idx.numel())
         past_key_values.graphs.clear()                                   # captured steps point at the buffers just replaced
         return past_key_values

@@ -207,3 +207,47 @@ def test_valid_image_logits_processor_rule():
     nn_ = NoNewlineLogitsProcessor(13, 2)
     s2 = nn_(torch.tensor([[5, 13], [13, 7]]), torch.zeros(2, 20))
     assert int(torch.isfinite(s2[0]).sum()) == 1 and torch.isfinite(s2[0, 2]) and torch.isfinite(s2[1]).all()
+
+
+def test_f4_host_helpers_match_oracle_and_reference_fixture():
+    """use_2d_rope position ids and the closed-form sources of vision_prediction_mode='2d' (decoder_engine.positions_2d /
+    pred2d_sources) against the oracle's restatements and the reference's own get_2d_position_ids output."""
+    from libra_amd import decoder_engine as DE
+    from oracle import libra_oracle as LO
+    t0, _ = load_golden("libra_tiny.safetensors")
+    t, meta = load_golden("libra_tiny_f4.safetensors")
+    c = meta["cfg"]
+    L, res = c["max_vision_token_length"], c["image_feature_resolution"]
+    d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=2, heads=2, vocab=c["vocab_size"],
+                   vision_vocab=c["vision_vocab_size"], codebooks=2, max_vision_len=L, signal=8, rope_2d=True, pred_2d=True, res=res)
+    vi, am = t0["in.vision_indices"], t0["in.attention_mask"]
+    assert torch.equal(DE.positions_2d(vi, d).permute(0, 2, 1).long(), t["rope2d.position_ids"])
+    for mask in (am, am.flip(-1)):                                                      # right- and left-padded
+        assert torch.equal(DE.positions_2d(vi, d, mask).permute(0, 2, 1).long(), LO.position_ids_2d(vi, L, res, mask))
+    # a bigger grid, two images per row, one truncated at the end of the sequence
+    res2, L2 = 4, 18
+    d2 = DE.DecDims(hidden=16, inter=32, layers=1, heads=2, vocab=10, vision_vocab=4, codebooks=1, max_vision_len=L2, signal=8,
+                    rope_2d=True, pred_2d=True, res=res2)
+    img = torch.arange(L2)
+    row = torch.cat([torch.full((3,), L2), img, torch.full((2,), L2), img, torch.full((1,), L2)])
+    vi2 = torch.stack([row, row.roll(1)])                                               # row 1: the second image ends the sequence
+    assert torch.equal(DE.positions_2d(vi2, d2).permute(0, 2, 1).long(), LO.position_ids_2d(vi2, L2, res2))
+    B, S = vi2.shape
+    H = 16
+    hid = torch.randn(B, S, H)
+    sd = {"vision_hidden_placeholder": torch.randn(H)}
+    flag = vi2 < L2
+    ref = LO.vision_features_2d(sd, hid, flag, L2, res2)
+    vis_idx = torch.nonzero(flag.reshape(-1)).squeeze(1).to(torch.int32)
+    a, b = DE.pred2d_sources(vi2.reshape(-1), vis_idx, d2, B * S)
+    hx = torch.cat([hid.reshape(-1, H), sd["vision_hidden_placeholder"][None]], 0)
+    assert torch.equal(torch.cat([hx[a.long()], hx[b.long()]], 1), ref)
+    assert bool((a.long() <= torch.where(a == B * S, a, vis_idx).long()).all())          # causal: sources at or before the row
+    # truncated image: the rows that exist get the same sources as in the complete image
+    cut = S - 5
+    vis_c = torch.nonzero(flag[:, :cut].reshape(-1)).squeeze(1).to(torch.int32)
+    a_c, b_c = DE.pred2d_sources(vi2[:, :cut].reshape(-1), vis_c, d2, B * cut)
+    hx_c = torch.cat([hid[:, :cut].reshape(-1, H), sd["vision_hidden_placeholder"][None]], 0)
+    keep = flag.clone()
+    keep[:, cut:] = False
+    assert torch.equal(torch.cat([hx_c[a_c.long()], hx_c[b_c.long()]], 1), ref[keep[flag]])
