@@ -88,13 +88,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     q = q < S ? q : S - 1;
 
     // ---- key-modality masks of this sequence into LDS (ballot over 32 flags) ----
-    const int n32 = (S + 31) / 32;
-    for (int t = wave; t < n32 + 1; t += 8) {                       // one spare word so a ragged 64-key tile reads zeros
-        const int key = t * 32 + l31;
-        const bool vis = (key < S) && (fk == 0) && p.flag[tok0 + key] != 0;
-        const unsigned long long bal = __ballot(vis);
-        if (lane == 0) kmask[t] = (unsigned)bal;
-    }
+    modality_masks(p.flag + tok0, S, kmask, tid, 512);
     const bool q_vis = p.flag[tok0 + q] != 0;
     // block-level query modality presence (for staging decisions all waves must agree on)
     int* qpres = (int*)(kmask + 192);        // all LDS lives in the one dynamic array (a second __shared__ object

@@ -74,10 +74,34 @@ __device__ __forceinline__ void glds16_off(const void* sbase, unsigned voff, voi
     const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
+__device__ __forceinline__ void glds4_off(const void* sbase, unsigned voff, void* lds_wave_base) {
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
 // Make the compiler finish (wait for) whatever produces `v` HERE: values loaded in a prologue and first used inside a
 // tile loop would otherwise get their s_waitcnt vmcnt inside the loop, where it also drains the hidden LDS-DMA queue.
 template <typename T>
 __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
+
+// Modality bit masks of one sequence into LDS: word t, bit i = token 32 t + i is a vision token, words [0, ceil(S/32)] (the
+// spare last word is zero so a ragged 64-token tile reads zeros).  One thread per word, its 32 flag bytes as 32 independent
+// loads: ONE memory round trip for the whole workgroup.  [The per-wave ballot loop this replaces made one dependent global
+// load per 256 tokens - 9 serial round trips per workgroup at S = 2048, ~10 us of every attention workgroup's prologue.]
+__device__ __forceinline__ void modality_masks(const unsigned char* __restrict__ flag_seq, int S, unsigned* masks, int tid, int nthreads) {
+    const int n32 = (S + 31) / 32;
+    for (int t = tid; t < n32 + 1; t += nthreads) {
+        unsigned char f[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {                              // clamped, unconditional loads: all 32 in flight together
+            const int tok = t * 32 + i;
+            f[i] = flag_seq[tok < S ? tok : S - 1];
+        }
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m |= ((f[i] != 0 && t * 32 + i < S) ? 1u : 0u) << i;
+        masks[t] = m;
+    }
+}
 
 // max of three without fmaxf's NaN-quieting canonicalisation moves (scores are finite or -inf here)
 __device__ __forceinline__ float max3f(float a, float b, float c) {
