@@ -74,10 +74,6 @@ __device__ __forceinline__ void glds16_off(const void* sbase, unsigned voff, voi
     const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
-__device__ __forceinline__ void glds4_off(const void* sbase, unsigned voff, void* lds_wave_base) {
-    const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
-}
 // Make the compiler finish (wait for) whatever produces `v` HERE: values loaded in a prologue and first used inside a
 // tile loop would otherwise get their s_waitcnt vmcnt inside the loop, where it also drains the hidden LDS-DMA queue.
 template <typename T>
