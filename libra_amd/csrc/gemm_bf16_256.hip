@@ -8,15 +8,20 @@
 //   * a K tile is FOUR 128x64 half-tiles (A_lo, A_hi, B_lo, B_hi; 16 KiB each, the same source-swizzled
 //     lane-linear LDS image as the small kernel), two K-tile buffers = 128 KiB LDS, 1 workgroup / CU;
 //   * every K tile is processed in 4 phases = the 4 (64x32) quadrants of the wave's block, each phase
-//     {LDS->register fragment reads + ONE half-tile of direct-to-LDS prefetch -> s_barrier -> 8 MFMA ->
-//     s_barrier}; fragments are reused across quadrants (A0,B0 | B1 | A1 | -) so a phase reads 12/4/8/0
-//     ds_read_b128;
+//     {LDS->register fragment reads -> s_barrier -> 8 MFMA with ONE half-tile of direct-to-LDS prefetch (2 pieces per
+//     wave) issued after the 2nd and the 6th of them -> s_barrier}; fragments are reused across quadrants
+//     (A0,B0 | B1 | A1 | -) so a phase reads 12/4/8/0 ds_read_b128.  [Round 2: a direct-to-LDS piece stalls the issuing
+//     wave 100-185 cycles next to ds_reads but ~50 among MFMAs; with the pieces next to the reads the "read" interval of
+//     one wave group outlasted the 256-cycle MFMA interval of the other - moving them took the step GEMMs from 7.43 to
+//     7.10 ms (positions 0|4: no gain, 3|7: half), a steady-state loop body without tail tests and one LDS address-space
+//     cast per kernel instead of per piece to 6.83 ms (tools/gemm_big.py; sq8k 1265 -> 1394 TFLOP/s).]
 //   * the two wave groups (rows 0-127 / 128-255) run the phase sequence staggered by ONE barrier, so on
 //     every SIMD one wave issues LDS/VMEM work while its partner owns the matrix pipe (s_setprio 1);
 //   * the prefetch stream never drains: half-tiles are issued in the order A_lo(t+1) A_hi(t+1) B_lo(t+2)
-//     B_hi(t+2) and the only wait is a counted `s_waitcnt vmcnt(4)` once per K tile (phase 4), i.e. two
-//     half-tiles stay in flight across every barrier.  A buffer is re-staged only after the reads of it
+//     B_hi(t+2) and the only wait is a counted `s_waitcnt vmcnt(2)` once per K tile (phase 4), i.e. one
+//     half-tile stays in flight across that barrier and B_hi(t+2) follows right behind it.  A buffer is re-staged only after the reads of it
 //     were retired before a barrier every wave has passed (B: lgkmcnt(0) before phase 2's barrier).
+#include <cstdlib>
 #include <type_traits>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
@@ -103,6 +108,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         glds16(base + srcB[h][0], dst);
         glds16(base + srcB[h][1], dst + 1024);
     };
+    const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;       // (one address-space cast, not one per piece)
+    auto pieceA = [&](int h, int kt, int j) { glds16_at(Ap + kt * kstepA + srcA[h][j], lds0 + (unsigned)((kt & 1) * KTB + h * HB + ldst + j * 1024)); };
+    auto pieceB = [&](int h, int kt, int j) { glds16_at(Bp + kt * kstepB + srcB[h][j], lds0 + (unsigned)((kt & 1) * KTB + (2 + h) * HB + ldst + j * 1024)); };
 
     const FragAddr fa = make_frag_addr(lane);
     const int aoff = wr * HB;                                  // A half of this wave group
@@ -129,7 +137,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     if (wr == 1) __builtin_amdgcn_s_barrier();                 // stagger the second wave group by one barrier
 
     bf16x8 a[2][4], b0[4], b1[4];
-    for (int kt = kt0; kt < nk; ++kt) {
+    // one K tile; STEADY = K tiles kt+1 and kt+2 exist (every iteration but the last two): no tests between the MFMAs
+    auto ktile = [&](const int kt, auto steady) {
+        constexpr bool STEADY = decltype(steady)::value;
+        const bool has1 = STEADY || kt + 1 < nk, has2 = STEADY || kt + 2 < nk;
         const char* buf = smem + (kt & 1) * KTB;
         const char* sa = buf + aoff;
         const char* sb = buf + boff;
@@ -140,31 +151,41 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) a[i][ks] = load_frag<AT>(sa, fa, toA[i], ks);
-        if (kt + 1 < nk) stageA(0, kt + 1);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b0[ks], acc[i][0], 0, 0, 0);
+                if (has1) {
+                    if (ks * 2 + i == 1) { __builtin_amdgcn_sched_barrier(0); pieceA(0, kt + 1, 0); __builtin_amdgcn_sched_barrier(0); }
+                    if (ks * 2 + i == 5) { __builtin_amdgcn_sched_barrier(0); pieceA(0, kt + 1, 1); __builtin_amdgcn_sched_barrier(0); }
+                }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ================= phase 2: read B1; prefetch A_hi(kt+1); quadrant (0,1) =================
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) b1[ks] = load_frag<BT>(sb, fa, toB[1], ks);
-        if (kt + 1 < nk) stageA(1, kt + 1);
         LIBRA_LGKMCNT0();            // all B reads of this K tile retired before the barrier: B may be re-staged next phase
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
                 acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b1[ks], acc[i][1], 0, 0, 0);
+                if (has1) {
+                    if (ks * 2 + i == 1) { __builtin_amdgcn_sched_barrier(0); pieceA(1, kt + 1, 0); __builtin_amdgcn_sched_barrier(0); }
+                    if (ks * 2 + i == 5) { __builtin_amdgcn_sched_barrier(0); pieceA(1, kt + 1, 1); __builtin_amdgcn_sched_barrier(0); }
+                }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -173,32 +194,47 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) a[i][ks] = load_frag<AT>(sa, fa, toA[2 + i], ks);
-        if (kt + 2 < nk) stageB(0, kt + 2);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
                 acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b1[ks], acc[2 + i][1], 0, 0, 0);
+                if (has2) {
+                    if (ks * 2 + i == 1) { __builtin_amdgcn_sched_barrier(0); pieceB(0, kt + 2, 0); __builtin_amdgcn_sched_barrier(0); }
+                    if (ks * 2 + i == 5) { __builtin_amdgcn_sched_barrier(0); pieceB(0, kt + 2, 1); __builtin_amdgcn_sched_barrier(0); }
+                }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ================= phase 4: prefetch B_hi(kt+2); counted wait for K tile kt+1; quadrant (1,0) =================
-        if (kt + 2 < nk) { stageB(1, kt + 2); LIBRA_VMCNT(4); } else { LIBRA_VMCNT(0); }
+        // (B_hi(kt+2) is issued after this wait, between the MFMAs below: only B_lo(kt+2) may stay in flight across the barrier)
+        if (has2) { LIBRA_VMCNT(2); } else { LIBRA_VMCNT(0); }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
                 acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b0[ks], acc[2 + i][0], 0, 0, 0);
+                if (has2) {
+                    if (ks * 2 + i == 1) { __builtin_amdgcn_sched_barrier(0); pieceB(1, kt + 2, 0); __builtin_amdgcn_sched_barrier(0); }
+                    if (ks * 2 + i == 5) { __builtin_amdgcn_sched_barrier(0); pieceB(1, kt + 2, 1); __builtin_amdgcn_sched_barrier(0); }
+                }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-    }
+    };
+    int kt = kt0;
+    for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{});
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{});
     if (wr == 0) __builtin_amdgcn_s_barrier();                 // re-align the two groups
     __syncthreads();
 
@@ -358,7 +394,7 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     void (*kern)(const Gemm256Args) =
         at ? (bt ? gemm_bf16_nt_256_kernel<true, true> : gemm_bf16_nt_256_kernel<true, false>)
            : (bt ? gemm_bf16_nt_256_kernel<false, true> : gemm_bf16_nt_256_kernel<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
+    static bool attr_set[4] = {};
     if (!attr_set[at * 2 + bt]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
         attr_set[at * 2 + bt] = true;

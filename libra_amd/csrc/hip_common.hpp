@@ -63,6 +63,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
 }
 
+// the same with the LDS destination given as a byte address (wave-uniform): no generic -> LDS pointer conversion per call
+__device__ __forceinline__ void glds16_at(const void* gsrc, unsigned lds_byte_addr) {
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
+}
+
 // 4-byte-per-lane variant (wave-uniform base + lane*4), same reasoning as glds16.
 __device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
     const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
