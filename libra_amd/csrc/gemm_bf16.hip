@@ -260,7 +260,7 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
 // remaining rows - the would-be partial wave - to the small one as a second launch: e.g. M=18464, N=1024 (ViT-L proj / fc2
 // at bs 32) = 73 x 4 tiles = 1.14 waves becomes one full wave + 136 small tiles instead of two waves.
 // Costs are microseconds fitted on MI355X (tools/prim.sh + tools/gemm_bench.py); kt = K / 64.
-static double cost256(double tiles, double kt) { return 8.6 + ceil(tiles / 256.0) * (1.74 * kt + 3.0); }
+static double cost256(double tiles, double kt) { return 8.6 + ceil(tiles / 256.0) * (1.48 * kt + 5.3); }   // (re-fitted round 2: DMA between MFMAs)
 static double cost128(double tiles, double kt) {
     const double full = floor(tiles / 512.0), rest = tiles - full * 512.0;
     return full * (5.8 + 1.245 * kt) + (rest <= 0 ? 0.0 : rest <= 256.0 ? 4.8 + 0.606 * kt      // <= 1 block / CU: it owns the CU
