@@ -13,7 +13,7 @@
 //     (A0,B0 | B1 | A1 | -) so a phase reads 12/4/8/0 ds_read_b128.  [Round 2: a direct-to-LDS piece stalls the issuing
 //     wave 100-185 cycles next to ds_reads but ~50 among MFMAs; with the pieces next to the reads the "read" interval of
 //     one wave group outlasted the 256-cycle MFMA interval of the other - moving them took the step GEMMs from 7.43 to
-//     7.10 ms (positions 0|4: no gain, 3|7: half), a steady-state loop body without tail tests and one LDS address-space
+//     7.10 ms (positions 0|4: no gain, 3|7: half; phase 4's two pieces back in its read-free load part: 7.25), a steady-state loop body without tail tests and one LDS address-space
 //     cast per kernel instead of per piece to 6.83 ms (tools/gemm_big.py; sq8k 1265 -> 1394 TFLOP/s).]
 //   * the two wave groups (rows 0-127 / 128-255) run the phase sequence staggered by ONE barrier, so on
 //     every SIMD one wave issues LDS/VMEM work while its partner owns the matrix pipe (s_setprio 1);
