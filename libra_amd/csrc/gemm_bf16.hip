@@ -296,6 +296,9 @@ extern "C" int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
     // (skinny outputs included: the rank-8 bridge weight gradients are [4096, 8] and [64, 4096] with K = 4.6k-11.8k tokens -
     //  as ordinary launches they occupy 16-32 workgroups; sliced over K they fill the chip and run at HBM speed)
     if (M < 8 || N < 8 || K < 4096 || (M % 8) || (N % 8)) return 1;
+    // (a problem that fills most of the chip with 128^2 tiles runs faster unsplit: [4096 x 1024] x K 4672 = 256 tiles 53 us vs 58
+    //  sliced four ways - the fp32 slabs and their reduction cost more than the partial wave)
+    if (((M + 127) / 128) * ((N + 127) / 128) >= 192) return 1;
     const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles > 128) return 1;
     long s = 256 / tiles;
