@@ -296,16 +296,22 @@ extern "C" int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
     // (skinny outputs included: the rank-8 bridge weight gradients are [4096, 8] and [64, 4096] with K = 4.6k-11.8k tokens -
     //  as ordinary launches they occupy 16-32 workgroups; sliced over K they fill the chip and run at HBM speed)
     if (M < 8 || N < 8 || K < 4096 || (M % 8) || (N % 8)) return 1;
-    // (a problem that fills most of the chip with 128^2 tiles runs faster unsplit: [4096 x 1024] x K 4672 = 256 tiles 53 us vs 58
-    //  sliced four ways - the fp32 slabs and their reduction cost more than the partial wave)
-    if (((M + 127) / 128) * ((N + 127) / 128) >= 192) return 1;
     const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles > 128) return 1;
     long s = 256 / tiles;
     const long max_s = K / 64 / 8;                               // at least 8 K tiles per slice
     if (s > max_s) s = max_s;
     if (s > 32) s = 32;
-    return s < 2 ? 1 : (int)s;
+    if (s < 2) return 1;
+    // a problem that fills most of the chip with 128^2 tiles and has a moderate K runs faster unsplit: the fp32 slabs and their
+    // reduction (2 s M N 4 bytes through HBM) cost more than the partial wave ([4096 x 1024] x K 4672: 53 us unsplit, 58 sliced 4x;
+    // at K 18496 sliced wins 140 : 180)
+    const double kt = (double)K / 64.0, tiles128 = (double)(((M + 127) / 128) * ((N + 127) / 128));
+    if (tiles128 >= 192.0) {
+        const double split_us = 8.6 + 1.48 * kt / (double)s + 5.3 + 2.0 * (double)s * (double)M * (double)N * 4.0 / 4.0e6;
+        if (cost128(tiles128, kt) < split_us) return 1;
+    }
+    return (int)s;
 }
 extern "C" size_t libra_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t splits) {
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
