@@ -14,6 +14,7 @@
 // accumulator registers), plus: V tiles are staged row-major as they lie in HBM and read with the LDS
 // transpose load (ds_read_b64_tr_b16) — no V^T copy exists; keys beyond the causal diagonal or the
 // sequence's valid length are masked; work-groups are ordered heaviest-first (causal imbalance).
+#include <atomic>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
@@ -371,7 +372,7 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     a.sl2 = scale * 1.4426950408889634f;
     const long nblk = (long)B * H * a.n_qt;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS);
         attr_set = true;

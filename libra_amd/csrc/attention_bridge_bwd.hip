@@ -15,6 +15,7 @@
 //              first-stage work duplicated for the same output).  The workgroup's K/V operand tiles stay
 //              resident in LDS (64 KiB); Q / dO tiles of 32 queries stream through a double buffer in BOTH
 //              images (row image for the first-stage A operand, reduction-major image for the transpose reads).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include "hip_common.hpp"
@@ -663,7 +664,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.dq = (bf16_t*)dq; a.lddq = lddq; a.dk_same = (bf16_t*)dk_same; a.dk_cross = (bf16_t*)dk_cross;
     a.dv_same = (bf16_t*)dv_same; a.dv_cross = (bf16_t*)dv_cross; a.ldg = ldg;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.scale = scale; a.sl2 = scale * LOG2E;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);

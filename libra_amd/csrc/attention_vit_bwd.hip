@@ -15,6 +15,7 @@
 //                 dV^T += dO^T P, dK^T += Q^T dS   (A = dO^T / Q^T fragments: LDS transpose reads of the dO / Q tiles)
 // Every operand tile is staged once, as it lies in HBM, in the dual-use image of attn_tiles64.hpp; D = rowsum(dO*O)
 // comes from libra_vit_attn_delta.
+#include <atomic>
 #include "hip_common.hpp"
 #include "attn_tiles64.hpp"
 #include "../../include/libra_hip.h"
@@ -351,7 +352,7 @@ extern "C" int libra_vit_attn_bwd(const void* qkv, int64_t ld_qkv, const void* d
     a.scale = scale; a.sl2 = scale * 1.4426950408889634f;
     const long nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)vit_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
         (void)hipFuncSetAttribute((const void*)vit_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);

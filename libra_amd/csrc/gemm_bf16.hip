@@ -21,6 +21,7 @@
 //
 // Requirements (checked by the C entry point): K % 64 == 0, row strides % 8 == 0 elements, pointers
 // 16-byte aligned.  M and N are arbitrary (tail rows are clamped on load and masked on store).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -416,7 +417,7 @@ static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     void (*kern)(const GemmArgs) = at ? (bt ? gemm_bf16_nt_kernel<true, true> : gemm_bf16_nt_kernel<true, false>)
                                       : (bt ? gemm_bf16_nt_kernel<false, true> : gemm_bf16_nt_kernel<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
+    static std::atomic<bool> attr_set[4];           // zero-initialised; idempotent call, atomic so concurrent first launches do not race
     if (!attr_set[at * 2 + bt]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         attr_set[at * 2 + bt] = true;

@@ -24,6 +24,7 @@
 //     B_hi(t+2) and the only wait is a counted `s_waitcnt vmcnt(2)` once per K tile (phase 4), i.e. one
 //     half-tile stays in flight across that barrier and B_hi(t+2) follows right behind it.  A buffer is re-staged only after the reads of it
 //     were retired before a barrier every wave has passed (B: lgkmcnt(0) before phase 2's barrier).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include "hip_common.hpp"
@@ -397,7 +398,7 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     void (*kern)(const Gemm256Args) =
         at ? (bt ? gemm_bf16_nt_256_kernel<true, true> : gemm_bf16_nt_256_kernel<true, false>)
            : (bt ? gemm_bf16_nt_256_kernel<false, true> : gemm_bf16_nt_256_kernel<false, false>);
-    static bool attr_set[4] = {};
+    static std::atomic<bool> attr_set[4];           // zero-initialised; idempotent call, atomic so concurrent first launches do not race
     if (!attr_set[at * 2 + bt]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
         attr_set[at * 2 + bt] = true;

@@ -6,6 +6,7 @@
 //   bit_j = x_j > 0 ;  index_q = sum_{j<9} bit_{9q+j} << (8-j)         (MSB first)
 //   ids[q,b,1+p] = offset + index_q ; ids[q,b,0] = BOI ; ids[q,b,hw+1] = EOI
 // Integer outputs are exact functions of the bits; the bits are exact functions of x's sign.
+#include <atomic>
 #include "hip_common.hpp"
 #include "../../include/libra_hip.h"
 
@@ -128,7 +129,7 @@ extern "C" int libra_lfq_encode(const void* h, int64_t ld_h, const void* w_in, c
     a.rows = rows; a.ld_h = ld_h; a.B = (int)B; a.hw = (int)hw; a.E = (int)E; a.Q = (int)Q; a.CD = (int)CD;
     a.offset = offset; a.boi = boi; a.eoi = eoi; a.has_proj = has_proj;
     const size_t lds = has_proj ? (size_t)(CD * E * 2) : 16;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)lfq_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set = true;
