@@ -5,12 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from libra_amd import kernels as K
 
-B, S, H = 8, 2048, 32
+B, S, H = int(os.environ.get("ATTN_B", 8)), int(os.environ.get("ATTN_S", 2048)), 32
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 N, D = B * S, H * 128
 g = torch.Generator(device="cuda").manual_seed(0)
 q, ks, kc, vs, vc, do = [torch.randn(N, D, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(6)]
-flag = torch.zeros(B, S, dtype=torch.uint8); flag[:, 1:579] = 1
+flag = torch.zeros(B, S, dtype=torch.uint8); flag[:, 1:min(579, S - 1)] = 1
 flag = flag.reshape(N).cuda()
 lens = torch.full((B,), S, dtype=torch.int32).cuda()
 sc = 128 ** -0.5
