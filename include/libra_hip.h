@@ -233,11 +233,14 @@ int libra_ce_rows_bwd(const void* logits, int64_t ldz, int64_t V, const int64_t*
 int libra_rmsnorm_routed_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* w_lang,
                              const void* w_vis, const uint8_t* flag, const float* rstd, const void* dres, int64_t lddr,
                              void* dx, int64_t lddx, int64_t rows, int64_t D, void* stream);
-/* dw_m[c] += sum_{rows of modality m} dy x rstd  (fp32 [D], deterministic two-stage; dw_vis NULL when unrouted) */
+/* dw_m[c] += sum_{rows of modality m} dy x rstd  (fp32 [D], deterministic two-stage; dw_vis NULL when unrouted).
+ * rows_sel (int32 [n_sel], optional): visit only these rows of the [rows, D] operands - e.g. the vision rows when only the
+ * vision norm weight is trainable (frozen-language pretraining): the other modality's rows are then not read.          */
 size_t libra_rmsnorm_wgrad_workspace_bytes(int64_t rows, int64_t D);
 int libra_rmsnorm_routed_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* rstd,
                                const uint8_t* flag, float* dw_lang, float* dw_vis, void* workspace,
-                               size_t workspace_bytes, int64_t rows, int64_t D, void* stream);
+                               size_t workspace_bytes, int64_t rows, int64_t D, const int32_t* rows_sel, int64_t n_sel,
+                               void* stream);
 /* SwiGLU backward: dgate = dy up s (1 + gate (1 - s)), dup = dy silu(gate)                                   */
 int libra_swiglu_bwd(const void* dy, int64_t lddy, const void* gate, const void* up, int64_t ldgu, void* dgate,
                      void* dup, int64_t ldd, int64_t rows, int64_t I, void* stream);

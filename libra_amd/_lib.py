@@ -54,7 +54,7 @@ SIGNATURES = {
     "libra_ce_rows_bwd": [_P, _I64, _I64, _P, _P, _I64, _F, _F, _P, _I64, _I64, _P],
     "libra_rmsnorm_routed_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_rmsnorm_wgrad_workspace_bytes": [_I64, _I64],
-    "libra_rmsnorm_routed_wgrad": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P],
+    "libra_rmsnorm_routed_wgrad": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P, _I64, _P],
     "libra_swiglu_bwd": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P],
     "libra_rope_bridge_bwd": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64,
                               _I64, _I64, _I64, _P, _I64, _P],
@@ -70,7 +70,7 @@ SIGNATURES = {
     "libra_adamw_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LibraHipError(RuntimeError):

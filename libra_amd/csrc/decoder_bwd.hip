@@ -98,11 +98,14 @@ constexpr int RW_STRIPS = 256;
 __global__ __launch_bounds__(256) void rmsnorm_wgrad_partial_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
                                                                     long ldx, const float* __restrict__ rstd,
                                                                     const unsigned char* __restrict__ flag, long rows, int D,
-                                                                    float* __restrict__ part) {
+                                                                    float* __restrict__ part, const int* __restrict__ sel) {
+    // sel (optional): the rows to visit, `rows` of them - when only one modality's weight is trainable (frozen-language
+    // pretraining) the other modality's rows are not read at all
     const int c8 = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (c8 >= D) return;
     const long per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+    auto row_of = [&](long i) -> long { return sel ? (long)sel[i] : i; };
     float sl[8], sv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sl[e] = 0.f; sv[e] = 0.f; }
@@ -122,16 +125,19 @@ __global__ __launch_bounds__(256) void rmsnorm_wgrad_partial_kernel(const bf16_t
         u32x4 ra[4], rb[4]; float rs[4]; bool vis[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            ra[u] = *(const u32x4*)(dy + (r + u) * lddy + c8);
-            rb[u] = *(const u32x4*)(x + (r + u) * ldx + c8);
-            rs[u] = rstd[r + u];
-            vis[u] = flag && flag[r + u];
+            const long rr = row_of(r + u);
+            ra[u] = *(const u32x4*)(dy + rr * lddy + c8);
+            rb[u] = *(const u32x4*)(x + rr * ldx + c8);
+            rs[u] = rstd[rr];
+            vis[u] = flag && flag[rr];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) add_row(ra[u], rb[u], rs[u], vis[u]);
     }
-    for (; r < r1; ++r)
-        add_row(*(const u32x4*)(dy + r * lddy + c8), *(const u32x4*)(x + r * ldx + c8), rstd[r], flag && flag[r]);
+    for (; r < r1; ++r) {
+        const long rr = row_of(r);
+        add_row(*(const u32x4*)(dy + rr * lddy + c8), *(const u32x4*)(x + rr * ldx + c8), rstd[rr], flag && flag[rr]);
+    }
     float* d0 = part + ((long)blockIdx.y * 2) * D + c8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { d0[e] = sl[e]; d0[D + e] = sv[e]; }
@@ -357,15 +363,20 @@ extern "C" size_t libra_rmsnorm_wgrad_workspace_bytes(int64_t rows, int64_t D) {
 
 extern "C" int libra_rmsnorm_routed_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* rstd,
                                           const uint8_t* flag, float* dw_lang, float* dw_vis, void* workspace,
-                                          size_t workspace_bytes, int64_t rows, int64_t D, void* stream) {
-    if (rows <= 0) return LIBRA_OK;
+                                          size_t workspace_bytes, int64_t rows, int64_t D, const int32_t* rows_sel,
+                                          int64_t n_sel, void* stream) {
+    if (rows_sel) {                                                   // visit only these rows (all inside [0, rows): caller's contract)
+        if (n_sel < 0 || n_sel > rows) return LIBRA_ERR_SHAPE;
+        rows = n_sel;
+    }
+    if (rows <= 0) return LIBRA_OK;                                   // nothing to add
     if (D <= 0 || (D % 8) || lddy < D || ldx < D || (lddy % 8) || (ldx % 8)) return LIBRA_ERR_SHAPE;
     if (!dy || !x || !rstd || !workspace || !al16(dy) || !al16(x) || !al16(workspace)) return LIBRA_ERR_ALIGN;
     if (workspace_bytes < libra_rmsnorm_wgrad_workspace_bytes(rows, D)) return LIBRA_ERR_ALIGN;
     const int strips = (int)(rows < RW_STRIPS ? rows : RW_STRIPS);
     dim3 grid((unsigned)((D + 2047) / 2048), (unsigned)strips);
     hipLaunchKernelGGL(rmsnorm_wgrad_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)lddy,
-                       (const bf16_t*)x, (long)ldx, rstd, flag, (long)rows, (int)D, (float*)workspace);
+                       (const bf16_t*)x, (long)ldx, rstd, flag, (long)rows, (int)D, (float*)workspace, (const int*)rows_sel);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     hipLaunchKernelGGL(rmsnorm_wgrad_final_kernel, dim3((unsigned)((D + 31) / 32), 2), dim3(1024), 0, (hipStream_t)stream,
                        (const float*)workspace, strips, (int)D, dw_lang, dw_vis);

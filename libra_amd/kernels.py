@@ -657,14 +657,19 @@ def rmsnorm_routed_bwd(dy, x, w_lang, w_vis, flag, rstd, *, dres=None, out=None)
     return dx
 
 
-def rmsnorm_routed_wgrad(dy, x, rstd, flag, dw_lang, dw_vis):
-    """dw_lang / dw_vis (fp32 [D], either may be None) += per-modality sums of dy * x * rstd."""
+def rmsnorm_routed_wgrad(dy, x, rstd, flag, dw_lang, dw_vis, *, rows_sel=None):
+    """dw_lang / dw_vis (fp32 [D], either may be None) += per-modality sums of dy * x * rstd.
+    rows_sel (int32 [n], optional): only these rows are visited (e.g. the vision rows when only the vision weight is wanted)."""
     rows, D = x.shape
+    if rows_sel is not None and (rows_sel.dtype != torch.int32 or not rows_sel.is_contiguous()):
+        raise ValueError("rmsnorm_routed_wgrad: rows_sel must be a contiguous int32 index tensor")
+    if rows_sel is not None and rows_sel.numel() == 0:
+        return                                               # an empty selection adds nothing (an empty tensor has no pointer to pass)
     nbytes = _lib.lib().libra_rmsnorm_wgrad_workspace_bytes(rows, D)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
     rc = _lib.lib().libra_rmsnorm_routed_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), rstd.data_ptr(),
                                                _ptr(flag), _ptr(dw_lang), _ptr(dw_vis), ws.data_ptr(), nbytes, rows, D,
-                                               _stream())
+                                               _ptr(rows_sel), rows_sel.numel() if rows_sel is not None else 0, _stream())
     _lib.check(rc, "rmsnorm_routed_wgrad")
 
 

@@ -65,6 +65,34 @@ def test_rmsnorm_routed(K, rows, D):
                        lambda t: LO.rms_norm(t, wv.float().cpu(), 1e-6)), rel=8e-3, what="routed rmsnorm vs fp32")
 
 
+def test_rmsnorm_routed_wgrad_full_and_row_subset(K):
+    """Per-modality weight gradient dw_m = sum_{rows of m} dy * x * rstd: all rows, and with only one modality's rows visited
+    (`rows_sel`, the frozen-language case) - same sums, nothing added to the other output."""
+    rows, D = 1000, 4096
+    dy, x = rnd(rows, D, seed=11), rnd(rows, D, seed=12)
+    rstd = (torch.rand(rows, generator=torch.Generator().manual_seed(13)) + 0.5).cuda()
+    flag = _flags(rows, 5, "random").cuda()
+    t = dy.float() * x.float() * rstd[:, None]
+    vis = flag.bool()
+    ref_l, ref_v = t[~vis].sum(0), t[vis].sum(0)
+    dl, dv = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    K.rmsnorm_routed_wgrad(dy, x, rstd, flag, dl, dv)
+    close(dl, ref_l, rel=1e-4, what="dw_lang"); close(dv, ref_v, rel=1e-4, what="dw_vis")
+    vis_idx = torch.nonzero(vis).squeeze(1).to(torch.int32)
+    dl2, dv2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")             # (the kernel ADDS onto its outputs)
+    K.rmsnorm_routed_wgrad(dy, x, rstd, flag, dl2, dv2, rows_sel=vis_idx)
+    close(dv2, ref_v, rel=1e-4, what="dw_vis (vision rows only)")
+    assert float(dl2.abs().max()) == 0.0
+    lang_idx = torch.nonzero(~vis).squeeze(1).to(torch.int32)
+    dl3, dv3 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    K.rmsnorm_routed_wgrad(dy, x, rstd, flag, dl3, dv3, rows_sel=lang_idx)
+    close(dl3, ref_l, rel=1e-4, what="dw_lang (text rows only)")
+    assert float(dv3.abs().max()) == 0.0
+    dl4, dv4 = torch.full((D,), 3.0, device="cuda"), torch.full((D,), 3.0, device="cuda")   # an empty selection adds nothing
+    K.rmsnorm_routed_wgrad(dy, x, rstd, flag, dl4, dv4, rows_sel=vis_idx[:0].contiguous())
+    assert float((dl4 - 3.0).abs().max()) == 0.0 and float((dv4 - 3.0).abs().max()) == 0.0
+
+
 def _attn_ref(q, ks, kc, vs, vc, flag, lens, B, S, H, scale):
     d = 128
     def hd(t):
