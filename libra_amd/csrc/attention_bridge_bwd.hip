@@ -48,15 +48,6 @@ struct BridgeBwdArgs {
 // cycles in the round-1 PMC profile.]
 __device__ __forceinline__ int tswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-__device__ __forceinline__ void stage_t32(const bf16_t* __restrict__ base, long ld, int row0, int nrows, char* dst,
-                                          int wave, int lane, int nwaves) {
-    for (int pc = wave; pc < 8; pc += nwaves) {
-        const int r = pc * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ tswz(r);
-        int row = row0 + r; row = row < nrows ? row : nrows - 1;
-        glds16(base + (long)row * ld + c * 8, dst + pc * 1024);
-    }
-}
 // [64 rows][128 d] image, 16 pieces of 1 KiB over 8 waves; base is wave-uniform, ld_b = row stride in bytes
 __device__ __forceinline__ void stage_t64(const bf16_t* __restrict__ base, unsigned ld_b, int row0, int nrows, char* dst,
                                           int wave, int lane) {
@@ -69,32 +60,6 @@ __device__ __forceinline__ void stage_t64(const bf16_t* __restrict__ base, unsig
         glds16_off(base, (unsigned)row * ld_b + (unsigned)(c * 16), dst + pc * 1024);
     }
 }
-// 16-byte row read (8 consecutive d of one row) from the reduction-major image
-__device__ __forceinline__ bf16x8 nread_t(const char* tile, int row, int chunk) {
-    return *(const bf16x8*)(tile + row * 256 + ((chunk ^ tswz(row)) << 4));
-}
-// transpose read: A-operand fragment X^T[d = 32*dt + l31][rows 16*sx + 4*fk + {0..3, 8..11}]
-__device__ __forceinline__ bf16x8 tread_t(const char* tile, int lane, int dt, int sx) {
-    const int pp = lane & 15, g16 = (lane >> 4) & 1, fk = lane >> 5;
-    const int r1 = 16 * sx + 4 * fk + (pp >> 2);
-    const int chunk = dt * 4 + 2 * g16 + ((pp & 3) >> 1);
-    const char* a = tile + r1 * 256 + ((pp & 1) << 3);
-    union { bf16x8 v; s16x4 h2[2]; } u;
-    u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + ((chunk ^ tswz(r1)) << 4)));
-    u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048 + ((chunk ^ tswz(r1 + 8)) << 4)));
-    return u.v;
-}
-__device__ __forceinline__ void split_pack(const f32x16& a, unsigned crossbits, int sx, bf16x8& same, bf16x8& cross) {
-    union { bf16x8 v; unsigned u[4]; } ps, pc;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r0 = 8 * sx + 2 * j, r1 = r0 + 1;
-        const bool c0 = (crossbits >> r0) & 1u, c1 = (crossbits >> r1) & 1u;
-        ps.u[j] = pack2bf(c0 ? 0.f : a[r0], c1 ? 0.f : a[r1]);
-        pc.u[j] = pack2bf(c0 ? a[r0] : 0.f, c1 ? a[r1] : 0.f);
-    }
-    same = ps.v; cross = pc.v;
-}
 
 // ================================================================================================
 // dQ pass: 8 waves x 32 queries per workgroup, 64-key tiles (two 32-key halves per barrier), per variant one K image
@@ -104,7 +69,6 @@ constexpr int DQ_STAGE_B = 2 * DQ_VAR;        // same + cross
 constexpr int DQ_LDS_B = 2 * DQ_STAGE_B + 1024;
 constexpr int DQ_BQ = 256;
 
-template <bool CA>        // CA: lane-constant LDS addressing, see bridge_attn_bwd_dkv_kernel
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* kmask = (unsigned*)(smem + 2 * DQ_STAGE_B);
@@ -184,9 +148,8 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
         }
     };
     stage(0, 0);
-    int lane_o = lane;                                              // (see the forward kernel: per-tile recomputed LDS offsets)
     int xr = 0, xt0 = 0, xt1 = 0;
-    if constexpr (CA) {
+    {
         const int pp = lane & 15, g16 = (lane >> 4) & 1;
         const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
         xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
@@ -202,20 +165,15 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
         if (!active) continue;
         const int kv0 = kt * 64;
         if (kv0 > q0w + 31) continue;
-        asm volatile("" : "+v"(lane_o));
-        if constexpr (CA) asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1));
-        const int l31o = lane_o & 31, fko = lane_o >> 5;
+        asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1));
         auto rd_row = [&](const char* tile, int ks) -> bf16x8 {
-            if constexpr (CA) return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
-            else return nread_t(tile, l31o, 2 * ks + fko);
+            return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
         };
         auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
-            if constexpr (CA) {
-                union { bf16x8 v; s16x4 h2[2]; } u;
-                u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
-                u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
-                return u.v;
-            } else return tread_t(tile, lane_o, dt, sx);
+            union { bf16x8 v; s16x4 h2[2]; } u;
+            u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
+            u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
+            return u.v;
         };
 #pragma unroll 1
         for (int kh = 0; kh < 2; ++kh) {
@@ -344,15 +302,9 @@ __device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, uns
         glds16_off(base, (unsigned)key * ld_b + (unsigned)(sub * 128 + c * 16), dst + pc * 1024);
     }
 }
-// fragment (row, 8 consecutive d of k-step ks) of a row image whose sub-tiles are `sub_bytes` apart
-__device__ __forceinline__ bf16x8 nfrag(const char* tile, int row, int ks, int fk, int sub_bytes) {
-    const int sub = ks >> 2, c = (2 * (ks & 3) + fk) ^ ((row >> 1) & 7);
-    return *(const bf16x8*)(tile + sub * sub_bytes + row * 128 + (c << 4));
-}
 
-// CA = lane-constant LDS addressing: every fragment address is a per-lane constant XOR a compile-time constant (one VALU op per
-// read) instead of the swizzle arithmetic rebuilt per read (the round-1 PMC profile counted 12.4 VALU per MFMA in this kernel)
-template <bool CA>
+// Lane-constant LDS addressing: every fragment address is a per-lane constant XOR a compile-time constant (one VALU op per
+// read) instead of the swizzle arithmetic rebuilt per read (the round-1 PMC profile counted 12.4 VALU per MFMA in this kernel).
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* res = smem;                                            // Ks, Kc, Vs, Vc
@@ -411,11 +363,10 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     if (it0 < nqt) stage_q(0, it0);
 
     const char* rK = res + kw * 32 * 128;                         // this wave's 32 key rows inside each 64-row sub-tile
-    int lane_o = lane;
-    // lane constants of the CA variant: row image (xr), resident image (xv), transposed reads (xt0 / xt1) - each read is then
+    // lane constants: row image (xr), resident image (xv), transposed reads (xt0 / xt1) - each read is then
     // `constant ^ (k-step or d-tile bits)`
     int xr = 0, xv = 0, xt0 = 0, xt1 = 0;
-    if constexpr (CA) {
+    {
         const int pp = lane & 15, g16 = (lane >> 4) & 1;
         const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
         xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
@@ -430,24 +381,18 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         if (it + 1 < nqt) stage_q(cur ^ 1, it + 1);
         const int q0 = it * 64 + qh * 32;
         if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
-        asm volatile("" : "+v"(lane_o));
-        if constexpr (CA) asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
-        const int l31o = lane_o & 31, fko = lane_o >> 5;
+        asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
         auto rd_row = [&](const char* tile, int ks) -> bf16x8 {
-            if constexpr (CA) return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
-            else return nread_t(tile, l31o, 2 * ks + fko);
+            return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
         };
         auto rd_res = [&](const char* tile, int ks) -> bf16x8 {
-            if constexpr (CA) return *(const bf16x8*)(tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5)));
-            else return nfrag(tile, l31o, ks, fko, 8192);
+            return *(const bf16x8*)(tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5)));
         };
         auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
-            if constexpr (CA) {
-                union { bf16x8 v; s16x4 h2[2]; } u;
-                u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
-                u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
-                return u.v;
-            } else return tread_t(tile, lane_o, dt, sx);
+            union { bf16x8 v; s16x4 h2[2]; } u;
+            u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
+            u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
+            return u.v;
         };
         const char* sq = qd + cur * QD_STAGE + qh * 8192;         // this wave's 32 query rows of the Q image (dO at +16384)
         const float* sL = (const float*)(qd + cur * QD_STAGE + 32768) + qh * 32;
@@ -666,20 +611,19 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.scale = scale; a.sl2 = scale * LOG2E;
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
     long nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    // (CA = lane-constant LDS addressing; the <false> instantiations are the round-1 kernels, kept for A/B builds only.
-    //  Other dK/dV structures that were built and measured this round: profiles/r02_attn_bwd_anatomy.md)
-    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel<true>, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
+    // (other dK/dV structures that were built and measured in round 2: profiles/r02_attn_bwd_anatomy.md)
+    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<true>, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
