@@ -118,14 +118,16 @@ class PackedOperands:
             self.layers.append(L)
         self.refresh(sd, force=True)
 
-    def refresh(self, sd: Dict[str, torch.Tensor], force: bool = False) -> int:
-        """Re-copy stale slices; returns the number of slices copied."""
+    def refresh(self, sd: Dict[str, torch.Tensor], force: bool = False, volatile: bool = True) -> int:
+        """Re-copy stale slices; returns the number of slices copied.  volatile=False: trust the (data_ptr, _version) key also for
+        trainable parameters - only for calls between which no optimizer can have run (the decode steps of ONE generation,
+        whose prefill did the full check: re-copying 10 GB of operands per generated token made a step 15 ms instead of 8.7)."""
         dsts, srcs = [], []
         with torch.no_grad():
             for k, (dst, name, tr) in enumerate(self._slices):
                 p = sd[name]
                 key = (p.data_ptr(), p._version)
-                if force or p.requires_grad or self._keys.get(k) != key:
+                if force or (volatile and p.requires_grad) or self._keys.get(k) != key:
                     src = p.detach()
                     dsts.append(dst)
                     srcs.append(src.t() if tr else src)
@@ -260,6 +262,7 @@ class KVCache:
         self.start: Optional[torch.Tensor] = None          # int32 [B] first valid slot of each sequence (left-padded prompts)
         self.graphs: Dict[tuple, tuple] = {}               # routing pattern of a decode step -> (hipGraph, static buffers, outputs)
         self.pack_key = None                               # version of the packed weights the graphs were captured against
+        self.sd = None                                     # the owner model's parameter dict at prefill (reused by its decode steps)
         self.run2d: Optional[torch.Tensor] = None          # use_2d_rope: int64 [B] running position (get_2d_position_ids' cumsum) at the last token
         self.hid: Optional[torch.Tensor] = None            # vision_prediction_mode="2d": final hidden state of every cached token [B, capacity, H]
 

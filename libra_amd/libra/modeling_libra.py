@@ -210,7 +210,7 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
     def get_output_embeddings(self):
         return self.lm_head
 
-    def _refresh_packed(self, sd):
+    def _refresh_packed(self, sd, volatile: bool = True):
         """Fused operand copies ([q;k;v|bridge A], [gate;up], bridge B / B^T): built once, then refreshed in place - always
         for trainable parameters (optimizers that write through `.data`, e.g. DeepSpeed ZeRO, bump no version counter),
         by (data_ptr, _version) for frozen ones.  See DE.PackedOperands."""
@@ -218,7 +218,7 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         if self._packed is None or self._packed.device != dev:
             self._packed = DE.PackedOperands(sd, self._dims)
         else:
-            self._packed.refresh(sd)
+            self._packed.refresh(sd, volatile=volatile)
         return self._packed
 
     def invalidate_packed(self):
@@ -226,9 +226,9 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         `.data`; trainable ones are refreshed every forward anyway)."""
         self._packed = None
 
-    def _state(self):
+    def _state(self, volatile: bool = True):
         sd = dict(self.named_parameters())
-        return sd, self._refresh_packed(sd)
+        return sd, self._refresh_packed(sd, volatile)
 
     def _ptr_key(self):
         return tuple(p.data_ptr() for p in self.parameters())
@@ -287,7 +287,14 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         The KV cache holds `max_cache_len` tokens (default max_position_embeddings; generate() passes its max_length)."""
         Q, B, S = input_ids.shape
         dims = self._dims
-        sd, packed = self._state()
+        # A decode step continues the generation its prefill started: the operand copies were checked and refreshed there, and
+        # as long as no parameter storage moved since (pack_key) the step reuses them and the parameter dict as they are - walking
+        # ~800 parameters and ~1000 operand slices in Python per generated token costs more than a millisecond of an 8 ms step.
+        ptr_key = self._ptr_key()
+        if isinstance(past, DE.KVCache) and past.sd is not None and self._packed is not None and past.pack_key == ptr_key:
+            sd, packed = past.sd, self._packed
+        else:
+            sd, packed = self._state(volatile=past is None)
         dev = input_ids.device
         if past is None:
             if attention_mask is None:
@@ -303,7 +310,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                     raise NotImplementedError("prefill positions other than attention_mask.cumsum(-1) - 1")
             cap = max(int(max_cache_len), S + 1) if max_cache_len else max(dims.max_pos, S + 1)
             cache = DE.KVCache(dims.layers, B, cap, dims.hidden, dev)
-            cache.pack_key = self._ptr_key()
+            cache.pack_key = ptr_key
+            cache.sd = sd
             out = DE.forward(sd, packed, dims, input_ids, attention_mask, vision_indices, signal, None, cache=cache)
         else:
             if not isinstance(past, DE.KVCache):
@@ -313,9 +321,9 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
             cache = past
             if cache.length >= cache.capacity:
                 raise ValueError(f"the KV cache is full ({cache.capacity} tokens): pass a larger max_cache_len / max_length")
-            if getattr(cache, "pack_key", None) != self._ptr_key():     # parameter storage moved since the graphs were captured
-                cache.graphs.clear()                                     # (values may change freely: operands are refreshed in place)
-                cache.pack_key = self._ptr_key()
+            if cache.pack_key != ptr_key:                # parameter storage moved since the graphs were captured
+                cache.graphs.clear()                     # (values may change freely: operands are refreshed in place)
+                cache.pack_key, cache.sd = ptr_key, sd
             if dims.rope_2d:
                 if position_ids is not None:                                            # [B, 2, 1] (:1199-1201) -> [B, 2]
                     position_ids = position_ids.reshape(B, 2)
