@@ -72,10 +72,12 @@ class CLIPVisionTower(nn.Module):
         return torch.cat(sel, dim=-1)
 
     def reshape_to_square(self, feats):
-        B, N, C = feats.shape
-        H = W = int(math.sqrt(N))
-        assert H * W == N
-        return feats.view(B, H, W, C).permute(0, 3, 1, 2)
+        """[B, hw, C] -> [B, C, h, w] for a square patch grid (the reference's helper of the same name, clip_encoder.py:47-51)."""
+        batch, tokens, channels = feats.shape
+        side = math.isqrt(tokens)
+        if side * side != tokens:
+            raise AssertionError(f"{tokens} patch tokens do not form a square grid")
+        return feats.view(batch, side, side, channels).permute(0, 3, 1, 2)
 
     def forward_flat(self, images):
         """-> [B, hw, C_total] contiguous (the ``encoder_feat`` layout of image_tokenizer.py:93)."""
@@ -95,26 +97,19 @@ class CLIPVisionTower(nn.Module):
         f = self.forward_flat(images)
         return self.reshape_to_square(f) if square_output else f
 
-    @property
-    def dummy_feature(self):
-        return torch.zeros(1, self.hidden_size, device=self.device, dtype=self.dtype)
-
-    @property
-    def dtype(self):
-        return self.vision_tower.dtype
-
-    @property
-    def device(self):
-        return self.vision_tower.device
+    # ---- read-only surface of the reference class (clip_encoder.py:72-96): everything is answered by the wrapped tower ----
+    dtype = property(lambda self: self.vision_tower.dtype)
+    device = property(lambda self: self.vision_tower.device)
+    hidden_size = property(lambda self: self.config.hidden_size)
+    num_patches = property(lambda self: (self.config.image_size // self.config.patch_size) ** 2)
 
     @property
     def config(self):
-        return self.vision_tower.config if self.is_loaded else self.cfg_only
+        """The tower's config once it is loaded, before that the one read from `vision_tower` at construction (delay_load)."""
+        if self.is_loaded:
+            return self.vision_tower.config
+        return self.cfg_only
 
     @property
-    def hidden_size(self):
-        return self.config.hidden_size
-
-    @property
-    def num_patches(self):
-        return (self.config.image_size // self.config.patch_size) ** 2
+    def dummy_feature(self):
+        return torch.zeros((1, self.hidden_size), dtype=self.dtype, device=self.device)
