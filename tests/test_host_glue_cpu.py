@@ -251,3 +251,35 @@ def test_f4_host_helpers_match_oracle_and_reference_fixture():
     keep = flag.clone()
     keep[:, cut:] = False
     assert torch.equal(torch.cat([hx_c[a_c.long()], hx_c[b_c.long()]], 1), ref[keep[flag]])
+
+
+def test_packed_operands_refresh_policy():
+    """decoder_engine.PackedOperands: trainable parameters are re-copied on every (volatile) refresh - optimizers that write
+    through `.data` bump neither `_version` nor `data_ptr` -, frozen ones by their (data_ptr, _version) key, and a
+    non-volatile refresh (the decode steps of one generation) trusts the key for both."""
+    from libra_amd import decoder_engine as DE
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    sd = {k[2:]: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in t.items() if k.startswith("w.")}
+    d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
+                   heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
+                   codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
+                   signal=c["contiguous_signal_size"], rank=c["bridge_rank"], down_ratio=c["vision_down_ratio"])
+    po = DE.PackedOperands(sd, d)
+    n_slices = len(po._slices)
+    assert po.refresh(sd) == n_slices                                   # everything is trainable: all re-copied
+    assert po.refresh(sd, volatile=False) == 0                          # ... unless the caller vouches that nothing ran in between
+    q = "model.layers.0.self_attn.q_proj.weight"
+    sd[q].data.add_(1.0)                                                # an optimizer writing through .data: invisible to the key
+    assert sd[q]._version == 0 and po.refresh(sd, volatile=False) == 0
+    wqkv = po[0]["wqkv_ab"]
+    H = c["hidden_size"]
+    assert not torch.equal(wqkv[:H, :H], sd[q].detach())                # stale by construction ...
+    assert po.refresh(sd) == n_slices and torch.equal(wqkv[:H, :H], sd[q].detach())     # ... and picked up by the volatile refresh
+    for p in sd.values():
+        p.requires_grad_(False)
+    assert po.refresh(sd) == 0                                          # frozen and unchanged: nothing to do
+    with torch.no_grad():
+        sd[q].add_(1.0)                                                 # an in-place op bumps the version: noticed
+    assert po.refresh(sd) >= 1 and torch.equal(wqkv[:H, :H], sd[q].detach())
+    assert po.refresh(sd, force=True) == n_slices
