@@ -283,3 +283,26 @@ def test_packed_operands_refresh_policy():
         sd[q].add_(1.0)                                                 # an in-place op bumps the version: noticed
     assert po.refresh(sd) >= 1 and torch.equal(wqkv[:H, :H], sd[q].detach())
     assert po.refresh(sd, force=True) == n_slices
+
+
+def test_gradient_emission_groups_are_rank_independent_and_cover_the_2d_placeholder():
+    """decoder_engine.emit_group / want_groups: the backward-order groups the data-parallel buckets are laid out by - heads and final
+    norms first, decoder layers last-to-first, the embedding stage last; `vision_hidden_placeholder` gets a gradient (group 0) only
+    in the 2d prediction mode."""
+    from libra_amd import decoder_engine as DE
+    L = 3
+    names = ["lm_head.weight", "vision_lm_head.heads.1.weight", "model.norm.weight", "model.vision_norm.weight",
+             "model.layers.0.mlp.vision_down_proj.weight_B", "model.layers.2.self_attn.q_proj.weight",
+             "model.embed_tokens.weight", "model.vision_embed_tokens.0.weight", "model.vision_signal_norm.weight",
+             "vision_hidden_placeholder"]
+    g = {n: DE.emit_group(n, L) for n in names}
+    assert g["lm_head.weight"] == g["vision_lm_head.heads.1.weight"] == g["model.norm.weight"] == g["vision_hidden_placeholder"] == 0
+    assert g["model.layers.2.self_attn.q_proj.weight"] == 1 and g["model.layers.0.mlp.vision_down_proj.weight_B"] == 3
+    assert g["model.embed_tokens.weight"] == g["model.vision_embed_tokens.0.weight"] == g["model.vision_signal_norm.weight"] == L + 1
+    groups = DE.want_groups(set(names), L)
+    assert len(groups) == L + 2 and "vision_hidden_placeholder" not in sum(groups, [])
+    assert groups == DE.want_groups(set(reversed(names)), L)                       # order does not depend on the caller's set order
+    assert "vision_hidden_placeholder" in DE.want_groups(set(names), L, skip=())[0]
+    d = DE.DecDims(hidden=256, inter=512, layers=2, heads=2, vocab=96, vision_vocab=18, codebooks=2, max_vision_len=6, signal=64,
+                   max_pos=64, rope_2d=True, res=2)
+    assert DE.rope_rows(d, 40) == 64 and DE.rope_rows(d, 100) == 104               # 2d positions run at most res + 2 ahead
