@@ -42,6 +42,19 @@ def test_row_kernels_argument_validation(L):
     assert L.libra_rope_bridge_bwd(*args2, 32, None, 1, None) == ERR_ALIGN
 
 
+def test_rmsnorm_wgrad_row_selection_validation(L):
+    # dy, lddy, x, ldx, rstd, flag, dw_lang, dw_vis, workspace, workspace_bytes, rows, D, rows_sel, n_sel, stream
+    ws = L.libra_rmsnorm_wgrad_workspace_bytes(100, 4096)
+    base = [FAKE, 4096, FAKE, 4096, FAKE, FAKE, FAKE, FAKE, FAKE, ws, 100, 4096]
+    assert L.libra_rmsnorm_routed_wgrad(*base, FAKE, 101, None) == ERR_SHAPE       # more selected rows than rows
+    assert L.libra_rmsnorm_routed_wgrad(*base, FAKE, -1, None) == ERR_SHAPE
+    assert L.libra_rmsnorm_routed_wgrad(*base, FAKE, 0, None) == OK                 # an empty selection adds nothing, launches nothing
+    small = list(base); small[9] = ws - 1
+    assert L.libra_rmsnorm_routed_wgrad(*small, None, 0, None) == ERR_ALIGN         # workspace too small
+    odd = list(base); odd[11] = 4100
+    assert L.libra_rmsnorm_routed_wgrad(*odd, None, 0, None) == ERR_SHAPE           # D % 8
+
+
 def test_generation_entry_points_argument_validation(L):
     # rope with explicit positions: the position operand is mandatory
     args = [FAKE, 3 * 256, FAKE, 64, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, 64, FAKE, FAKE, 256, 4]
