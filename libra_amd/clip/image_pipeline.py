@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import functools
 import math
-from typing import List, Optional, Sequence, Tuple, Union
+from typing import Sequence, Tuple, Union
 
 import numpy as np
 import torch

@@ -27,7 +27,7 @@ Works unchanged on the gloo backend with CPU tensors (world_size-2 tests); the o
 from __future__ import annotations
 
 import contextlib
-from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist

@@ -7,7 +7,6 @@ arithmetic hot path).  The text half of the reference tokenizer (sentencepiece L
 is outside the hot path: callers hand in the text ids with every ``<img_ph>`` already expanded to
 ``max_vision_token_length`` placeholder slots, exactly what ``self.text_tokenizer(texts, ...)`` returns upstream (:245).
 """
-import json
 import logging
 import os
 from typing import Optional, Sequence

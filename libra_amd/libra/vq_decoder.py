@@ -15,7 +15,7 @@ The 3x3 operand is materialised (9x the activation bytes): HBM-bound at the top 
 from __future__ import annotations
 
 import math
-from typing import List, Optional
+from typing import Optional
 
 import torch
 from torch import nn
