@@ -306,9 +306,18 @@ int libra_resample_v_u8_norm(const uint8_t* tmp, int64_t tmp_w, int64_t row0, co
  * Trainer / DeepSpeed fused Adam with bf16 + fp32 master weights, libra/configs/libra_pretrain.yaml:83-91,
  * libra/configs/deepspeed_configs/ZeRO-2.json).  g = grad_scale * grad;  master -= lr*wd*master;
  * m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  master -= lr/bias_corr1 * m / (sqrt(v)/sqrt(bias_corr2) + eps);
- * param = bf16(master).  master / m / v fp32, grad / param bf16; all pointers 16-byte aligned.  One HBM pass (28 B/element). */
+ * param = bf16(master).  master / m / v fp32, grad / param bf16; all pointers 16-byte aligned.  One HBM pass (28 B/element).
+ * grad_norm_sq (device scalar or NULL) + max_grad_norm: global-norm gradient clipping as torch.nn.utils.clip_grad_norm_
+ * (HF Trainer `max_grad_norm: 1.0`, libra_pretrain.yaml / deepspeed_configs/ZeRO-2.json "gradient_clipping": "auto"):
+ * grad_scale is further multiplied by min(1, max_grad_norm / (sqrt(*grad_norm_sq) + 1e-6)), read on the device. */
 int libra_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+                     const float* grad_norm_sq, float max_grad_norm, void* stream);
+
+/* out[0] (+)= sum of squares of the bf16 range x[0..n) - the gradient-norm pass of the clipping above.  Deterministic
+ * (fixed partition, fixed fold order); workspace >= libra_sumsq_workspace_bytes(n).  HBM-bound: 2 B / element. */
+size_t libra_sumsq_workspace_bytes(int64_t n);
+int libra_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
                      void* stream);
 
 #ifdef __cplusplus

@@ -41,7 +41,8 @@ def _taps(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray]:
     scale = n_in / n_out
     fs = scale if scale > 1.0 else 1.0
     support = 2.0 * fs
-    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / fs                   # Pillow's precompute_coeffs multiplies by the reciprocal (a division can differ by one ulp
+    ksize = int(math.ceil(support)) * 2 + 1          # for fs != 1 and, rarely, flip a 22-bit fixed-point coefficient)
     bounds = np.zeros((n_out, 2), dtype=np.int32)
     coeffs = np.zeros((n_out, ksize), dtype=np.int32)
     for i in range(n_out):
@@ -51,7 +52,7 @@ def _taps(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray]:
         hi = int(center + support + 0.5)
         hi = hi if hi < n_in else n_in
         n = hi - lo
-        w = [_cubic((j + lo - center + 0.5) / fs) for j in range(n)]
+        w = [_cubic((j + lo - center + 0.5) * ss) for j in range(n)]
         tot = sum(w)
         for j in range(n):
             v = w[j] / tot if tot != 0.0 else w[j]

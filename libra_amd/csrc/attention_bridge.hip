@@ -258,7 +258,9 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
         tmax = half_swap_max(tmax * p.sl2);
         const float m_new = fmaxf(m_run, tmax);
         if (__any(m_new > m_run + DEFER_THR)) {                     // wave-uniform; the first tile always lands here
-            rescale(__builtin_amdgcn_exp2f(m_run - m_new));
+            // a row that has seen no key yet (left padding: a whole tile masked for the real rows while the pad rows of the
+            // same wave keep theirs) has m_run = m_new = -inf: exp2(-inf - -inf) = NaN would poison o and l for good
+            rescale(m_new == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new));
             m_run = m_new;
         }
         const float nm = m_run == -INFINITY ? 0.f : -m_run;         // (a row with no visible key yet stays at exactly 0)

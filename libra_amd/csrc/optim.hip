@@ -10,6 +10,8 @@ namespace libra {
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2, gscale;
+    const float* gnorm_sq;     // device scalar: squared global gradient norm (null = no clipping)
+    float max_norm;
 };
 
 __device__ __forceinline__ void adam1(float g, float& p, float& m, float& v, const AdamArgs& a) {
@@ -27,6 +29,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
                                                     AdamArgs a) {
     const long i8 = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i8 >= n) return;
+    if (a.gnorm_sq) {
+        // torch.nn.utils.clip_grad_norm_ (HF Trainer `max_grad_norm`, DeepSpeed `gradient_clipping`): coef = max / (norm + 1e-6),
+        // applied only when < 1.  The norm is a device scalar: no host read between the backward and the update.
+        const float coef = a.max_norm / (sqrtf(*a.gnorm_sq) + 1e-6f);
+        a.gscale *= coef < 1.f ? coef : 1.f;
+    }
     if (i8 + 8 <= n) {
         const u32x4 gq = *(const u32x4*)(grad + i8);
         f32x4 p0 = *(const f32x4*)(master + i8), p1 = *(const f32x4*)(master + i8 + 4);
@@ -56,18 +64,75 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     }
 }
 
+// Sum of squares of a bf16 range, deterministic: per-block partials (fixed partition, fixed in-block order), then ONE block
+// folds the partials in index order into out[0] (+= when accumulate).  HBM-bound: 2 B / element.
+constexpr int SUMSQ_ELEMS_PER_BLOCK = 256 * 8 * 8;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const bf16_t* __restrict__ x, long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * SUMSQ_ELEMS_PER_BLOCK;
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long i8 = base + ((long)it * 256 + threadIdx.x) * 8;
+        if (i8 + 8 <= n) {
+            float g[8];
+            unpack8(*(const u32x4*)(x + i8), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += g[e] * g[e];
+        } else {
+            for (long i = i8; i < n; ++i) { const float g = bf2f(x[i]); acc += g * g; }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, long nblk, float* __restrict__ out,
+                                                          int accumulate) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < nblk; i += 256) acc += part[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
 }  // namespace libra
 
 using namespace libra;
 
+extern "C" size_t libra_sumsq_workspace_bytes(int64_t n) {
+    return n <= 0 ? 0 : (size_t)((n + SUMSQ_ELEMS_PER_BLOCK - 1) / SUMSQ_ELEMS_PER_BLOCK) * sizeof(float);
+}
+
+extern "C" int libra_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
+                                void* stream) {
+    if (!out) return LIBRA_ERR_ALIGN;
+    if (n < 0) return LIBRA_ERR_SHAPE;
+    const long nblk = n > 0 ? (n + SUMSQ_ELEMS_PER_BLOCK - 1) / SUMSQ_ELEMS_PER_BLOCK : 0;
+    if (n > 0 && (!x || ((uintptr_t)x & 15) || !workspace || workspace_bytes < (size_t)nblk * sizeof(float))) return LIBRA_ERR_ALIGN;
+    if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
+    if (nblk)
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)n,
+                           workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nblk, out, accumulate);
+    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+}
+
 extern "C" int libra_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                                float grad_scale, void* stream) {
+                                float grad_scale, const float* grad_norm_sq, float max_grad_norm, void* stream) {
     if (n <= 0) return LIBRA_OK;
+    if (grad_norm_sq && !(max_grad_norm > 0.f)) return LIBRA_ERR_SHAPE;
     if (!master || !m || !v || !grad || !param) return LIBRA_ERR_ALIGN;
     if ((((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad | (uintptr_t)param) & 15)) return LIBRA_ERR_ALIGN;
     if (!(bias_corr1 > 0.f) || !(bias_corr2 > 0.f)) return LIBRA_ERR_SHAPE;
-    AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f / bias_corr1, 1.f / sqrtf(bias_corr2), grad_scale};
+    AdamArgs a{lr, beta1, beta2, eps, weight_decay, 1.f / bias_corr1, 1.f / sqrtf(bias_corr2), grad_scale, grad_norm_sq, max_grad_norm};
     const long blocks = (n + 2047) / 2048;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, master, m, v,
                        (const bf16_t*)grad, (bf16_t*)param, (long)n, a);

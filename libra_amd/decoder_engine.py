@@ -116,6 +116,17 @@ class PackedOperands:
                 self._slices.append((L["wgu"][j * I:(j + 1) * I], m + f"{nm}_proj.weight", False))
                 self._slices.append((L["agu"][j * rg:(j + 1) * rg], m + f"vision_{nm}_proj.weight_A", False))
             self.layers.append(L)
+        # unified_head (modeling_libra.py:1054-1064): per codebook the row-concatenated head [lm_head; head_q], its row count
+        # zero-padded to the dgrad's 64 granule - one refreshed slice like the rest instead of a torch.cat per codebook in the
+        # forward and a zeros + two copies in the backward (~1 GB of extra HBM traffic per step at the 11B shape)
+        self.heads: List[torch.Tensor] = []
+        if d.unified_head:
+            V, Vv = d.vocab, d.vision_vocab
+            for q in range(d.codebooks):
+                wcat = z((V + Vv + 63) // 64 * 64, H)
+                self._slices.append((wcat[:V], "lm_head.weight", False))
+                self._slices.append((wcat[V:V + Vv], f"vision_lm_head.heads.{q}.weight", False))
+                self.heads.append(wcat)
         self.refresh(sd, force=True)
 
     def refresh(self, sd: Dict[str, torch.Tensor], force: bool = False, volatile: bool = True) -> int:
@@ -363,8 +374,8 @@ def check_ids(input_ids, flag_bs, d: DecDims):
     ids0 = input_ids[0]
     bad_flag = (flag_bs != (ids0 >= V)).any()
     bad_text = ((ids0 < 0) & ~flag_bs).any()
-    vis = input_ids[:, flag_bs]                                   # [Q, n_v]
-    bad_vis = ((vis < V) | (vis >= V + Vv)).any() if vis.numel() else torch.zeros((), dtype=torch.bool, device=ids0.device)
+    # (no boolean-mask gather: `input_ids[:, flag_bs]` is a hidden nonzero() + host sync)
+    bad_vis = (flag_bs[None] & ((input_ids < V) | (input_ids >= V + Vv))).any()
     code = int((bad_flag.to(torch.int32) + 2 * bad_text.to(torch.int32) + 4 * bad_vis.to(torch.int32)).item())
     if code & 1:
         raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
@@ -374,7 +385,7 @@ def check_ids(input_ids, flag_bs, d: DecDims):
         raise IndexError(f"a vision token id lies outside [{V}, {V + Vv}) in one of the codebooks")
 
 
-def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, unified: bool = False, feats=None):
+def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, unified: bool = False, feats=None, packed=None):
     """cal_vl_logits (modeling_libra.py:1018-1064) without the -inf padding: -> (z_lang [n_l, V] or None, z_vis list of
     [n_v, Vv] or None, z_all list of [N, V+Vv] or None).
     default: text rows through lm_head, vision rows through head_q.
@@ -388,7 +399,7 @@ def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, un
         z_all = []
         ld = K.round_up(d.vocab + d.vision_vocab, 8)
         for q in range(Q):
-            wcat = torch.cat([sd["lm_head.weight"], sd[f"vision_lm_head.heads.{q}.weight"]], 0)
+            wcat = packed.heads[q][:d.vocab + d.vision_vocab]           # [lm_head; head_q], refreshed in place with the operands
             buf = torch.empty((N, ld), dtype=BF16, device=dev)
             z_all.append(K.gemm_nt(hidden, wcat, out=buf[:, :d.vocab + d.vision_vocab]))
         return None, [None] * Q, z_all
@@ -474,7 +485,7 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
             feats = K.alloc_rows(n_v, 2 * d.hidden, dev)[:n_v]          # 64-row padded: the head wgrad's reduction operand
             K.copy_rows(hidden_src, src2d[0], n_v, feats, 0)
             K.copy_rows(hidden_src, src2d[1], n_v, feats, d.hidden)
-    z_lang, z_vis, z_all = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, unified=unified, feats=feats)
+    z_lang, z_vis, z_all = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, unified=unified, feats=feats, packed=packed)
     loss = None
     tgts, counts = [], []
     if labels is not None:
@@ -718,9 +729,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
         gl = None
         for q in range(Q):
             name = f"vision_lm_head.heads.{q}.weight"
-            wcat = torch.zeros((Vp, H), dtype=BF16, device=dev)
-            wcat[:V] = sd["lm_head.weight"]
-            wcat[V:V + Vv] = sd[name]
+            wcat = packed.heads[q]                                       # [Vp, H]: the forward's operand, pad rows zero
             dzf = dlogits(out["z_all"][q], sv["tgts"][q][0], None, 0, coef[q], 0.0, Vp)
             K.gemm_nt(dzf[:N], wcat, b_t=True, out=dhid, resid=dhid if q > 0 else None)
             if w(name) or w("lm_head.weight"):

@@ -135,6 +135,7 @@ class GradBuckets:
         self._micro = 0                 # micro-steps accumulated into the buckets since the last exchange
         self._next = 0                  # next bucket (layout order) to send
         self._seen: set = set()
+        self._autograd_owned: Dict[str, tuple] = {}     # name -> (parameter whose gradient autograd leaves in p.grad, installed grad)
         self.bytes_exchanged = 0
         self.launches = 0
 
@@ -149,6 +150,12 @@ class GradBuckets:
         _capturing = self
         self._sync = sync
         self._seen = set()
+        # a parameter outside the engines still holds the exchanged gradient finish_into() installed last step; left there,
+        # autograd would accumulate this backward's gradient onto it: a captured backward starts from nothing, like the
+        # engine-owned gradients do (whoever runs backward OUTSIDE the capture follows PyTorch's rule: zero_grad() first)
+        for n, (p, installed) in self._autograd_owned.items():
+            if p.grad is installed:
+                p.grad = None
         for b in self.buckets:
             b.ready = 0
         self._next = 0
@@ -257,11 +264,39 @@ class GradBuckets:
                  and p.grad.data_ptr() != self.view(n).data_ptr()}
         if extra:
             self.add(extra)
+            for n, p in named:
+                if n in extra:
+                    self._autograd_owned[n] = (p, None)
+                    p.grad = None             # its value now lives in the bucket: the next micro-step's autograd starts fresh
         out = self.finish()
         if not self._sync:
             return
         for n, p in named:
-            p.grad = out[n]
+            if n in self._autograd_owned:
+                # never a bucket VIEW for these: autograd's in-place accumulation of the next backward would write into the
+                # bucket behind the store's back (and the slot would look "never emitted" and be zeroed)
+                p.grad = out[n].clone()
+                self._autograd_owned[n] = (p, p.grad)
+            else:
+                p.grad = out[n]
+
+    def grad_norm_sq(self, out: Optional[torch.Tensor] = None, *, sumsq_fn: Optional[Callable] = None) -> torch.Tensor:
+        """Squared global L2 norm of the exchanged (averaged) gradients as an fp32 device scalar - identical on every rank.
+        mode zero1: each rank sums its own shard (the only part of a bucket it holds reduced) and the W partial sums are
+        all-reduced; other modes: every rank holds every averaged bucket and sums them all, no communication.  Alignment
+        pad elements are zero.  `sumsq_fn(x, out, accumulate=)`: the HIP pass (kernels.sumsq) unless a test injects its own."""
+        if sumsq_fn is None:
+            from . import kernels as K
+            sumsq_fn = K.sumsq
+        if out is None:
+            out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        sharded = self.mode == "zero1" and self.world > 1
+        for i, b in enumerate(self.buckets):
+            lo, hi = b.shard if sharded else (0, b.flat.numel())
+            sumsq_fn(b.flat[lo:hi], out, accumulate=i > 0)
+        if sharded:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out
 
 
 # =====================================================================================================================
@@ -283,18 +318,26 @@ class FlatAdamW:
     def __init__(self, buckets: GradBuckets, named_params: Iterable[Tuple[str, torch.nn.Parameter]], *, lr: float = 1e-4,
                  betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 0.01,
                  no_decay: Callable[[str, torch.nn.Parameter], bool] = lambda n, p: p.ndim < 2,
-                 update_fn: Optional[Callable] = None):
+                 max_grad_norm: Optional[float] = None, update_fn: Optional[Callable] = None,
+                 sumsq_fn: Optional[Callable] = None):
         self.buckets = buckets
         self.shard = buckets.mode == "zero1" and buckets.world > 1
         if buckets.world > 1 and buckets.mode == "zero1" and not self.shard:
             raise AssertionError
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # global-norm clipping of the exchanged gradients (libra_pretrain.yaml `max_grad_norm: 1.0`, ZeRO-2.json
+        # "gradient_clipping": "auto"): one 2 B/element norm pass over the buckets, the coefficient is applied inside the update
+        self.max_grad_norm = max_grad_norm if max_grad_norm and max_grad_norm > 0 else None
+        self.sumsq_fn = sumsq_fn
+        self.last_grad_norm_sq: Optional[torch.Tensor] = None
+        self._params = None
         self.t = 0
         if update_fn is None:
             from . import kernels as K                       # HIP only: raises on CPU tensors
             update_fn = K.adamw_step
         self.update_fn = update_fn
         params = dict(named_params)
+        self._params = params
         missing = [n for n in buckets.where if n not in params]
         if missing:
             raise ValueError(f"FlatAdamW: parameters missing for bucket entries {missing[:3]}...")
@@ -336,15 +379,52 @@ class FlatAdamW:
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
         works = []
+        clip = {}
+        if self.max_grad_norm is not None:
+            self.last_grad_norm_sq = self.buckets.grad_norm_sq(sumsq_fn=self.sumsq_fn)
+            clip = dict(grad_norm_sq=self.last_grad_norm_sq, max_grad_norm=self.max_grad_norm)
         for b, pf, st in zip(self.buckets.buckets, self.pflat, self.state):
             lo = st["lo"]
             for s, e, wd in st["segs"]:
                 self.update_fn(st["master"][s:e], st["m"][s:e], st["v"][s:e], b.flat[lo + s:lo + e], pf[lo + s:lo + e],
-                               lr=lr, beta1=b1, beta2=b2, eps=self.eps, weight_decay=wd, bias_corr1=bc1, bias_corr2=bc2)
+                               lr=lr, beta1=b1, beta2=b2, eps=self.eps, weight_decay=wd, bias_corr1=bc1, bias_corr2=bc2, **clip)
             if self.shard:
                 works.append(dist.all_gather_into_tensor(pf, pf[lo:st["hi"]], group=self.buckets.group, async_op=True))
         for w in works:
             w.wait()
 
-    def zero_grad(self):
-        pass                                                 # the buckets are overwritten by the next backward
+    def zero_grad(self, set_to_none: bool = True):
+        """Engine-owned gradients live in the buckets and are overwritten by the next backward; gradients autograd owns
+        (parameters outside the engines) are dropped so that the next backward does not accumulate onto an exchanged value."""
+        for p in (self._params or {}).values():
+            p.grad = None
+
+    # ---- checkpoint / resume (HF Trainer `save_strategy`, DeepSpeed checkpoint of the fp32 master + moments) ----------------
+    def state_dict(self) -> dict:
+        """This rank's optimizer state: step count, and per bucket the fp32 master weights and both moments of the range
+        [lo, hi) it owns (the whole bucket unless sharded) with the layout that range belongs to.  zero1: one file per rank,
+        as DeepSpeed's `zero_pp_rank_*_optim_states`."""
+        return {"t": self.t, "world": self.buckets.world, "rank": self.buckets.rank, "sharded": self.shard,
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                          "max_grad_norm": self.max_grad_norm},
+                "buckets": [{"names": list(b.names), "numel": b.flat.numel(), "lo": st["lo"], "hi": st["hi"],
+                             "master": st["master"].clone(), "m": st["m"].clone(), "v": st["v"].clone()}
+                            for b, st in zip(self.buckets.buckets, self.state)]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict) -> None:
+        """Resume: restores step count, master weights and moments, and re-derives the bf16 parameters from the masters (so a
+        resumed run continues from the fp32 values, not from bf16-rounded weights with zero moments)."""
+        if len(sd["buckets"]) != len(self.state):
+            raise ValueError("FlatAdamW.load_state_dict: bucket count differs (different parameter set or bucket size)")
+        for b, st, pf, src in zip(self.buckets.buckets, self.state, self.pflat, sd["buckets"]):
+            if src["names"] != list(b.names) or src["numel"] != b.flat.numel() or (src["lo"], src["hi"]) != (st["lo"], st["hi"]):
+                raise ValueError("FlatAdamW.load_state_dict: bucket layout / shard range differs from the saved one "
+                                 "(same parameters, bucket_bytes, world size and rank are required)")
+            for k in ("master", "m", "v"):
+                st[k].copy_(src[k].to(st[k].device))
+            pf[st["lo"]:st["hi"]].copy_(st["master"])                     # bf16(master), in place: the parameters are views
+        self.t = int(sd["t"])
+        if self.shard:
+            for pf, st in zip(self.pflat, self.state):
+                dist.all_gather_into_tensor(pf, pf[st["lo"]:st["hi"]], group=self.buckets.group)

@@ -427,8 +427,10 @@ def resample_v_u8_norm(tmp: torch.Tensor, row0: int, bounds: torch.Tensor, coeff
 
 
 def adamw_step(master, m, v, grad, param, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
-               bias_corr1: float, bias_corr2: float, grad_scale: float = 1.0):
-    """One fused AdamW update of a flat range: master / m / v fp32 [n], grad / param bf16 [n] (param = bf16(master))."""
+               bias_corr1: float, bias_corr2: float, grad_scale: float = 1.0, grad_norm_sq: Optional[torch.Tensor] = None,
+               max_grad_norm: float = 0.0):
+    """One fused AdamW update of a flat range: master / m / v fp32 [n], grad / param bf16 [n] (param = bf16(master)).
+    grad_norm_sq (fp32 device scalar) + max_grad_norm: global-norm clipping, the coefficient is formed on the device."""
     n = master.numel()
     for t, dt, nm in ((master, torch.float32, "master"), (m, torch.float32, "m"), (v, torch.float32, "v"),
                       (grad, BF16, "grad"), (param, BF16, "param")):
@@ -437,8 +439,21 @@ def adamw_step(master, m, v, grad, param, *, lr: float, beta1: float, beta2: flo
                              f"(got {t.dtype} {tuple(t.shape)} {t.device}); there is no CPU optimizer path")
     rc = _lib.lib().libra_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), n,
                                      float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                     float(bias_corr1), float(bias_corr2), float(grad_scale), _stream())
+                                     float(bias_corr1), float(bias_corr2), float(grad_scale), _ptr(grad_norm_sq),
+                                     float(max_grad_norm), _stream())
     _lib.check(rc, "adamw_step")
+
+
+def sumsq(x: torch.Tensor, out: torch.Tensor, *, accumulate: bool = False) -> torch.Tensor:
+    """out (fp32 device scalar) (+)= sum of squares of the contiguous bf16 tensor x; deterministic."""
+    if x.dtype != BF16 or not x.is_contiguous() or not x.is_cuda or out.dtype != torch.float32 or out.numel() != 1:
+        raise ValueError("sumsq: x must be a contiguous cuda bf16 tensor, out an fp32 scalar tensor")
+    n = x.numel()
+    nbytes = _lib.lib().libra_sumsq_workspace_bytes(n)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().libra_sumsq_bf16(x.data_ptr(), n, out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, _stream())
+    _lib.check(rc, "sumsq")
+    return out
 
 
 # ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------

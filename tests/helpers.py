@@ -80,11 +80,20 @@ class FakeTextTokenizer:
         return BatchEncoding({"input_ids": self.ids.clone(), "attention_mask": self.am.clone(), "length": self.am.sum(1)})
 
 
+def torch_sumsq(x, out, *, accumulate=False):
+    """Plain-torch statement of `libra_sumsq_bf16` (injected into dp.FlatAdamW / GradBuckets.grad_norm_sq by the CPU tests)."""
+    s = x.float().pow(2).sum()
+    out.copy_(out + s if accumulate else s.reshape(1))
+    return out
+
+
 def torch_adamw_update(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2,
-                       grad_scale=1.0):
+                       grad_scale=1.0, grad_norm_sq=None, max_grad_norm=0.0):
     """Plain-torch statement of `libra_adamw_step` (torch.optim.AdamW's arithmetic on an fp32 master): the checker for the
     HIP kernel, and the `update_fn` the CPU (gloo) tests inject into dp.FlatAdamW - the product has no CPU optimizer."""
     import math
+    if grad_norm_sq is not None:                   # torch.nn.utils.clip_grad_norm_: coef = max / (norm + 1e-6), clamped to 1
+        grad_scale = grad_scale * min(1.0, max_grad_norm / (math.sqrt(float(grad_norm_sq)) + 1e-6))
     g = grad.float() * grad_scale
     master.mul_(1.0 - lr * weight_decay)
     m.mul_(beta1).add_(g, alpha=1.0 - beta1)

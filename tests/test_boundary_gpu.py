@@ -147,6 +147,42 @@ def test_adamw_kernel_vs_torch():
                      lr=1.0, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=0.0, bias_corr1=0.1, bias_corr2=0.01)
 
 
+def test_sumsq_and_clipped_adamw_kernel_vs_torch():
+    """libra_sumsq_bf16 (deterministic, accumulate flag, ragged tail) and the device-side clipping coefficient of
+    libra_adamw_step vs torch.nn.utils.clip_grad_norm_ + AdamW arithmetic."""
+    from helpers import torch_sumsq
+    from libra_amd import kernels as K
+    g = torch.Generator().manual_seed(1)
+    for n in (8, 12345, (1 << 20) + 24):
+        x = (torch.randn(n, generator=g) * 0.3).to(BF).cuda()
+        out = torch.full((1,), 5.0, device="cuda")
+        K.sumsq(x, out)
+        ref = float(x.double().pow(2).sum())
+        assert abs(float(out) - ref) <= 1e-5 * ref
+        first = float(out)
+        K.sumsq(x, out, accumulate=True)
+        assert abs(float(out) - 2 * ref) <= 2e-5 * ref
+        out2 = torch.zeros(1, device="cuda")
+        K.sumsq(x, out2)
+        assert float(out2) == first                                   # bit-identical rerun
+    n = 4099
+    for scale, clips in ((1.0, True), (1e-3, False)):
+        master = torch.randn(n, generator=g).cuda()
+        m, v = torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        param = torch.empty(n, dtype=BF).cuda()
+        rm, rmm, rv, rp = master.clone(), m.clone(), v.clone(), param.clone()
+        grad = (torch.randn(n, generator=g) * scale).to(BF).cuda()
+        nsq = torch.zeros(1, device="cuda")
+        K.sumsq(grad, nsq)
+        assert (float(nsq.sqrt()) > 1.0) == clips
+        kw = dict(lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=0.01, bias_corr1=0.1, bias_corr2=0.01)
+        K.adamw_step(master, m, v, grad, param, grad_norm_sq=nsq, max_grad_norm=1.0, **kw)
+        torch_adamw_update(rm, rmm, rv, grad, rp, grad_norm_sq=nsq.cpu(), max_grad_norm=1.0, **kw)
+        assert rel_err(master.cpu(), rm.cpu()) < 1e-5 and rel_err(m.cpu(), rmm.cpu()) < 1e-5 and rel_err(v.cpu(), rv.cpu()) < 2e-5
+    with pytest.raises(ValueError):                                    # a norm pointer without a positive max_grad_norm
+        K.adamw_step(master, m, v, grad, param, grad_norm_sq=nsq, max_grad_norm=0.0, **kw)
+
+
 def test_libra_tokenizer_module_on_device_matches_reference_fixture():
     """a11 on DEVICE tensors: LibraTokenizer.forward (nn.Module surface) with the fixture's text / image ids living on the GPU
     reproduces the reference's own LibraTokenizer.forward outputs bit for bit."""

@@ -162,6 +162,53 @@ def test_bridge_attention_bwd(K, B, S, H, mode):
         assert torch.isfinite(g.float()).all(), n
 
 
+@pytest.mark.parametrize("pad,S,mode", [(70, 300, "span"), (578, 700, "random"), (33, 200, "none"), (64, 256, "span"),
+                                        (100, 2048, "span")])
+def test_bridge_attention_left_padding_equals_unpadded(K, pad, S, mode):
+    """a 32-query wave that straddles kv_start with kv_start >= 64 saw a fully masked first tile for its real
+    rows while its pad rows kept their keys; the wave-uniform rescale then computed exp2(-inf - -inf) = NaN for the real rows.
+    A batch of one image prompt and one text prompt is left-padded by 578.  The padded run must be finite and equal the same
+    tokens run without padding (positions do not enter the kernel)."""
+    H = 2
+    Sr = S - pad
+    D = H * 128
+    real = [rnd(Sr, D, seed=80 + i) for i in range(5)]
+    fl_r = _flags(Sr, 9, mode)
+    padded = []
+    for i, t in enumerate(real):
+        junk = rnd(pad, D, seed=90 + i) * 3.0
+        padded.append(torch.cat([junk, t], 0).contiguous())
+    fl_p = torch.cat([_flags(pad, 10, "random"), fl_r])
+    sc = 128 ** -0.5
+    start = torch.tensor([pad], dtype=torch.int32).cuda()
+    lens_p = torch.tensor([S], dtype=torch.int32).cuda()
+    o_p, lse_p = K.bridge_attn_fwd(*padded, fl_p.cuda(), lens_p, 1, S, H, sc, need_lse=True, kv_start=start)
+    o_r, lse_r = K.bridge_attn_fwd(*real, fl_r.cuda(), torch.tensor([Sr], dtype=torch.int32).cuda(), 1, Sr, H, sc, need_lse=True)
+    assert torch.isfinite(o_p[pad:].float()).all() and torch.isfinite(lse_p[:, :, pad:]).all()
+    ro, rl = _attn_ref(*[t.cpu() for t in real], fl_r, torch.tensor([Sr]), 1, Sr, H, sc)
+    close(o_p.cpu()[pad:], ro, rel=2e-3, what="left-padded bridge attn out")
+    close(lse_p.cpu()[:, :, pad:], rl, rel=1e-4, what="left-padded lse")
+    # same arithmetic up to the tile phase of the keys: bf16-rounding level agreement with the unpadded launch
+    assert float((o_p[pad:].float() - o_r.float()).abs().max()) <= float(o_r.float().abs().max()) * 2 ** -6
+
+
+def test_bridge_attention_deferred_max_rescale_branch(K):
+    """The deferred running-max rescale is a rare, data-dependent branch (cdna_hip_programming.md rule 26): force it by spiking
+    one key against one query at a late tile (raw score far above the row's other scores), full-tensor fp32 reference."""
+    B, S, H = 1, 1024, 1
+    N, D = B * S, H * 128
+    q, ks, kc, vs, vc = [rnd(N, D, seed=120 + i) for i in range(5)]
+    flag = _flags(N, 3, "span")
+    for (qi, kj, amp) in ((700, 650, 6.0), (1000, 130, 9.0), (301, 300, 12.0)):
+        ks[kj] = (q[qi].float() * amp / 8).to(BF)              # q.k / sqrt(d) ~ amp * |q|^2 / (8 sqrt(128))
+        kc[kj] = ks[kj]
+    lens = torch.full((B,), S, dtype=torch.int32)
+    o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag.cuda(), lens.cuda(), B, S, H, 128 ** -0.5, need_lse=True)
+    ro, rl = _attn_ref(q.cpu(), ks.cpu(), kc.cpu(), vs.cpu(), vc.cpu(), flag, lens.long(), B, S, H, 128 ** -0.5)
+    close(o.cpu(), ro, rel=4e-3, what="bridge attn out (spiked keys)")
+    close(lse.cpu(), rl, rel=1e-4, what="bridge lse (spiked keys)")
+
+
 def test_bridge_attention_output_residual(K):
     """Same contract for the bridge kernels: identical bf16 output, O + out_lo ~ fp32 O, dq no worse (usually several times better)."""
     from helpers import rel_err

@@ -248,3 +248,116 @@ def test_single_process_passthrough_and_alignment():
         assert torch.equal(out[n], g[n]) and out[n].shape == params[n].shape
         assert out[n].data_ptr() % 128 == 0 or out[n].storage_offset() % dp.ALIGN == 0
     assert [b.names for b in st.buckets][0] == ["head.w"] and st.buckets[-1].names[-1] == "embed.w"
+
+
+# ---- parameters whose gradient autograd leaves in p.grad (outside the engines) ---------------------------------
+def _worker_autograd_owned(rank, world, port, q, accum, order):
+    _init(rank, world, port)
+    from libra_amd import dp
+    params = _params()
+    st = dp.GradBuckets(params.items(), bucket_bytes=2048, group_fn=_group, mode="allreduce", dtype=torch.float32)
+    outs = []
+    for step in range(3):
+        micro = 3 if accum else 1
+        for k in range(micro):
+            # "embed.w" is autograd-owned: a real autograd backward deposits / accumulates into p.grad; the rest is emitted
+            w = params["embed.w"]
+            if order == "outside":                          # backward before the capture: PyTorch's rule, zero_grad() first
+                if k == 0:
+                    for p_ in params.values():
+                        p_.grad = None
+                (w * float(2 + rank + step)).sum().backward()
+            with st.capture(sync=(k == micro - 1)):
+                if order == "inside":                       # the product's flow: `with buckets.capture(): loss.backward()`
+                    (w * float(2 + rank + step)).sum().backward()
+                g, seen = {}, set()
+                for n in sorted(params, key=_group):
+                    if n != "embed.w":
+                        g[n] = torch.full(params[n].shape, float(1 + step))
+                        dp.emit_new(g, seen)
+            st.finish_into(params.items())
+        outs.append(_np({n: p.grad for n, p in params.items()}))
+    q.put((rank, outs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accum,order", [(False, "inside"), (True, "inside"), (True, "outside")])
+def test_autograd_owned_gradient_over_steps_and_accumulation(accum, order):
+    """finish_into's path for parameters outside the engines: step 2 must not see step 1's exchanged value again (it used to be
+    zero-filled from step 2 on), and three accumulated micro-steps of gradient g give 3 g, not 6 g."""
+    (_, o0), (_, o1) = _run(_worker_autograd_owned, 2, accum, order)
+    for step in range(3):
+        mean_rank = ((2 + 0 + step) + (2 + 1 + step)) / 2
+        want = mean_rank * (3 if accum else 1)
+        assert np.allclose(o0[step]["embed.w"], want), (step, o0[step]["embed.w"].ravel()[:3], want)
+        assert np.allclose(o0[step]["head.w"], (1 + step) * (3 if accum else 1)), step
+        assert np.array_equal(o0[step]["embed.w"], o1[step]["embed.w"])
+
+
+def _worker_clip(rank, world, port, q, mode):
+    _init(rank, world, port)
+    from helpers import torch_adamw_update, torch_sumsq
+    from libra_amd import dp
+    torch.manual_seed(3)
+    params = {n: torch.nn.Parameter(torch.randn(p.shape).to(torch.bfloat16)) for n, p in _params().items()}
+    ref = {n: p.detach().float().clone().requires_grad_(True) for n, p in params.items()}
+    nodecay = [n for n, p in params.items() if p.ndim < 2]
+    opt_ref = torch.optim.AdamW([{"params": [ref[n] for n in ref if n not in nodecay], "weight_decay": 0.1},
+                                 {"params": [ref[n] for n in nodecay], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    st = dp.GradBuckets(params.items(), bucket_bytes=2048, group_fn=_group, mode=mode)
+    opt = dp.FlatAdamW(st, params.items(), lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
+                       update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    norms = []
+    for step in range(2):
+        gens = [torch.Generator().manual_seed(1000 * step + r) for r in range(world)]
+        scale = 1.0 if step == 0 else 1e-3                  # step 0 clips (norm ~ 38), step 1 does not (norm << 1)
+        allg = [{n: (torch.randn(p.shape, generator=gens[r]) * scale).to(torch.bfloat16) for n, p in params.items()}
+                for r in range(world)]
+        with st.capture():
+            g, seen = {}, set()
+            for n in sorted(params, key=_group):
+                g[n] = allg[rank][n]
+                dp.emit_new(g, seen)
+        st.finish()
+        opt.step()
+        norms.append(float(opt.last_grad_norm_sq.sqrt()))
+        for n in ref:
+            ref[n].grad = (sum(a[n].float() for a in allg) / world).to(torch.bfloat16).float()
+        rn = float(torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0))
+        norms.append(rn)
+        opt_ref.step()
+    snap = _np(params)                                      # after the two reference-checked steps
+    # checkpoint / resume: a fresh optimizer over fresh (zeroed) parameters continues identically after load_state_dict
+    sd = opt.state_dict()
+    params2 = {n: torch.nn.Parameter(torch.zeros_like(p)) for n, p in params.items()}
+    st2 = dp.GradBuckets(params2.items(), bucket_bytes=2048, group_fn=_group, mode=mode)
+    opt2 = dp.FlatAdamW(st2, params2.items(), lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
+                        update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    opt2.load_state_dict(sd)
+    same_after_load = all(torch.equal(params[n], params2[n]) for n in params)
+    gen = torch.Generator().manual_seed(77 + rank)
+    gl = {n: torch.randn(p.shape, generator=gen).to(torch.bfloat16) for n, p in params.items()}
+    for s_, o_ in ((st, opt), (st2, opt2)):
+        with s_.capture():
+            s_.add({n: gl[n].clone() for n in gl})
+        s_.finish()
+        o_.step()
+    same_after_step = all(torch.equal(params[n], params2[n]) for n in params) and opt2.t == opt.t == 3
+    q.put((rank, snap, _np({n: r.detach().to(torch.bfloat16) for n, r in ref.items()}), norms, same_after_load,
+           same_after_step))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["zero1", "allreduce"])
+def test_global_norm_clipping_and_optimizer_state_roundtrip_world2(mode):
+    """max_grad_norm (libra_pretrain.yaml: 1.0): the global norm over the (sharded) buckets equals clip_grad_norm_'s, the clipped
+    update equals torch's AdamW on clipped gradients; state_dict -> load_state_dict into a fresh optimizer resumes bit for bit."""
+    res = _run(_worker_clip, 2, mode)
+    (_, p0, r0, n0, l0, s0), (_, p1, _, n1, l1, s1) = res
+    assert l0 and l1 and s0 and s1
+    assert np.allclose(n0[0], n0[1], rtol=1e-3) and n0[0] > 5.0           # step 0: our norm == clip_grad_norm_'s, and it clips
+    assert np.allclose(n0[2], n0[3], rtol=1e-3) and n0[2] < 1.0           # step 1: below the threshold, untouched
+    assert n0 == n1 or np.allclose(n0, n1)                                # every rank sees the same norm (sharded: all-reduced)
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
+        assert np.allclose(p0[k], r0[k], atol=0, rtol=2 ** -7), k
