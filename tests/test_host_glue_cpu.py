@@ -306,3 +306,31 @@ def test_gradient_emission_groups_are_rank_independent_and_cover_the_2d_placehol
     d = DE.DecDims(hidden=256, inter=512, layers=2, heads=2, vocab=96, vision_vocab=18, codebooks=2, max_vision_len=6, signal=64,
                    max_pos=64, rope_2d=True, res=2)
     assert DE.rope_rows(d, 40) == 64 and DE.rope_rows(d, 100) == 104               # 2d positions run at most res + 2 ahead
+
+
+def test_bench_self_launch_refuses_silently_measuring_one_gpu():
+    """`python bench.py --gpus N` outside torchrun used to run ONE rank and print n_gpus: 1.  It now launches its
+    own N ranks; without N visible GPUs (this container has none) it fails loudly instead; a WORLD_SIZE that disagrees with --gpus
+    is refused too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LIBRA_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and not r.stdout.strip()
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_bench_physical_core_count_is_sane():
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    phys, logical = bench.physical_cores()
+    assert 1 <= phys <= logical <= (os.cpu_count() or 1)
