@@ -100,15 +100,17 @@ def make_vit(device, batch, world, mode):
     return w
 
 
-def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recompute=False, accum=1, full_finetune=False):
-    """configs[2]/[3]: the reference's real pretraining step (see module docstring)."""
+def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recompute=False, accum=1, full_finetune=False,
+                layers=None, max_grad_norm=1.0):
+    """configs[2]/[3]: the reference's real pretraining step (see module docstring).  `layers` (tests only): a shallower decoder
+    of the same width - the bench itself always runs the 32 layers of the configuration."""
     from libra_amd import decoder_engine as DE
     from libra_amd import dp
     from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy, assemble_inputs, get_labels
     clip, tok, pixel, _ = build_vit(device, batch)
     clip.requires_grad_(False)
     tok.model.encoder.allow_grad = False
-    cfg = LibraConfig(max_position_embeddings=max(2048, seq))
+    cfg = LibraConfig(max_position_embeddings=max(2048, seq), **({} if layers is None else {"num_hidden_layers": layers}))
     with torch.device(device):
         dec = LibraForCausalLM(cfg)
     dec = dec.to(torch.bfloat16)
@@ -137,7 +139,8 @@ def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recomp
         nl = cfg.num_hidden_layers
         w.buckets = dp.GradBuckets(named, bucket_bytes=256 << 20, group_fn=lambda n: DE.emit_group(n, nl), mode=mode)
     if with_optimizer:
-        w.opt = dp.FlatAdamW(w.buckets, named, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)   # libra_pretrain.yaml:83-91
+        # libra_pretrain.yaml:83-91 (+ max_grad_norm 1.0: the norm pass over the buckets and the clipped update are in the step)
+        w.opt = dp.FlatAdamW(w.buckets, named, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, max_grad_norm=max_grad_norm)
 
     def step():
         loss = None

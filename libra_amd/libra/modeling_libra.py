@@ -269,7 +269,9 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
             loss = None
         hs = None
         if output_hidden_states:
-            hs = tuple(h.view(B, S, -1) for h in out["hidden_states"]) + (out["hidden"],)
+            # the reference's tuple (modeling_libra.py:781-813): the input of every layer (embeddings, outputs of layers 0..L-2)
+            # and the NORMED output of the last layer - its raw output never appears
+            hs = tuple(h.view(B, S, -1) for h in out["hidden_states"][:-1]) + (out["hidden"],)
         training_step = out["saved"] is not None              # autograd will call back: the Trainer reads only .loss
         logits = None if training_step else DE.dense_logits(out, self._dims, B, S)
         res = LibraCausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None)
@@ -459,6 +461,9 @@ class LibraTrainWrapper(PreTrainedModel):
     config_class = LibraConfig
     base_model_prefix = "module"
     supports_gradient_checkpointing = True
+    # HF Trainer (>= 4.46) hands `num_items_in_batch` to any model whose forward has **kwargs; the wrapper's loss is the
+    # reference's own mean over the label counts (modeling_libra.py:1160-1174) and takes no such argument
+    accepts_loss_kwargs = False
 
     def __init__(self, config, *, module: Optional["LibraForCausalLM"] = None, tokenizer=None):
         from .tokenization_libra import LibraTokenizer, apply_freeze_policy
@@ -515,6 +520,7 @@ class LibraTrainWrapper(PreTrainedModel):
                           bos_token_id=self.tokenizer.text_tokenizer.bos_token_id)
 
     def forward(self, samples, return_loss=None, **kwargs):
+        kwargs.pop("num_items_in_batch", None)
         inputs = self.tokenizer(samples, return_tensors="pt", padding="longest",
                                 max_length=self.tokenizer.text_tokenizer.model_max_length, truncation=True)
         labels = self.get_labels(inputs, samples["label_mask_position_map"])

@@ -182,9 +182,11 @@ def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Option
 
 
 def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, layers: int, heads: int, vocab: int,
-                  max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048, rope_2d_res: Optional[int] = None):
+                  max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048, rope_2d_res: Optional[int] = None,
+                  hidden_states: Optional[list] = None):
     """LibraForCausalLM up to the final routed norm: -> hidden [B,S,H], vision_flag.  `rope_2d_res` = image_feature_resolution
-    switches on use_2d_rope (position ids from `position_ids_2d`, :731-733)."""
+    switches on use_2d_rope (position ids from `position_ids_2d`, :731-733).  `hidden_states` (a list) receives the reference's
+    `output_hidden_states` tuple: the embeddings and every layer's output, before the final norm (:781-807)."""
     flag = vision_indices < max_vision_token_length                      # :1118
     assert torch.equal(flag, input_ids[0] >= vocab)                        # :707-710
     B, S = input_ids.shape[1:]
@@ -197,8 +199,12 @@ def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, laye
         cos, sin = rope_tables(d, max(max_pos, S), dtype=x.dtype)
         pos = torch.arange(S).unsqueeze(0).expand(B, S)
     mask = additive_mask(attention_mask, S, x.dtype)
+    if hidden_states is not None:
+        hidden_states.append(x)
     for i in range(layers):
         x = decoder_layer(sd, i, x, flag, mask, pos, heads, eps, cos, sin)
+        if hidden_states is not None:
+            hidden_states.append(x)
     x = routed(x, flag, lambda t: rms_norm(t, sd["model.norm.weight"], eps),
                lambda t: rms_norm(t, sd["model.vision_norm.weight"], eps))
     return x, flag

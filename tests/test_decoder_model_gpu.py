@@ -334,3 +334,72 @@ def test_libra_model_path_at_seq_4096_vs_oracle():
     from helpers import parity_report
     parity_report(f"[configs[4] sequence length, tiny width] S=4096 model path: hidden {e_h:.3e}, loss {float(out.loss):.4f} vs {float(ref_loss):.4f}, "
                   f"worst parameter gradient {worst[1]:.3e} at {worst[0]}")
+
+
+def test_libra_depth32_vs_reference_fixture_error_growth():
+    """Tiny width x FULL depth: the 32-iteration routed layer loop (modeling_libra.py:781-807) against the
+    reference's own 32-layer run - every one of the 33 hidden states, the loss, and the reference's autograd gradients; the error
+    per depth, ours (HIP, bf16) next to theirs (the oracle executed op by op in bf16 = the reference's arithmetic), goes to the
+    parity report.  Gate: at every depth ours <= max(1.5 x theirs, 4e-3)."""
+    from helpers import parity_report
+    from libra_amd.libra import LibraConfig, LibraForCausalLM
+    from oracle import libra_oracle as LO
+    from test_oracle_libra_golden import depth32_names_shapes, depth32_state
+    t, meta = load_golden("libra_tiny_depth32.safetensors")
+    c = meta["cfg"]
+    m = LibraForCausalLM(LibraConfig(**c))
+    ours_ns = {n: tuple(p.shape) for n, p in m.named_parameters()}
+    assert ours_ns == {n: tuple(s) for n, s in depth32_names_shapes(c)}       # the product's parameters = the reference layout
+    sd32 = depth32_state(meta, list(ours_ns.items()))
+    m.load_state_dict(sd32, strict=False)
+    m = m.to(BF).cuda()
+    m.requires_grad_(True)
+    ids, am, vi = t["in.input_ids"].cuda(), t["in.attention_mask"].cuda(), t["in.vision_indices"].cuda()
+    sig, lab = t["in.signal"].to(BF).cuda(), t["in.labels"].cuda()
+    out = m(input_ids=ids, attention_mask=am, vision_indices=vi, contiguous_signal=sig, labels=lab, output_hidden_states=True)
+    assert len(out.hidden_states) == 33
+    out.loss.backward()
+    # theirs: the oracle op by op in bf16 (the reference's own arithmetic under torch_dtype=bfloat16)
+    sdb = {k: v.to(BF) for k, v in sd32.items()}
+    hsb = []
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+              max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    hidb, _ = LO.model_forward(sdb, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"], t["in.signal"].to(BF),
+                               hidden_states=hsb, **kw)
+    hsb = hsb[:32] + [hidb]
+    valid = t["in.attention_mask"].bool()
+    ref = t["out.hidden_states"]
+    lines, worst = [], 0.0
+    for l in range(33):
+        e_o = rel_err(out.hidden_states[l].float().cpu()[valid], ref[l][valid])
+        e_t = rel_err(hsb[l].float()[valid], ref[l][valid])
+        worst = max(worst, e_o)
+        if l % 4 == 0 or l >= 31:
+            lines.append(f"{l}:{e_o:.2e}/{e_t:.2e}")
+        assert e_o < max(1.5 * e_t, 4e-3), (l, e_o, e_t)
+    loss_ref = float(t["out.loss"])
+    assert abs(float(out.loss) - loss_ref) < 3e-2 * abs(loss_ref), (float(out.loss), loss_ref)
+    # theirs for the gradients: autograd through the bf16 oracle (what the reference's bf16 training run computes)
+    sdg = {k: v.to(BF).requires_grad_(True) for k, v in sd32.items()}
+    hg, fg = LO.model_forward(sdg, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"], t["in.signal"].to(BF), **kw)
+    LO.causal_lm_loss(LO.vl_logits(sdg, hg, fg, c["vision_codebook_num"]).float(), t["in.labels"]).backward()
+    gw, gname, gt, n = 0.0, "", 0.0, 0
+    params = dict(m.named_parameters())
+    for k, g in sub(t, "grad.").items():
+        if k == "vision_hidden_placeholder":
+            continue
+        gmax = float(g.float().abs().max())
+        if gmax < 1e-6:
+            continue
+        e = rel_err(params[k].grad.float().cpu(), g.float())
+        et = rel_err(sdg[k].grad.float(), g.float())
+        gt = max(gt, et)
+        if e > gw:
+            gw, gname = e, k
+        assert e < max(2.0 * et, 5e-2), (k, e, et)
+        n += 1
+    lines.append(f"| worst gradient ours {gw:.2e} theirs {gt:.2e}")
+    parity_report(f"[a20 depth 32, tiny width, vs the reference's own 32-layer run] hidden-state rel err by depth ours/theirs(bf16 "
+                  f"oracle): {' '.join(lines)}; loss {float(out.loss):.5f} vs {loss_ref:.5f}; worst of {n} reference gradients "
+                  f"{gw:.2e} ({gname})")
+    assert n > 400, n

@@ -183,3 +183,83 @@ def test_f4_variants_match_reference():
             assert rel_err(sd[k].grad, g) < 2e-4, (name, k, rel_err(sd[k].grad, g))
             n += 1
         assert n >= 11, (name, n)
+
+
+# ---- tiny width x FULL depth (32 layers): SURVEY §8c(i) ------------------------------------------------------------------
+def depth32_state(meta, names_shapes):
+    """The fixture's weights, re-derived (tests/golden/seeded_weights.py) and checked against the generating run's checksum."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from seeded_weights import checksum, seeded_state
+    sd = seeded_state(names_shapes, meta["seed"])
+    cs, ref = checksum(sd), meta["checksum"]
+    assert cs["n"] == ref["n"] == meta["n_params"] and cs["first"] == ref["first"]
+    assert abs(cs["sum"] - ref["sum"]) <= 1e-9 * ref["abs_sum"] and abs(cs["abs_sum"] - ref["abs_sum"]) <= 1e-9 * ref["abs_sum"]
+    return sd
+
+
+def depth32_names_shapes(c):
+    """(name, shape) of every parameter of LibraForCausalLM(c): the reference's state-dict layout (checked against the fixture's
+    parameter count and the product model's own parameters in the GPU test)."""
+    H, I, V, Vv, Q = c["hidden_size"], c["intermediate_size"], c["vocab_size"], c["vision_vocab_size"], c["vision_codebook_num"]
+    r, rg, rank, Cs = H // c["vision_down_ratio"], I // c["vision_down_ratio"], c["bridge_rank"], c["contiguous_signal_size"]
+    out = [("model.embed_tokens.weight", (V, H))] + [(f"model.vision_embed_tokens.{q}.weight", (Vv, H // Q)) for q in range(Q)]
+    out += [("model.vision_signal_norm.weight", (H + Cs,)), ("model.vision_contiguous_signal_processor.weight", (H, H + Cs))]
+    for i in range(c["num_hidden_layers"]):
+        a, m = f"model.layers.{i}.self_attn.", f"model.layers.{i}.mlp."
+        for n in "qkvo":
+            out += [(a + f"{n}_proj.weight", (H, H)), (a + f"vision_{n}_proj.weight_A", (r, H)), (a + f"vision_{n}_proj.weight_B", (H, r))]
+        for kv in "kv":
+            for w in ("language", "vision"):
+                out += [(a + f"vision_{kv}_bridge_on_{w}.weight_A", (rank, H)), (a + f"vision_{kv}_bridge_on_{w}.weight_B", (H, rank))]
+        out += [(m + "gate_proj.weight", (I, H)), (m + "up_proj.weight", (I, H)), (m + "down_proj.weight", (H, I)),
+                (m + "vision_gate_proj.weight_A", (rg, H)), (m + "vision_gate_proj.weight_B", (I, rg)),
+                (m + "vision_up_proj.weight_A", (rg, H)), (m + "vision_up_proj.weight_B", (I, rg)),
+                (m + "vision_down_proj.weight_A", (r, I)), (m + "vision_down_proj.weight_B", (H, r))]
+        p = f"model.layers.{i}."
+        out += [(p + n, (H,)) for n in ("input_layernorm.weight", "vision_input_layernorm.weight",
+                                        "post_attention_layernorm.weight", "vision_post_attention_layernorm.weight")]
+    out += [("model.norm.weight", (H,)), ("model.vision_norm.weight", (H,)), ("lm_head.weight", (V, H))]
+    out += [(f"vision_lm_head.heads.{q}.weight", (Vv, H)) for q in range(Q)]
+    out += [("vision_hidden_placeholder", (H,))]
+    return out
+
+
+def test_depth32_oracle_matches_reference_at_every_depth():
+    """The oracle against the reference's own 32-layer run: all 33 hidden states, logits, loss and autograd gradients."""
+    t, meta = load_golden("libra_tiny_depth32.safetensors")
+    c = meta["cfg"]
+    ns = depth32_names_shapes(c)
+    assert len(ns) == meta["n_params"]
+    sd = {k: v.requires_grad_(True) for k, v in depth32_state(meta, ns).items()}
+    hs = []
+    hid, flag = LO.model_forward(sd, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"], t["in.signal"],
+                                 layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+                                 max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"],
+                                 max_pos=c["max_position_embeddings"], hidden_states=hs)
+    ref_hs = t["out.hidden_states"]
+    assert len(hs) == ref_hs.shape[0] == 33
+    valid = t["in.attention_mask"].bool()
+    # the reference's tuple = embeddings, the outputs of layers 0..30, and the NORMED output of layer 31 (:809-813)
+    worst = max(rel_err(h.detach()[valid], ref_hs[l][valid]) for l, h in enumerate(hs[:32]))
+    worst = max(worst, rel_err(hid.detach()[valid], ref_hs[32][valid]))
+    assert worst < 2e-5, worst
+    logits = LO.vl_logits(sd, hid, flag, c["vision_codebook_num"])
+    fin = torch.isfinite(t["out.logits"])
+    assert torch.equal(fin, torch.isfinite(logits)) and rel_err(logits.detach()[fin], t["out.logits"][fin]) < 2e-5
+    loss = LO.causal_lm_loss(logits, t["in.labels"])
+    assert abs(float(loss) - float(t["out.loss"])) < 1e-5 * abs(float(t["out.loss"]))
+    loss.backward()
+    n = 0
+    for k, g in sub(t, "grad.").items():
+        if k == "vision_hidden_placeholder":
+            continue
+        gmax = float(g.float().abs().max())
+        if gmax < 1e-6:
+            assert float(sd[k].grad.abs().max()) < 1e-5, k
+        else:
+            tol = 2e-3 if g.dtype == torch.float16 else 2e-4
+            assert rel_err(sd[k].grad, g.float()) < tol, (k, rel_err(sd[k].grad, g.float()))
+        n += 1
+    assert n == meta["n_grads"] - (1 if "grad.vision_hidden_placeholder" in t else 0) and n > 400
