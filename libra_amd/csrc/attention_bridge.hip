@@ -15,8 +15,10 @@
 // transpose load (ds_read_b64_tr_b16) — no V^T copy exists; keys beyond the causal diagonal or the
 // sequence's valid length are masked; work-groups are ordered heaviest-first (causal imbalance).
 #include <atomic>
+#include <cstdlib>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
+#include "attention_bridge_args.hpp"
 #include "../../include/libra_hip.h"
 
 namespace libra {
@@ -27,20 +29,6 @@ constexpr int BKV = 64;            // keys per tile (two 32-key halves)
 constexpr int VAR_BYTES = 2 * BKV * BD * 2;     // one variant: K tile (16 KiB) + V tile (16 KiB)
 constexpr int STAGE_BYTES = 2 * VAR_BYTES;      // same + cross
 constexpr int BR_LDS = 2 * STAGE_BYTES + 1024;  // double buffered + key-modality masks
-
-struct BridgeArgs {
-    const bf16_t* q; long ldq;
-    const bf16_t* k_same; const bf16_t* k_cross; long ldk, ldkc;
-    const bf16_t* v_same; const bf16_t* v_cross; long ldv, ldvc;
-    const unsigned char* flag;     // [B*S] 1 = vision token
-    const int* kv_len;             // [B] end of the valid keys (right padding), or null
-    const int* kv_start;           // [B] first valid key (LEFT padding: generation prompts, demo/libra_demo.ipynb), or null
-    bf16_t* out; long ldo;
-    float* lse;                    // [B,H,S] or null
-    bf16_t* out_lo;                // optional rounding residual of `out` (same layout), see libra_bridge_attn_fwd
-    int B, S, H, n_qt;
-    float sl2;
-};
 
 // K tile image: four N-type [32 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 4 KiB each, ordered
 //               (key half, d half).  V tile image: T-type [64 keys][128 d] (256-byte rows, chunk ^ ((row&3)<<2)), 16 KiB.
@@ -372,6 +360,10 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.n_qt = (int)((S + BQ - 1) / BQ);
     a.sl2 = scale * 1.4426950408889634f;
+    // two structures of the same kernel contract: 2 = 4-wave workgroups, two per CU, register-staged single-variant units
+    // (attention_bridge_fwd2.hip, the default); 1 = the 8-wave LDS-DMA structure below.  LIBRA_ATTN_FWD selects (A/B runs).
+    static const int structure = [] { const char* e = getenv("LIBRA_ATTN_FWD"); return e && e[0] == '1' ? 1 : 2; }();
+    if (structure == 2) return bridge_attn_fwd2_launch(a, (hipStream_t)stream);
     const long nblk = (long)B * H * a.n_qt;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)

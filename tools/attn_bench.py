@@ -29,12 +29,13 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
-res = {}
-o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True)
+res = {"fwd_structure": os.environ.get("LIBRA_ATTN_FWD", "default"), "bwd_structure": os.environ.get("LIBRA_ATTN_BWD", "default")}
+o_lo = torch.empty_like(q) if os.environ.get("ATTN_LO", "1") == "1" else None      # the training step asks for the residual too
+o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True, out_lo=o_lo)
 if which in ("all", "fwd"):
-    ms = timeit(lambda: K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True))
+    ms = timeit(lambda: K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True, out_lo=o_lo))
     res["fwd_ms"] = round(ms, 3); res["fwd_TF"] = round(fl_fwd / ms / 1e9, 1)
 if which in ("all", "bwd"):
-    ms = timeit(lambda: K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag, lens, lse, B, S, H, sc))
+    ms = timeit(lambda: K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag, lens, lse, B, S, H, sc, out_lo=o_lo))
     res["bwd_ms"] = round(ms, 3); res["bwd_TF"] = round(2.5 * fl_fwd / ms / 1e9, 1)
 print(json.dumps(res))
