@@ -301,6 +301,18 @@ int libra_resample_v_u8_norm(const uint8_t* tmp, int64_t tmp_w, int64_t row0, co
                              int64_t ksize, int64_t top, int64_t left, int64_t crop, const void* lut, void* out, int64_t patch,
                              int64_t kpad, void* stream);
 
+/* ---- rank-8 bridge weight gradients -------------------------------------------------------------*/
+/* out_m[j][c] = bf16( sum_{t < N, modality(t) = m} coef[t][j] * x[t][c] ), j < ncoef (8 or 16), c < C: the weight gradients of
+ * Libra's rank-8 bridge LibraLinears (modeling_libra.py:150-189, :310-340) as one HBM pass over x instead of N = 8 GEMMs on
+ * row-compacted copies.  dB (weight_B [H, 8]): x = dkb, coef = t_k, transpose_out = 1 (out[c][j], row stride ldo >= ncoef);
+ * dA (weight_A [8, H]): x = h, coef = dt (16 columns: k rows 0-7, v rows 8-15), transpose_out = 0 (out[j][c], ldo >= C).
+ * flag [N] (1 = vision token; NULL: every token counts for out_l); out_l / out_v may be NULL.  fp32 accumulation, deterministic.
+ * workspace >= libra_rank_outer_wgrad_workspace_bytes(N, C, ncoef), 16-byte aligned. */
+size_t libra_rank_outer_wgrad_workspace_bytes(int64_t N, int64_t C, int64_t ncoef);
+int libra_rank_outer_wgrad(const void* x, int64_t ldx, const void* coef, int64_t ldcoef, int64_t ncoef, const uint8_t* flag,
+                           void* out_l, void* out_v, int64_t ldo, int transpose_out, int64_t N, int64_t C, float* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- optimizer -----------------------------------------------------------------------------------*/
 /* Fused AdamW on a flat range of n elements (the data-parallel optimizer step of the reference's recipes: AdamW via HF
  * Trainer / DeepSpeed fused Adam with bf16 + fp32 master weights, libra/configs/libra_pretrain.yaml:83-91,

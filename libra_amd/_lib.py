@@ -68,11 +68,13 @@ SIGNATURES = {
     "libra_resample_h_u8": [_P, _I64, _I64, _I64, _I64, _I, _I, _I, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_resample_v_u8_norm": [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _I64, _P],
     "libra_adamw_step": [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _F, _P],
+    "libra_rank_outer_wgrad_workspace_bytes": [_I64, _I64, _I64],
+    "libra_rank_outer_wgrad": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I, _I64, _I64, _P, C.c_size_t, _P],
     "libra_sumsq_workspace_bytes": [_I64],
     "libra_sumsq_bf16": [_P, _I64, _P, _I, _P, C.c_size_t, _P],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class LibraHipError(RuntimeError):

@@ -90,6 +90,7 @@ class PackedOperands:
         H, r, rg, I = d.hidden, d.r, d.rg, d.inter
         self.device = dev
         self.layers: List[dict] = []
+        self.arena = K.RowArena()               # zero-padded row buffers of this model's training passes (see _arows)
         self._slices: List[tuple] = []          # (dest view, source name, transposed?)
         self._keys: Dict[int, tuple] = {}
         z = lambda *shape: torch.zeros(shape, dtype=BF16, device=dev)
@@ -207,7 +208,7 @@ def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None):
             K.copy_rows(signal.reshape(N, Cs).to(BF16), vis_idx, n_v, ve, H)
         else:
             ve[:, H:].zero_()
-        ven = _rows(n_v, H + Cs, dev, sv is not None)
+        ven = _rows(n_v, H + Cs, dev, sv is not None)          # (once per step: not worth an arena slot)
         _, rstd_e = K.rmsnorm_routed(ve, sd["model.vision_signal_norm.weight"], None, None, d.eps, out=ven, save_rstd=True)
         K.gemm_nt(ven, sd["model.vision_contiguous_signal_processor.weight"], out=x, c_rows=vis_idx)
         if sv is not None:
@@ -215,9 +216,22 @@ def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None):
     return x
 
 
-def _rows(n: int, c: int, dev, save: bool):
+_ARENA: Optional["K.RowArena"] = None      # the running pass's row arena (set by forward / backward from packed.arena), or None
+_ARENA_PREFIX = ""                          # forward: "L<i>." (saved per layer) or "R." (recompute: one layer alive at a time)
+
+
+def _arows(tag: str, n: int, c: int, dev) -> torch.Tensor:
+    """[n, c] rows of a 64-row zero-padded buffer: from the pass's arena when there is one (no fill, no allocation), else fresh."""
+    if _ARENA is not None:
+        return _ARENA.rows(tag, n, c, dev)
+    return K.alloc_rows(n, c, dev)[:n]
+
+
+def _rows(n: int, c: int, dev, save: bool, tag: Optional[str] = None):
     """Compact per-modality buffer; when it will later be a reduction-major wgrad operand it needs zeroed pad rows."""
-    return K.alloc_rows(n, c, dev)[:n] if save else torch.empty((n, c), dtype=BF16, device=dev)
+    if not save:
+        return torch.empty((n, c), dtype=BF16, device=dev)
+    return _arows(_ARENA_PREFIX + tag, n, c, dev) if tag is not None and _ARENA_PREFIX else K.alloc_rows(n, c, dev)[:n]
 
 
 def positions_2d(vision_indices: torch.Tensor, d: DecDims, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -306,7 +320,7 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     if n_l:
         K.gemm_nt(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)
     if n_v:
-        t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save))      # [n_v, 3r + 64]
+        t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save, "t_ext"))      # [n_v, 3r + 64]
         t = t_ext[:, :3 * r]
         tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])          # 64 columns of the vision rows: plumbing copy
         # the three rank-r expansions share one launch (each alone is 1.2 waves of 256^2 tiles)
@@ -337,7 +351,7 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     if n_l:
         K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x)
     if n_v:
-        to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save))
+        to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save, "to"))
         K.gemm_nt(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x)
     # ---- MLP block
     h2, rstd2 = K.rmsnorm_routed(x_mid, sd[pre + "post_attention_layernorm.weight"],
@@ -346,16 +360,16 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     gu = act = tg = guv = actv = td = None
     if n_l:
         gu = K.gemm_nt(h2, pk["wgu"], a_rows=lang_idx)                                 # [n_l, 2I]
-        act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save))
+        act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save, "act"))
         if need_out:
             K.gemm_nt(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid)
     if n_v:
-        tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save))               # [n_v, 2 rg]
+        tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save, "tg"))               # [n_v, 2 rg]
         guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
         K.gemm_nt_grouped([tg[:, :rg], tg[:, rg:]], [sd[m + "vision_gate_proj.weight_B"], sd[m + "vision_up_proj.weight_B"]],
                           [guv[:, :I], guv[:, I:]])
-        actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save))
-        td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save))
+        actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save, "actv"))
+        td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save, "td"))
         if need_out:
             K.gemm_nt(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)
     if save:
@@ -458,15 +472,28 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
     x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None)
     hs = [x] if want_hidden_states else None
-    for i in range(d.layers):
-        sv = {} if save and not recompute else None
-        x_in = x
-        x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv, cache=cache,
-                          positions=positions, kv_start=starts)
-        if save:
-            saved["layers"].append(sv if not recompute else {"x": x_in})
-        if want_hidden_states:
-            hs.append(x)
+    # per-layer saved row buffers come from the model's arena unless an earlier saved forward still waits for its backward
+    global _ARENA, _ARENA_PREFIX
+    arena = getattr(packed, "arena", None) if save and not recompute else None
+    if arena is not None and arena.busy:
+        arena = None
+    try:
+        _ARENA = arena
+        for i in range(d.layers):
+            sv = {} if save and not recompute else None
+            x_in = x
+            _ARENA_PREFIX = f"L{i}." if arena is not None else ""
+            x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, lens, cos, sin, B, S, sv, cache=cache,
+                              positions=positions, kv_start=starts)
+            if save:
+                saved["layers"].append(sv if not recompute else {"x": x_in})
+            if want_hidden_states:
+                hs.append(x)
+    finally:
+        _ARENA, _ARENA_PREFIX = None, ""
+    if arena is not None:
+        arena.busy = True
+        saved["arena_owner"] = True
     if cache is not None:
         cache.flag[:, :S] = flag.view(B, S)
         cache.length = S
@@ -651,12 +678,13 @@ def _full(t: torch.Tensor) -> torch.Tensor:
     return torch.as_strided(t, (K.round_up(t.shape[0], 64), t.shape[1]), t.stride(), t.storage_offset())
 
 
-def _compact(t2d: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    """Rows `idx` of a sequence-order tensor, gathered into a 64-row-padded compact buffer (reduction-major wgrad operand)."""
+def _compact(t2d: torch.Tensor, idx: torch.Tensor, tag: Optional[str] = None) -> torch.Tensor:
+    """Rows `idx` of a sequence-order tensor, gathered into a 64-row-padded compact buffer (reduction-major wgrad operand).
+    `tag`: the backward-arena slot of this temporary (layer_backward's compacts: one slot serves every layer)."""
     n = idx.numel()
-    buf = K.alloc_rows(n, t2d.shape[1], t2d.device)
+    buf = _arows("b." + tag, n, t2d.shape[1], t2d.device) if tag is not None else K.alloc_rows(n, t2d.shape[1], t2d.device)[:n]
     K.copy_rows(t2d, idx, n, buf, 0)
-    return buf[:n]
+    return buf
 
 
 def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None, name: Optional[str] = None):
@@ -674,15 +702,16 @@ def _norm_wgrad(dy, x, rstd, flag, lang_idx, vis_idx, want_l: bool, want_v: bool
     """(dw_lang, dw_vis) bf16 of a routed RMSNorm.  When only one modality's weight is trainable (frozen-language pretraining)
     only that modality's rows are read (28 % of the tokens at the Libra-11B shape)."""
     dev = dy.device
-    dl = torch.zeros(H, dtype=torch.float32, device=dev)
-    dv = torch.zeros(H, dtype=torch.float32, device=dev)
+    acc = torch.zeros(2 * H, dtype=torch.float32, device=dev)          # [dw_lang | dw_vis]: one fill, one conversion
+    dl, dv = acc[:H], acc[H:]
     sel = None
     if want_v and not want_l:
         sel = vis_idx
     elif want_l and not want_v:
         sel = lang_idx
     K.rmsnorm_routed_wgrad(dy, x, rstd, flag, dl, dv, rows_sel=sel)
-    return K.f32_to_bf16(dl), K.f32_to_bf16(dv)
+    out = K.f32_to_bf16(acc)
+    return out[:H], out[H:]
 
 
 def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
@@ -786,18 +815,27 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     groups = want_groups(want, d.layers, () if d.pred_2d else _NO_GRAD_NAMES)
     _zero_fill(g, groups[0], sd)               # a head whose modality is absent from this batch still gets a (zero) gradient
     dp.emit_new(g, emitted)                    # heads + final norm
-    for i in range(d.layers - 1, -1, -1):
-        svi = sv["layers"][i]
-        if sv["recompute"]:                    # gradient checkpointing: rebuild this layer's activations from its input
-            x_in, svi = svi["x"], {}
-            layer_forward(sd, packed[i], i, d, x_in, flag, lang_idx, vis_idx, lens, cos, sin, B, S, svi, need_out=False,
-                          positions=sv["positions"])
-        dx = layer_backward(sd, packed[i], i, d, svi, dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w,
-                            positions=sv["positions"])
-        svi.clear()
-        sv["layers"][i] = None
-        _zero_fill(g, groups[1 + (d.layers - 1 - i)], sd)
-        dp.emit_new(g, emitted)                # data parallel: this layer's gradients start their all-reduce now
+    global _ARENA, _ARENA_PREFIX
+    arena = getattr(packed, "arena", None)
+    try:
+        _ARENA = arena                         # the layer temporaries ("b.*": one slot for all layers) and, under gradient
+        _ARENA_PREFIX = "R." if arena is not None else ""      # checkpointing, the rebuilt activations ("R.*") live in the arena
+        for i in range(d.layers - 1, -1, -1):
+            svi = sv["layers"][i]
+            if sv["recompute"]:                # gradient checkpointing: rebuild this layer's activations from its input
+                x_in, svi = svi["x"], {}
+                layer_forward(sd, packed[i], i, d, x_in, flag, lang_idx, vis_idx, lens, cos, sin, B, S, svi, need_out=False,
+                              positions=sv["positions"])
+            dx = layer_backward(sd, packed[i], i, d, svi, dx, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w,
+                                positions=sv["positions"])
+            svi.clear()
+            sv["layers"][i] = None
+            _zero_fill(g, groups[1 + (d.layers - 1 - i)], sd)
+            dp.emit_new(g, emitted)            # data parallel: this layer's gradients start their all-reduce now
+    finally:
+        _ARENA, _ARENA_PREFIX = None, ""
+        if arena is not None and sv.get("arena_owner"):
+            arena.busy = False
 
     # ---- embeddings (modeling_libra.py:625-661)
     e = sv["emb"]
@@ -878,25 +916,25 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         gu = sv["gu"]
         dact = K.gemm_nt(dx_out, sd[m + "down_proj.weight"], b_t=True, a_rows=lang_idx)                 # [n_l, I]
         if w(m + "down_proj.weight"):
-            g[m + "down_proj.weight"] = _wg(_compact(dx_out, lang_idx), sv["act"], name=m + "down_proj.weight")
-        dgu = K.alloc_rows(n_l, 2 * I, dev)[:n_l]
+            g[m + "down_proj.weight"] = _wg(_compact(dx_out, lang_idx, "dxo_l"), sv["act"], name=m + "down_proj.weight")
+        dgu = _arows("b.dgu", n_l, 2 * I, dev)
         K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         K.gemm_nt(dgu, pk["wgu"], b_t=True, out=dh2, c_rows=lang_idx)
         if any_l([m + "gate_proj.weight", m + "up_proj.weight"]):
-            dwgu = _wg(dgu, _compact(h2, lang_idx))
+            dwgu = _wg(dgu, _compact(h2, lang_idx, "h2_l"))
             g[m + "gate_proj.weight"], g[m + "up_proj.weight"] = dwgu[:I], dwgu[I:]
     if n_v:
         tg, guv, actv, td = sv["tg"], sv["guv"], sv["actv"], sv["td"]
-        dxo_v = _compact(dx_out, vis_idx)
-        dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=K.alloc_rows(n_v, r, dev)[:n_v])
+        dxo_v = _compact(dx_out, vis_idx, "dxo_v")
+        dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=_arows("b.dtd", n_v, r, dev))
         if w(m + "vision_down_proj.weight_B"):
             g[m + "vision_down_proj.weight_B"] = _wg(dxo_v, td, name=m + "vision_down_proj.weight_B")
         dactv = K.gemm_nt(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True)                            # [n_v, I]
         if w(m + "vision_down_proj.weight_A"):
             g[m + "vision_down_proj.weight_A"] = _wg(dtd, actv, name=m + "vision_down_proj.weight_A")
-        dguv = K.alloc_rows(n_v, 2 * I, dev)[:n_v]
+        dguv = _arows("b.dguv", n_v, 2 * I, dev)
         K.swiglu_bwd(dactv, guv[:, :I], guv[:, I:], dguv[:, :I], dguv[:, I:])
-        dtg = K.alloc_rows(n_v, 2 * rg, dev)[:n_v]
+        dtg = _arows("b.dtg", n_v, 2 * rg, dev)
         K.gemm_nt_grouped([dguv[:, :I], dguv[:, I:]], [sd[m + "vision_gate_proj.weight_B"], sd[m + "vision_up_proj.weight_B"]],
                           [dtg[:, :rg], dtg[:, rg:]], b_t=True)
         if w(m + "vision_gate_proj.weight_B"):
@@ -905,7 +943,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
             g[m + "vision_up_proj.weight_B"] = _wg(dguv[:, I:], tg[:, rg:], name=m + "vision_up_proj.weight_B")
         K.gemm_nt(dtg, pk["agu"], b_t=True, out=dh2, c_rows=vis_idx)
         if any_l([m + "vision_gate_proj.weight_A", m + "vision_up_proj.weight_A"]):
-            dagu = _wg(dtg, _compact(h2, vis_idx))
+            dagu = _wg(dtg, _compact(h2, vis_idx, "h2_v"))
             g[m + "vision_gate_proj.weight_A"], g[m + "vision_up_proj.weight_A"] = dagu[:rg], dagu[rg:]
     ln_l, ln_v = pre + "post_attention_layernorm.weight", pre + "vision_post_attention_layernorm.weight"
     dx_mid = K.rmsnorm_routed_bwd(dh2, sv["x_mid"], sd[ln_l], sd[ln_v], flag, sv["rstd2"], dres=dx_out)
@@ -918,15 +956,15 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     if n_l:
         K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do)
         if w(a + "o_proj.weight"):
-            g[a + "o_proj.weight"] = _wg(_compact(dx_mid, lang_idx), _compact(o, lang_idx), name=a + "o_proj.weight")
+            g[a + "o_proj.weight"] = _wg(_compact(dx_mid, lang_idx, "dxm_l"), _compact(o, lang_idx, "o_l"), name=a + "o_proj.weight")
     if n_v:
-        dxm_v = _compact(dx_mid, vis_idx)
-        dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=K.alloc_rows(n_v, r, dev)[:n_v])
+        dxm_v = _compact(dx_mid, vis_idx, "dxm_v")
+        dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=_arows("b.dto", n_v, r, dev))
         if w(a + "vision_o_proj.weight_B"):
             g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"], name=a + "vision_o_proj.weight_B")
         K.gemm_nt(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx)
         if w(a + "vision_o_proj.weight_A"):
-            g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx), name=a + "vision_o_proj.weight_A")
+            g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx, "o_v"), name=a + "vision_o_proj.weight_A")
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
     dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
                                                sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5, out_lo=sv["o_lo"])
@@ -940,37 +978,52 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     dvb = dvc
     # rank-8 bridges: kb = B_k[m] t_k, vb = B_v[m] t_v, t = [A_k[m]; A_v[m]] h
     h = sv["h"]
-    for idx, which in ((lang_idx, "language"), (vis_idx, "vision")):
-        if idx.numel() == 0:
-            continue
-        nk, nv = a + f"vision_k_bridge_on_{which}.weight_B", a + f"vision_v_bridge_on_{which}.weight_B"
-        if w(nk) or w(nv):
-            tbc = _compact(tb, idx)
-            if w(nk):
-                g[nk] = _wg(_compact(dkb, idx), tbc[:, 0:8], post=lambda o: o[:, :d.rank].contiguous())
-            if w(nv):
-                g[nv] = _wg(_compact(dvb, idx), tbc[:, 8:16], post=lambda o: o[:, :d.rank].contiguous())
+    bnames = {kv: [a + f"vision_{kv}_bridge_on_{which}.weight_B" for which in ("language", "vision")] for kv in "kv"}
+    if d.rank == 8:
+        # dB[m][c][j] = sum_{t in m} dkb[t][c] t_k[t][j]: one pass over dkb / dvb for both modalities (libra_rank_outer_wgrad)
+        for kv, xg, col0 in (("k", dkb, 0), ("v", dvb, 8)):
+            nl_, nv_ = bnames[kv]
+            if w(nl_) or w(nv_):
+                gl_, gv_ = K.rank_outer_wgrad(xg, tb[:, col0:col0 + 8], flag, transpose_out=True, want_l=w(nl_), want_v=w(nv_))
+                if w(nl_):
+                    g[nl_] = gl_
+                if w(nv_):
+                    g[nv_] = gv_
+    else:
+        for wi, (idx, which) in enumerate(((lang_idx, "language"), (vis_idx, "vision"))):
+            if idx.numel() == 0:
+                continue
+            nk, nv = bnames["k"][wi], bnames["v"][wi]
+            if w(nk) or w(nv):
+                tbc = _compact(tb, idx, "tb_" + which)
+                if w(nk):
+                    g[nk] = _wg(_compact(dkb, idx, "dkb_" + which), tbc[:, 0:8], post=lambda o: o[:, :d.rank].contiguous())
+                if w(nv):
+                    g[nv] = _wg(_compact(dvb, idx, "dvb_" + which), tbc[:, 8:16], post=lambda o: o[:, :d.rank].contiguous())
     dh = torch.empty((N, H), dtype=BF16, device=dev)
     if n_l:
         K.gemm_nt(dqkvt, pk["wqkv_ab"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)       # K = 3H + 64
         nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
         if any_l([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]):
-            hl = _compact(h, lang_idx)
-            dw, gk, gv = _wg(_compact(dqkvt, lang_idx), hl,                              # [3H + 64, H]
+            hl = _compact(h, lang_idx, "h_l")
+            dw, gk, gv = _wg(_compact(dqkvt, lang_idx, "dqkvt_l"), hl,                              # [3H + 64, H]
                              post=lambda o: (o, o[3 * H:3 * H + d.rank].contiguous(), o[3 * H + 8:3 * H + 8 + d.rank].contiguous()))
             for j, nm in enumerate(("q", "k", "v")):
                 g[a + f"{nm}_proj.weight"] = dw[j * H:(j + 1) * H]
             if w(nk) or w(nv):
                 g[nk], g[nv] = gk, gv
-        elif w(nk) or w(nv):                                   # frozen language projections (pretraining): bridge A's only
-            hl = _compact(h, lang_idx)
-            g[nk], g[nv] = _wg(_compact(dtb, lang_idx), hl,                                  # [64, H]
+        elif (w(nk) or w(nv)) and d.rank == 8:                 # frozen language projections (pretraining): bridge A's only -
+            # dA[j][c] = sum_{text t} dt[t][j] h[t][c], j = (k: 0-7, v: 8-15): one pass over h, no compacted copy of it
+            ga, _ = K.rank_outer_wgrad(h, dtb[:, 0:16], flag, transpose_out=False, want_l=True, want_v=False)
+            g[nk], g[nv] = ga[0:8], ga[8:16]
+        elif w(nk) or w(nv):
+            hl = _compact(h, lang_idx, "h_l")
+            g[nk], g[nv] = _wg(_compact(dtb, lang_idx, "dtb_l"), hl,                                  # [64, H]
                                post=lambda o: (o[0:d.rank].contiguous(), o[8:8 + d.rank].contiguous()))
     if n_v:
         t = sv["t"]
-        dqkv_v = _compact(dqkv, vis_idx)                                                    # [n_v, 3H]
-        dt_buf = K.alloc_rows(n_v, 3 * r + 64, dev)                  # [dt_q | dt_k | dt_v | dt_bridge], mirrors the forward's t_ext
-        dt_ext = dt_buf[:n_v]
+        dqkv_v = _compact(dqkv, vis_idx, "dqkv_v")                                                    # [n_v, 3H]
+        dt_ext = _arows("b.dt_ext", n_v, 3 * r + 64, dev)            # [dt_q | dt_k | dt_v | dt_bridge], mirrors the forward's t_ext
         dt = dt_ext[:, :3 * r]
         K.gemm_nt_grouped([dqkv_v[:, j * H:(j + 1) * H] for j in range(3)],
                           [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
@@ -978,12 +1031,12 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         for j, nm in enumerate(("q", "k", "v")):
             if w(a + f"vision_{nm}_proj.weight_B"):
                 g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r], name=a + f"vision_{nm}_proj.weight_B")
-        K.copy_rows(dtb, vis_idx, n_v, dt_buf, 3 * r)                # the vision rows' 64 bridge columns
+        K.copy_rows(dtb, vis_idx, n_v, dt_ext, 3 * r)                # the vision rows' 64 bridge columns
         K.gemm_nt(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx)                   # K = 3r + 64
         nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
         want_a = any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"])
         if want_a or w(nk) or w(nv):
-            hv = _compact(h, vis_idx)
+            hv = _compact(h, vis_idx, "h_v")
             da, gk, gv = _wg(dt_ext, hv,                                                   # [3r + 64, H]
                              post=lambda o: (o, o[3 * r:3 * r + d.rank].contiguous(), o[3 * r + 8:3 * r + 8 + d.rank].contiguous()))
             if want_a:

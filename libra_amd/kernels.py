@@ -46,6 +46,35 @@ def alloc_rows(rows: int, cols: int, device) -> torch.Tensor:
     return buf
 
 
+class RowArena:
+    """Reusable zero-padded row buffers for one model: `rows(tag, n, c)` behaves like `alloc_rows(n, c)[:n]` but hands out the
+    SAME storage for the same tag every time, so the pad rows are zeroed once instead of once per call (the decoder step made
+    ~800 five-microsecond fill launches for them, and the caching allocator round trips on top).  Only for buffers whose lifetime
+    is bounded by the caller's own schedule: per-layer temporaries of a backward (one tag serves all layers, the stream orders
+    the reuse) and per-layer saved activations (one tag per layer, reused by the next step)."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.busy = False          # a saved forward that has not met its backward yet owns the per-layer tags
+
+    def rows(self, tag: str, rows: int, cols: int, device) -> torch.Tensor:
+        rp = round_up(rows, 64)
+        key = (tag, cols)
+        ent = self.bufs.get(key)
+        if ent is None or ent[0].shape[0] < rp or ent[0].device != torch.device(device):
+            buf = torch.zeros((rp, cols), dtype=BF16, device=device)
+            self.bufs[key] = [buf, rows]
+            return buf[:rows]
+        buf, hi = ent
+        if hi > rows:
+            buf[rows:hi].zero_()                         # a shorter use after a longer one: its tail is pad again
+        ent[1] = rows
+        return buf[:rows]
+
+    def nbytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b, _ in self.bufs.values())
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, quick_gelu: bool = False,
             qgelu_grad_of: Optional[torch.Tensor] = None, preact_out: Optional[torch.Tensor] = None,
@@ -686,6 +715,27 @@ def rmsnorm_routed_wgrad(dy, x, rstd, flag, dw_lang, dw_vis, *, rows_sel=None):
                                                _ptr(flag), _ptr(dw_lang), _ptr(dw_vis), ws.data_ptr(), nbytes, rows, D,
                                                _ptr(rows_sel), rows_sel.numel() if rows_sel is not None else 0, _stream())
     _lib.check(rc, "rmsnorm_routed_wgrad")
+
+
+def rank_outer_wgrad(x, coef, flag, *, transpose_out: bool, want_l: bool = True, want_v: bool = True):
+    """(out_l, out_v): out_m[j][c] = sum over the tokens of modality m of coef[t][j] * x[t][c]  (bf16, fp32 accumulation).
+    x [N, C], coef [N, 8 or 16] (a column slice is fine), flag uint8 [N] or None.  transpose_out: out_m is [C, ncoef] (weight_B
+    layout) instead of [ncoef, C] (weight_A layout).  The rank-8 bridge weight gradients in one pass over x."""
+    _chk2d(x, "x"); _chk2d(coef, "coef")
+    N, Cc = x.shape
+    nc = coef.shape[1]
+    if coef.shape[0] != N or nc not in (8, 16):
+        raise ValueError(f"rank_outer_wgrad: coef must be [N, 8] or [N, 16], got {tuple(coef.shape)} for x {tuple(x.shape)}")
+    shape = (Cc, nc) if transpose_out else (nc, Cc)
+    out_l = torch.empty(shape, dtype=BF16, device=x.device) if want_l else None
+    out_v = torch.empty(shape, dtype=BF16, device=x.device) if want_v else None
+    nbytes = _lib.lib().libra_rank_outer_wgrad_workspace_bytes(max(N, 1), Cc, nc)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().libra_rank_outer_wgrad(x.data_ptr(), x.stride(0), coef.data_ptr(), coef.stride(0), nc, _ptr(flag), _ptr(out_l),
+                                           _ptr(out_v), nc if transpose_out else Cc, int(transpose_out), N, Cc, ws.data_ptr(), nbytes,
+                                           _stream())
+    _lib.check(rc, "rank_outer_wgrad")
+    return out_l, out_v
 
 
 def swiglu_bwd(dy, gate, up, dgate, dup):

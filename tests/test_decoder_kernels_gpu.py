@@ -399,3 +399,29 @@ def test_bridge_attention_decode(K, B, H, Lmax, mode):
     ref = torch.einsum("bhl,blhd->bhd", torch.softmax(s, -1), vv).reshape(B, D)
     close(out, ref, rel=2e-3, what="bridge decode attention")
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("N,C,nc,tr", [(300, 256, 8, True), (16384, 4096, 8, True), (1000, 512, 16, False), (16384, 4096, 16, False),
+                                       (77, 264, 8, False)])
+def test_rank_outer_wgrad(K, N, C, nc, tr):
+    """libra_rank_outer_wgrad (the rank-8 bridge weight gradients as one pass over x) vs fp32 math on the same bf16 inputs:
+    out_m[j][c] = sum over the tokens of modality m of coef[t][j] x[t][c]; column-sliced coef, both layouts, ragged sizes."""
+    x = rnd(N, C, seed=1)
+    wide = rnd(N, 64, seed=2)
+    coef = wide[:, 8:8 + nc] if nc == 8 else wide[:, 0:16]
+    flag = _flags(N, 4, "span" if N > 500 else "random").cuda()
+    ol, ov = K.rank_outer_wgrad(x, coef, flag, transpose_out=tr)
+    f = flag.bool().cpu()
+    xf, cf = x.float().cpu(), coef.float().cpu()
+    rl, rv = cf[~f].t() @ xf[~f], cf[f].t() @ xf[f]
+    if tr:
+        rl, rv = rl.t(), rv.t()
+    close(ol, rl, rel=2e-3, what="rank outer wgrad (text)")
+    close(ov, rv, rel=2e-3, what="rank outer wgrad (vision)")
+    ol2, ov2 = K.rank_outer_wgrad(x, coef, flag, transpose_out=tr)
+    assert torch.equal(ol, ol2) and torch.equal(ov, ov2)                       # deterministic
+    only_l, none_v = K.rank_outer_wgrad(x, coef, flag, transpose_out=tr, want_v=False)
+    assert none_v is None and torch.equal(only_l, ol)
+    al, _ = K.rank_outer_wgrad(x, coef, None, transpose_out=tr, want_v=False)   # no flag: every token counts for out_l
+    ra = cf.t() @ xf
+    close(al, ra.t() if tr else ra, rel=2e-3, what="rank outer wgrad (no flag)")
