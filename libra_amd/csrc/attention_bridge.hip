@@ -363,9 +363,8 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     // two structures of the same kernel contract: 1 = the 8-wave LDS-DMA structure below (default: equal at S = 2048, 25 % faster at
     // S = 700, profiles/r03_attn_fwd_anatomy.md); 2 = 4-wave workgroups, two per CU, register-staged single-variant units
     // (attention_bridge_fwd2.hip).  LIBRA_ATTN_FWD selects (A/B runs, the timing-anatomy builds live in structure 2).
-    static const int structure = [] { const char* e = getenv("LIBRA_ATTN_FWD"); return e && e[0] >= '2' && e[0] <= '4' ? e[0] - '0' : 1; }();
+    static const int structure = [] { const char* e = getenv("LIBRA_ATTN_FWD"); return e && e[0] == '2' ? 2 : 1; }();
     if (structure == 2) return bridge_attn_fwd2_launch(a, (hipStream_t)stream);
-    if (structure >= 3) return bridge_attn_fwd3_launch(a, (hipStream_t)stream, structure == 4);     // 3: software-pipelined, 4: + sched_group_barrier
     const long nblk = (long)B * H * a.n_qt;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)

@@ -21,6 +21,5 @@ struct BridgeArgs {
 };
 
 int bridge_attn_fwd2_launch(BridgeArgs a, hipStream_t stream);      // attention_bridge_fwd2.hip
-int bridge_attn_fwd3_launch(BridgeArgs a, hipStream_t stream, int sgb);
 
 }  // namespace libra
