@@ -918,6 +918,9 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         if w(m + "down_proj.weight"):
             g[m + "down_proj.weight"] = _wg(_compact(dx_out, lang_idx, "dxo_l"), sv["act"], name=m + "down_proj.weight")
         dgu = _arows("b.dgu", n_l, 2 * I, dev)
+        # (SwiGLU' as an epilogue of the dgrad above was built and measured: the 256^2 kernel's un-overlapped epilogue moves the
+        #  extra 3 tiles of traffic slower than this HBM-rate kernel does - +13.3 ms of GEMM for 9.5 ms of row kernel per step;
+        #  profiles/r03_fusion_ab.txt)
         K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         K.gemm_nt(dgu, pk["wgu"], b_t=True, out=dh2, c_rows=lang_idx)
         if any_l([m + "gate_proj.weight", m + "up_proj.weight"]):
