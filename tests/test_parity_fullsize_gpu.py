@@ -188,6 +188,19 @@ def test_vq_indices_at_baseline_batch_vs_fp64_oracle():
     nflip, nidx = int(flip.sum()), int(((bits64.long() * pw).sum(-1) != idx).sum())
     mflip = float(x64.abs().view(N, Q, 9)[flip].max()) if nflip else 0.0
     min_margin = float(x64.abs().min())
+    # ---- the other side: the reference's OWN arithmetic - the oracle executed op by op in bf16 (bf16 Linear outputs,
+    # a bf16 pre-sign value) on the same tower features - against the same float64 chain, and against ours
+    sdb = {k: v.cuda() for k, v in sd.items()}
+    with torch.no_grad():
+        _, _, idx_b, _, _ = QO.vq_encode(sdb, feat.view(32, 24, 24, 2048).permute(0, 3, 1, 2).contiguous(), num_codebooks=Q, codebook_dim=9)
+    idx_b = idx_b.reshape(N, Q).to(idx.device)
+    bits_b = ((idx_b.unsqueeze(-1) >> torch.arange(8, -1, -1, device="cuda")) & 1).bool()
+    n_theirs = int((bits_b != bits64).sum())
+    n_ours_theirs = int((bits_b != got_bits).sum())
+    parity_report(f"[configs[1] VQ encode B=32 E=512, two-sided] sign-bit flips vs the float64 chain: ours {nflip}, the reference's bf16 "
+                  f"arithmetic (oracle op by op in bf16) {n_theirs}; ours vs theirs {n_ours_theirs} of {N * Q * 9} bits "
+                  f"({int((idx_b != idx).sum())} of {N * Q} indices)")
+    assert n_ours_theirs <= max(8, 2 * n_theirs + 4), (n_ours_theirs, n_theirs)
     parity_report(f"[configs[1] VQ encode B=32 E=512] {N * Q * 9} sign bits: stage A (h rounding) {nA} of {h2d.numel()} elements "
                   f"differ from bf16(h64), all within fp32 accumulation noise of a rounding boundary; stage B (bits on the kernel's own h) {nB} flips, max margin "
                   f"{mB:.2e}; end-to-end vs float64 chain: {nflip} bit flips in {nidx} of {N * Q} indices, largest |x64| among "
