@@ -178,16 +178,29 @@ int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, co
                           const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                           int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, const int* positions,
                           int64_t pos_stride, int64_t H, void* stream);
+/* Append the new token of every sequence to a layer's four caches (the reference's `torch.cat` of past and present key / value
+ * states, modeling_libra.py:344-361) in one launch: cache_x[b][*slot][0..W) = x[b][0..W) for x in (K_same, K_cross, V_same,
+ * V_cross); x [B, W] with row strides ld_x, caches [B, Lmax, W] with row / batch strides in elements, slot = the position,
+ * read on the device (one int64): the decode step stays capturable in a hipGraph. */
+int libra_kv_cache_append(const void* k_same, int64_t ld_ks, const void* k_cross, int64_t ld_kc, const void* v_same, int64_t ld_vs,
+                          const void* v_cross, int64_t ld_vc, void* cache_k_same, void* cache_k_cross, void* cache_v_same,
+                          void* cache_v_cross, int64_t row_stride, int64_t batch_stride, const int64_t* slot, int64_t B, int64_t W,
+                          void* stream);
 /* Routed-bridge attention of ONE new query token per sequence against the KV cache (LibraAttention.forward with
  * past_key_value, modeling_libra.py:344-391, at q_len = 1).  The reference's cache ([K_for_vision, K_for_language], V,
  * V_bridge, flag) is held as the four row buffers the training path produces - K_same, K_cross, V_same, V_cross
  * [B, Lmax, H*128] bf16 (row stride ldc, batch stride batch_stride elements) - plus key_flag [B, Lmax] (row stride
  * flag_stride): key j uses the *_cross buffers iff key_flag[b][j] != query_flag[b].  q, out [B, H*128]; kv_len[b] = number
- * of valid cached tokens including the new one; scale = 1/sqrt(128).                                                       */
+ * of valid cached tokens including the new one; scale = 1/sqrt(128).
+ * workspace (fp32, 16-byte aligned, >= libra_bridge_attn_decode_workspace_bytes(B, H)) or NULL: with it the cached keys of
+ * every (sequence, head) are split over 4 workgroups whose partial softmax states a second kernel folds (4x the loads in
+ * flight: the B x H workgroups of the unsplit launch fill a quarter of the chip); without it one workgroup per (sequence, head). */
+size_t libra_bridge_attn_decode_workspace_bytes(int64_t B, int64_t H);
 int libra_bridge_attn_decode(const void* q, int64_t ldq, const void* k_same, const void* k_cross, const void* v_same,
                              const void* v_cross, int64_t ldc, int64_t batch_stride, const uint8_t* key_flag,
                              int64_t flag_stride, const uint8_t* query_flag, const int* kv_len, const int* kv_start,
-                             void* out, int64_t ldo, int64_t B, int64_t H, float scale, void* stream);
+                             void* out, int64_t ldo, int64_t B, int64_t H, float scale, float* workspace,
+                             size_t workspace_bytes, void* stream);
 /* Fused routed-bridge causal flash attention, forward (LibraAttention.forward + attn_with_bridge,
  * modeling_libra.py:267-414):  S_ij = q_i.(k_j + [m_i!=m_j] kb_j)/sqrt(d) (+causal, +right padding via
  * kv_len[b] = end of the valid keys, +left padding via kv_start[b] = first valid key; either may be NULL), O_i = sum_j softmax(S)_ij (v_j + [m_i!=m_j] vb_j).  Operands are [B*S, H*128] views with row

@@ -43,7 +43,10 @@ SIGNATURES = {
     "libra_rmsnorm_routed_fwd": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _F, _P],
     "libra_rope_bridge": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "libra_rope_bridge_pos": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, _P],
-    "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P],
+    "libra_kv_cache_append": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P],
+    "libra_bridge_attn_decode_workspace_bytes": [_I64, _I64],
+    "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P,
+                                 C.c_size_t, _P],
     "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _P],
     "libra_bridge_attn_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
                               _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
@@ -74,7 +77,7 @@ SIGNATURES = {
     "libra_sumsq_bf16": [_P, _I64, _P, _I, _P, C.c_size_t, _P],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class LibraHipError(RuntimeError):

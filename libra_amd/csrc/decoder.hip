@@ -262,6 +262,28 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const bf16_t* __restrict__
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH; }
 
+// Append one new token per sequence to the four K/V caches of a layer in ONE launch (the decode step made four index_copy
+// launches per layer for it).  src_x [B, W] (row strides ld_x), cache_x [B, Lmax, W] (row / batch strides), slot = the cache
+// position, read from device memory so that the step stays free of host-side indices (hipGraph capture).
+struct KvAppendArgs {
+    const bf16_t* src[4]; long ld[4];
+    bf16_t* dst[4];
+    long row_stride, batch_stride;
+    const long long* slot;
+    int B, W;
+};
+__global__ __launch_bounds__(256) void kv_cache_append_kernel(const KvAppendArgs p) {
+    const int b = blockIdx.x, which = blockIdx.y;
+    const long long s = p.slot[0];
+    const bf16_t* src = p.src[0]; long ld = p.ld[0]; bf16_t* dst = p.dst[0];
+    if (which == 1) { src = p.src[1]; ld = p.ld[1]; dst = p.dst[1]; }
+    else if (which == 2) { src = p.src[2]; ld = p.ld[2]; dst = p.dst[2]; }
+    else if (which == 3) { src = p.src[3]; ld = p.ld[3]; dst = p.dst[3]; }
+    const bf16_t* sr = src + (long)b * ld;
+    bf16_t* dr = dst + (long)b * p.batch_stride + s * p.row_stride;
+    for (int c = threadIdx.x * 8; c < p.W; c += 256 * 8) *(u32x4*)(dr + c) = *(const u32x4*)(sr + c);
+}
+
 }  // namespace libra
 
 using namespace libra;
@@ -368,5 +390,27 @@ extern "C" int libra_ce_rows(const void* logits, int64_t ldz, int64_t V, const i
     hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)logits, (long)ldz, (int)V, (const long long*)target, (long long)target_sub, loss_rows,
                        (long)rows);
+    return launched();
+}
+
+extern "C" int libra_kv_cache_append(const void* k_same, int64_t ld_ks, const void* k_cross, int64_t ld_kc, const void* v_same,
+                                     int64_t ld_vs, const void* v_cross, int64_t ld_vc, void* cache_k_same, void* cache_k_cross,
+                                     void* cache_v_same, void* cache_v_cross, int64_t row_stride, int64_t batch_stride,
+                                     const int64_t* slot, int64_t B, int64_t W, void* stream) {
+    if (B <= 0) return LIBRA_OK;
+    if (W <= 0 || (W % 8) || ld_ks < W || ld_kc < W || ld_vs < W || ld_vc < W || row_stride < W || batch_stride < row_stride ||
+        (ld_ks % 8) || (ld_kc % 8) || (ld_vs % 8) || (ld_vc % 8) || (row_stride % 8) || (batch_stride % 8) || B > 65535)
+        return LIBRA_ERR_SHAPE;
+    if (!k_same || !k_cross || !v_same || !v_cross || !cache_k_same || !cache_k_cross || !cache_v_same || !cache_v_cross || !slot)
+        return LIBRA_ERR_ALIGN;
+    if (!al16(k_same) || !al16(k_cross) || !al16(v_same) || !al16(v_cross) || !al16(cache_k_same) || !al16(cache_k_cross) ||
+        !al16(cache_v_same) || !al16(cache_v_cross))
+        return LIBRA_ERR_ALIGN;
+    KvAppendArgs a;
+    a.src[0] = (const bf16_t*)k_same; a.src[1] = (const bf16_t*)k_cross; a.src[2] = (const bf16_t*)v_same; a.src[3] = (const bf16_t*)v_cross;
+    a.ld[0] = ld_ks; a.ld[1] = ld_kc; a.ld[2] = ld_vs; a.ld[3] = ld_vc;
+    a.dst[0] = (bf16_t*)cache_k_same; a.dst[1] = (bf16_t*)cache_k_cross; a.dst[2] = (bf16_t*)cache_v_same; a.dst[3] = (bf16_t*)cache_v_cross;
+    a.row_stride = row_stride; a.batch_stride = batch_stride; a.slot = (const long long*)slot; a.B = (int)B; a.W = (int)W;
+    hipLaunchKernelGGL(kv_cache_append_kernel, dim3((unsigned)B, 4), dim3(256), 0, (hipStream_t)stream, a);
     return launched();
 }

@@ -45,19 +45,34 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyArgs p) {
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[c][m] = 0.f;
-    for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
-        u32x4 a[MR], w[NC];
+    // Weight rows are streamed once by exactly one wave: non-temporal loads (they should not displace A in the caches), and the
+    // chunk of the NEXT 512 reduction elements is requested before the dot products of the current one - the round-2 loop issued
+    // its loads, waited for all of them and only then computed: the memory pipe idled through every compute phase (3.3 TB/s).
+    const bf16_t* wrow[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int n = n0 + c < p.N ? n0 + c : p.N - 1;                        // clamped columns are computed and dropped
+        wrow[c] = p.B + (long)n * p.ldb;
+    }
+    u32x4 w[NC];
+    int k0 = lane * 8;
+    if (k0 < p.K) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) w[c] = __builtin_nontemporal_load((const u32x4*)(wrow[c] + k0));
+    }
+    for (; k0 < p.K; k0 += 512) {
+        u32x4 a[MR], wn[NC];
 #pragma unroll
         for (int m = 0; m < MR; ++m) a[m] = *(const u32x4*)(p.A + arow[m] + k0);
+        const int k1 = k0 + 512 < p.K ? k0 + 512 : k0;                        // (the last pass re-requests its own chunk: no branch)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int n = n0 + c < p.N ? n0 + c : p.N - 1;                  // clamped columns are computed and dropped
-            w[c] = *(const u32x4*)(p.B + (long)n * p.ldb + k0);
-        }
+        for (int c = 0; c < NC; ++c) wn[c] = __builtin_nontemporal_load((const u32x4*)(wrow[c] + k1));
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int m = 0; m < MR; ++m) acc[c][m] = dot8(w[c], a[m], acc[c][m]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) w[c] = wn[c];
     }
     // 16 sums at a time: v[16] = (MR = 8: two columns x 8 rows | MR = 16: one column x 16 rows); afterwards lane row rho
     // (lane >> 4) holds the totals of v[e + 4 rho] in rs[e]

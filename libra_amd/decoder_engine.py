@@ -331,12 +331,13 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
         kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
     else:
         kc, vc = K.rope_bridge_pos(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, positions, d.heads)
-    if cache is not None:                                   # plumbing copies into the cache slots
-        for buf, rows in zip(cache.layers[i], (qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc)):
-            if slot is None:
-                buf[:, :S].copy_(rows.view(B, S, H))
-            else:
-                buf.index_copy_(1, slot, rows.view(B, 1, H))
+    if cache is not None:                                   # the cache slots
+        new_rows = (qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc)
+        if slot is None:
+            for buf, rows in zip(cache.layers[i], new_rows):
+                buf[:, :S].copy_(rows.view(B, S, H))         # prefill: plumbing copies
+        else:
+            K.kv_cache_append(new_rows, cache.layers[i], slot)                # decode step: the four appends in one launch
     if slot is None:
         o_lo = torch.empty((N, H), dtype=BF16, device=dev) if save else None   # rounding residual of o (the backward's D = dO.O)
         o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,

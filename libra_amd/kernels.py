@@ -598,12 +598,33 @@ def bridge_attn_decode(q, k_same, k_cross, v_same, v_cross, key_flag, query_flag
     if kv_start is not None and (kv_start.dtype != torch.int32 or kv_start.numel() != B):
         raise ValueError("bridge_attn_decode: kv_start must be int32 [B]")
     out = torch.empty((B, H * 128), dtype=BF16, device=q.device)
+    nbytes = _lib.lib().libra_bridge_attn_decode_workspace_bytes(B, H)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)      # partial states of the key splits
     rc = _lib.lib().libra_bridge_attn_decode(q.data_ptr(), q.stride(0), k_same.data_ptr(), k_cross.data_ptr(), v_same.data_ptr(),
                                              v_cross.data_ptr(), k_same.stride(1), k_same.stride(0), key_flag.data_ptr(),
                                              key_flag.stride(0), query_flag.data_ptr(), kv_len.data_ptr(), _ptr(kv_start),
-                                             out.data_ptr(), out.stride(0), B, H, float(scale), _stream())
+                                             out.data_ptr(), out.stride(0), B, H, float(scale), ws.data_ptr(), nbytes, _stream())
     _lib.check(rc, "bridge_attn_decode")
     return out
+
+
+def kv_cache_append(rows, caches, slot: torch.Tensor):
+    """caches[x][b, slot] = rows[x][b] for the four K/V buffers of a layer (one launch).  rows: four [B, W] bf16 tensors (column
+    slices allowed), caches: four [B, Lmax, W] buffers with identical strides, slot: int64 device tensor [1]."""
+    B, W = rows[0].shape
+    c0 = caches[0]
+    for r in rows:
+        _chk2d(r, "kv_cache_append rows")
+    for c in caches:
+        if c.dim() != 3 or c.shape[0] != B or c.shape[2] != W or c.stride(2) != 1 or c.dtype != BF16 or c.stride() != c0.stride():
+            raise ValueError("kv_cache_append: caches must be [B, Lmax, W] bf16 with identical strides")
+    if slot.dtype != torch.int64 or slot.numel() != 1 or not slot.is_cuda:
+        raise ValueError("kv_cache_append: slot must be a cuda int64 tensor with one element")
+    rc = _lib.lib().libra_kv_cache_append(rows[0].data_ptr(), rows[0].stride(0), rows[1].data_ptr(), rows[1].stride(0),
+                                          rows[2].data_ptr(), rows[2].stride(0), rows[3].data_ptr(), rows[3].stride(0),
+                                          caches[0].data_ptr(), caches[1].data_ptr(), caches[2].data_ptr(), caches[3].data_ptr(),
+                                          c0.stride(1), c0.stride(0), slot.data_ptr(), B, W, _stream())
+    _lib.check(rc, "kv_cache_append")
 
 
 def bridge_attn_fwd(q, k_same, k_cross, v_same, v_cross, flag, kv_len, B: int, S: int, H: int, scale: float, *,

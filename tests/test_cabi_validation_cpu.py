@@ -66,8 +66,11 @@ def test_generation_entry_points_argument_validation(L):
     def call(**kw):
         a = dict(ok, **kw)
         return L.libra_bridge_attn_decode(a["q"], a["ldq"], a["ks"], a["kc"], a["vs"], a["vc"], a["ldc"], a["bs"], a["kf"], a["fs"],
-                                          a["qf"], a["kl"], a.get("kstart"), a["out"], a["ldo"], a["B"], a["H"], 128 ** -0.5, None)
+                                          a["qf"], a["kl"], a.get("kstart"), a["out"], a["ldo"], a["B"], a["H"], 128 ** -0.5,
+                                          a.get("ws"), a.get("wsb", 0), None)
     assert call(ldc=128) == ERR_SHAPE
+    assert call(ws=FAKE, wsb=16) == ERR_ALIGN                          # a workspace smaller than the key-split partial states
+    assert L.libra_bridge_attn_decode_workspace_bytes(2, 2) == 2 * 2 * 4 * 132 * 4
     assert call(bs=64) == ERR_SHAPE
     assert call(kc=None) == ERR_ALIGN
     assert call(ks=P(0x10008)) == ERR_ALIGN

@@ -425,3 +425,19 @@ def test_rank_outer_wgrad(K, N, C, nc, tr):
     al, _ = K.rank_outer_wgrad(x, coef, None, transpose_out=tr, want_v=False)   # no flag: every token counts for out_l
     ra = cf.t() @ xf
     close(al, ra.t() if tr else ra, rel=2e-3, what="rank outer wgrad (no flag)")
+
+
+def test_kv_cache_append(K):
+    """libra_kv_cache_append: the four per-layer cache appends of a decode step in one launch == four index_copy_ calls."""
+    B, W, Lmax = 3, 256, 11
+    wide = rnd(B, 3 * W + 64, seed=1)
+    rows = (wide[:, W:2 * W], rnd(B, W, seed=2), wide[:, 2 * W:3 * W], rnd(B, W, seed=3))
+    caches = [rnd(B, Lmax, W, seed=10 + i) for i in range(4)]
+    ref = [c.clone() for c in caches]
+    slot = torch.tensor([7], dtype=torch.int64, device="cuda")
+    K.kv_cache_append(rows, caches, slot)
+    for c, r, x in zip(caches, ref, rows):
+        r.index_copy_(1, slot, x.reshape(B, 1, W))
+        assert torch.equal(c, r)
+    with pytest.raises(ValueError):
+        K.kv_cache_append(rows, caches, torch.tensor([7], dtype=torch.int32, device="cuda"))

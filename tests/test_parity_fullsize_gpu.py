@@ -190,9 +190,9 @@ def test_vq_indices_at_baseline_batch_vs_fp64_oracle():
     min_margin = float(x64.abs().min())
     # ---- the other side: the reference's OWN arithmetic - the oracle executed op by op in bf16 (bf16 Linear outputs,
     # a bf16 pre-sign value) on the same tower features - against the same float64 chain, and against ours
-    sdb = {k: v.cuda() for k, v in sd.items()}
-    with torch.no_grad():
-        _, _, idx_b, _, _ = QO.vq_encode(sdb, feat.view(32, 24, 24, 2048).permute(0, 3, 1, 2).contiguous(), num_codebooks=Q, codebook_dim=9)
+    with torch.no_grad():                                   # (on the host: the oracle builds its bit weights on the CPU)
+        _, _, idx_b, _, _ = QO.vq_encode({k: v.cpu() for k, v in sd.items()},
+                                         feat.view(32, 24, 24, 2048).permute(0, 3, 1, 2).contiguous().cpu(), num_codebooks=Q, codebook_dim=9)
     idx_b = idx_b.reshape(N, Q).to(idx.device)
     bits_b = ((idx_b.unsqueeze(-1) >> torch.arange(8, -1, -1, device="cuda")) & 1).bool()
     n_theirs = int((bits_b != bits64).sum())
