@@ -23,12 +23,13 @@ constexpr int RW_CHUNK = 4 * RW_TOK;         // tokens per workgroup (4 waves wa
 // LDS once (a token's coefficients are then a broadcast ds_read, not a vector memory load per lane); each wave streams its 64
 // tokens with U x-loads in flight per lane, accumulates NC x COLS x 2 (modality) fp32 sums, and the four waves are folded through
 // LDS in a fixed order before ONE partial per workgroup is written: partials ws[chunk][m][j][c].
-template <int NC, int COLS>
+// MODS = 2: both modalities' sums; MODS = 1: only modality `only` is wanted (half the accumulators: twice the columns per lane)
+template <int NC, int COLS, int MODS>
 __global__ __launch_bounds__(RW_THREADS) void rank_outer_partial_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                         const bf16_t* __restrict__ coef, long ldc,
                                                                         const unsigned char* __restrict__ flag, long N, int C,
-                                                                        float* __restrict__ ws) {
-    constexpr int ACC = 2 * NC * COLS;                         // accumulators per lane
+                                                                        float* __restrict__ ws, int only) {
+    constexpr int ACC = MODS * NC * COLS;                      // accumulators per lane
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * ACC * 4 > RW_CHUNK * (NC * 2 + 4) ? 2 * 64 * ACC * 4 : RW_CHUNK * (NC * 2 + 4)];
     bf16_t* scoef = (bf16_t*)lds;                              // [RW_CHUNK][NC]
     unsigned* sflag = (unsigned*)(lds + RW_CHUNK * NC * 2);    // [RW_CHUNK]
@@ -47,11 +48,11 @@ __global__ __launch_bounds__(RW_THREADS) void rank_outer_partial_kernel(const bf
         sflag[tid] = f;
     }
     __syncthreads();
-    float al[NC][COLS], av[NC][COLS];
+    float al[NC][COLS], av[MODS == 2 ? NC : 1][COLS];        // (MODS = 1: `al` carries the wanted modality, `av` is unused)
 #pragma unroll
     for (int j = 0; j < NC; ++j)
 #pragma unroll
-        for (int e = 0; e < COLS; ++e) { al[j][e] = 0.f; av[j][e] = 0.f; }
+        for (int e = 0; e < COLS; ++e) { al[j][e] = 0.f; if (MODS == 2) av[j][e] = 0.f; }
     const bool col_ok = c0 < C;
     const long t0 = tb + wave * RW_TOK;
     long t1 = t0 + RW_TOK; t1 = t1 < N ? t1 : N;
@@ -79,7 +80,14 @@ __global__ __launch_bounds__(RW_THREADS) void rank_outer_partial_kernel(const bf
 #pragma unroll
                     for (int j8 = 0; j8 < NC / 8; ++j8) unpack8(*(const u32x4*)(scoef + ti * NC + j8 * 8), cf + j8 * 8);   // broadcast read
                     const bool vis = __builtin_amdgcn_readfirstlane((int)sflag[ti]) != 0;
-                    if (vis) {
+                    if (MODS == 1) {
+                        if ((vis ? 1 : 0) == only) {
+#pragma unroll
+                            for (int j = 0; j < NC; ++j)
+#pragma unroll
+                                for (int e = 0; e < COLS; ++e) al[j][e] = __builtin_fmaf(cf[j], xv[u][e], al[j][e]);
+                        }
+                    } else if (vis) {
 #pragma unroll
                         for (int j = 0; j < NC; ++j)
 #pragma unroll
@@ -101,14 +109,14 @@ __global__ __launch_bounds__(RW_THREADS) void rank_outer_partial_kernel(const bf
 #pragma unroll
         for (int j = 0; j < NC; ++j)
 #pragma unroll
-            for (int e = 0; e < COLS; ++e) { r[(j * COLS + e) * 64] = al[j][e]; r[((NC + j) * COLS + e) * 64] = av[j][e]; }
+            for (int e = 0; e < COLS; ++e) { r[(j * COLS + e) * 64] = al[j][e]; if (MODS == 2) r[((NC + j) * COLS + e) * 64] = av[j][e]; }
     };
     auto add = [&](int slot) {
         const float* r = red + slot * 64 * ACC + lane;
 #pragma unroll
         for (int j = 0; j < NC; ++j)
 #pragma unroll
-            for (int e = 0; e < COLS; ++e) { al[j][e] += r[(j * COLS + e) * 64]; av[j][e] += r[((NC + j) * COLS + e) * 64]; }
+            for (int e = 0; e < COLS; ++e) { al[j][e] += r[(j * COLS + e) * 64]; if (MODS == 2) av[j][e] += r[((NC + j) * COLS + e) * 64]; }
     };
     __syncthreads();                                            // everyone is done with the staged coefficients
     if (wave >= 2) put(wave - 2);
@@ -119,15 +127,15 @@ __global__ __launch_bounds__(RW_THREADS) void rank_outer_partial_kernel(const bf
     __syncthreads();
     if (wave == 0 && col_ok) {
         add(0);
-        float* w = ws + (long)blockIdx.y * 2 * NC * C;
+        float* w = ws + (long)blockIdx.y * 2 * NC * C + (MODS == 1 ? (long)only * NC * C : 0);
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             if constexpr (COLS == 4) {
                 *(f32x4*)(w + (long)j * C + c0) = f32x4{al[j][0], al[j][1], al[j][2], al[j][3]};
-                *(f32x4*)(w + (long)(NC + j) * C + c0) = f32x4{av[j][0], av[j][1], av[j][2], av[j][3]};
+                if (MODS == 2) *(f32x4*)(w + (long)(NC + j) * C + c0) = f32x4{av[j][0], av[j][1], av[j][2], av[j][3]};
             } else {
                 *(float2*)(w + (long)j * C + c0) = float2{al[j][0], al[j][1]};
-                *(float2*)(w + (long)(NC + j) * C + c0) = float2{av[j][0], av[j][1]};
+                if (MODS == 2) *(float2*)(w + (long)(NC + j) * C + c0) = float2{av[j][0], av[j][1]};
             }
         }
     }
@@ -142,8 +150,9 @@ __global__ __launch_bounds__(256) void rank_outer_final_kernel(const float* __re
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + lane;                  // over (m, j, c)
     const long per = (long)NC * C;
+    const bool wanted = i < 2 * per && ((i < per ? out_l : out_v) != nullptr);       // (an unwanted half was never written)
     float s = 0.f;
-    if (i < 2 * per)
+    if (wanted)
         for (int k = grp; k < chunks; k += 4) s += ws[(long)k * 2 * per + i];
     red[grp][lane] = s;
     __syncthreads();
@@ -189,12 +198,17 @@ extern "C" int libra_rank_outer_wgrad(const void* x, int64_t ldx, const void* co
         if (ncoef == 8) {
             if ((C % 4) || (ldx % 4)) return LIBRA_ERR_SHAPE;
             const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)chunks);
-            hipLaunchKernelGGL((rank_outer_partial_kernel<8, 4>), grid, dim3(RW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
-                               (long)ldx, (const bf16_t*)coef, (long)ldcoef, flag, (long)N, (int)C, workspace);
+            hipLaunchKernelGGL((rank_outer_partial_kernel<8, 4, 2>), grid, dim3(RW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (long)ldx, (const bf16_t*)coef, (long)ldcoef, flag, (long)N, (int)C, workspace, 0);
+        } else if ((out_l == nullptr) != (out_v == nullptr) && (C % 4) == 0 && (ldx % 4) == 0) {
+            // one modality wanted (the frozen-language recipe's bridge A gradients): half the accumulators, 4 columns per lane
+            const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)chunks);
+            hipLaunchKernelGGL((rank_outer_partial_kernel<16, 4, 1>), grid, dim3(RW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (long)ldx, (const bf16_t*)coef, (long)ldcoef, flag, (long)N, (int)C, workspace, out_v ? 1 : 0);
         } else {
             const dim3 grid((unsigned)((C / 2 + 63) / 64), (unsigned)chunks);
-            hipLaunchKernelGGL((rank_outer_partial_kernel<16, 2>), grid, dim3(RW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
-                               (long)ldx, (const bf16_t*)coef, (long)ldcoef, flag, (long)N, (int)C, workspace);
+            hipLaunchKernelGGL((rank_outer_partial_kernel<16, 2, 2>), grid, dim3(RW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (long)ldx, (const bf16_t*)coef, (long)ldcoef, flag, (long)N, (int)C, workspace, 0);
         }
         if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     }
