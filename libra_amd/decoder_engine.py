@@ -40,6 +40,7 @@ class DecDims:
     unified_head: bool = False     # config.unified_head (:1054-1064)
     pred_2d: bool = False          # config.vision_prediction_mode == "2d" (:942-1014)
     res: int = 0                   # config.image_feature_resolution (max_vision_len == res * res + 2)
+    bridge: bool = True            # config.use_bridge (:258); False: no bridge parameters, K_cross = K_same, V_cross = V_same
 
     @property
     def r(self):
@@ -103,16 +104,20 @@ class PackedOperands:
                 self._slices.append((L["aqkv_ab"][j * r:(j + 1) * r], a + f"vision_{nm}_proj.weight_A", False))
             # the rank-8 bridge A's ride along as 64 extra output rows of the q/k/v projection of their modality: one GEMM
             # produces [q | k | v | t_k t_v 0...] (and one dgrad / wgrad GEMM handles both in the backward)
+            # use_bridge = False: the same operand layout with the bridge rows / matrices left at zero (kb = vb = 0, so the kernels
+            # compute plain routed attention; the configuration is in neither recipe and is not separately tuned)
             for key, which, base in (("wqkv_ab", "language", 3 * H), ("aqkv_ab", "vision", 3 * r)):
-                self._slices.append((L[key][base:base + d.rank], a + f"vision_k_bridge_on_{which}.weight_A", False))
-                self._slices.append((L[key][base + 8:base + 8 + d.rank], a + f"vision_v_bridge_on_{which}.weight_A", False))
+                if d.bridge:
+                    self._slices.append((L[key][base:base + d.rank], a + f"vision_k_bridge_on_{which}.weight_A", False))
+                    self._slices.append((L[key][base + 8:base + 8 + d.rank], a + f"vision_v_bridge_on_{which}.weight_A", False))
             for kv in ("k", "v"):
                 for which, tag in (("language", "l"), ("vision", "v")):
                     b, bT = z(H, 8), z(8, H)      # B [H, rank] and the same transposed [8, H]: the backward takes
                     L[f"b{kv}_{tag}"], L[f"b{kv}T_{tag}"] = b, bT       # B^T dkb / B^T dvb with v_dot2 over channel pairs
                     src = a + f"vision_{kv}_bridge_on_{which}.weight_B"
-                    self._slices.append((b[:, :d.rank], src, False))
-                    self._slices.append((bT[:d.rank], src, True))
+                    if d.bridge:
+                        self._slices.append((b[:, :d.rank], src, False))
+                        self._slices.append((bT[:d.rank], src, True))
             for j, nm in enumerate(("gate", "up")):
                 self._slices.append((L["wgu"][j * I:(j + 1) * I], m + f"{nm}_proj.weight", False))
                 self._slices.append((L["agu"][j * rg:(j + 1) * rg], m + f"vision_{nm}_proj.weight_A", False))

@@ -5,7 +5,7 @@ LibraDecoderLayer :416-435, LibraModel :524-600, MultiLMHead :834-843, LibraForC
 The sub-modules only own the parameters (same names and shapes as the reference checkpoints: SURVEY §8b); the
 compute is the kernel schedule in ``libra_amd/decoder_engine.py`` (forward and hand-written backward, exposed to
 autograd through one ``torch.autograd.Function``), parity-tested against the reference fixtures.
-Built: use_bridge, concat + norm signals, dropout 0, with 1d or 2d RoPE (`use_2d_rope`), routed or unified heads
+Built: use_bridge on / off, concat + norm signals, dropout 0, with 1d or 2d RoPE (`use_2d_rope`), routed or unified heads
 (`unified_head`), 1d or 2d vision prediction (`vision_prediction_mode`); anything else raises NotImplementedError rather
 than silently diverging.
 """
@@ -61,9 +61,10 @@ class LibraAttention(_EngineOwned):        # modeling_libra.py:245-265 (+ LlamaA
             setattr(self, n, nn.Linear(H, H, bias=False))
         for n in ("vision_q_proj", "vision_k_proj", "vision_v_proj", "vision_o_proj"):
             setattr(self, n, LibraLinear(H, H, down_ratio=c.vision_down_ratio))
-        for n in ("vision_v_bridge_on_language", "vision_v_bridge_on_vision", "vision_k_bridge_on_language",
-                  "vision_k_bridge_on_vision"):
-            setattr(self, n, LibraLinear(H, H, rank=c.bridge_rank))
+        if c.use_bridge:                   # :258 - without the bridge the layer is plain routed attention (no such parameters)
+            for n in ("vision_v_bridge_on_language", "vision_v_bridge_on_vision", "vision_k_bridge_on_language",
+                      "vision_k_bridge_on_vision"):
+                setattr(self, n, LibraLinear(H, H, rank=c.bridge_rank))
 
 
 class LibraMLP(_EngineOwned):              # modeling_libra.py:208-238 (+ LlamaMLP modeling_llama.py:185-201)
@@ -153,10 +154,10 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
     def __init__(self, config: LibraConfig):
         super().__init__(config)
         c = config
-        if (not c.use_bridge or not c.concat_signals or not c.norm_signals or c.addition_mode
+        if (not c.concat_signals or not c.norm_signals or c.addition_mode
                 or c.use_vision_position_embedding or c.vision_prediction_mode not in ("1d", "2d")):
-            raise NotImplementedError("built: bridge on, concat + norm signals, 1d / 2d prediction, 1d / 2d RoPE, routed / unified "
-                                      "heads; not built: use_bridge=False, addition_mode, un-normed / un-concatenated signals, "
+            raise NotImplementedError("built: bridge on / off, concat + norm signals, 1d / 2d prediction, 1d / 2d RoPE, routed / "
+                                      "unified heads; not built: addition_mode, un-normed / un-concatenated signals, "
                                       "use_vision_position_embedding (DESIGN.md §7 row f4)")
         pred_2d = c.vision_prediction_mode == "2d"
         if pred_2d and c.unified_head:
@@ -182,7 +183,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                                 codebooks=c.vision_codebook_num, max_vision_len=c.max_vision_token_length,
                                 signal=c.contiguous_signal_size, rank=c.bridge_rank, down_ratio=c.vision_down_ratio,
                                 eps=c.rms_norm_eps, max_pos=c.max_position_embeddings, rope_2d=bool(c.use_2d_rope),
-                                unified_head=bool(c.unified_head), pred_2d=pred_2d, res=int(c.image_feature_resolution))
+                                unified_head=bool(c.unified_head), pred_2d=pred_2d, res=int(c.image_feature_resolution),
+                                bridge=bool(c.use_bridge))
         self._packed: Optional[DE.PackedOperands] = None
         self.post_init()
 

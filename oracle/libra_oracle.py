@@ -118,10 +118,13 @@ def attention(sd, pre, x, flag, mask, position_ids, heads: int, cos, sin) -> tor
     q = routed(x, flag, lambda t: F.linear(t, sd[pre + "q_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_q_proj."))
     k = routed(x, flag, lambda t: F.linear(t, sd[pre + "k_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_k_proj."))
     v = routed(x, flag, lambda t: F.linear(t, sd[pre + "v_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_v_proj."))
-    kb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_language."),
-                lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_vision."))
-    vb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_v_bridge_on_language."),
-                lambda t: libra_linear(t, sd, pre + "vision_v_bridge_on_vision."))
+    if pre + "vision_k_bridge_on_language.weight_A" in sd:
+        kb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_language."),
+                    lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_vision."))
+        vb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_v_bridge_on_language."),
+                    lambda t: libra_linear(t, sd, pre + "vision_v_bridge_on_vision."))
+    else:                                          # config.use_bridge = False (:258, :311-317, :394): plain routed attention
+        kb, vb = torch.zeros_like(k), torch.zeros_like(v)
     # the reference adds the bridge to K *before* RoPE and rotates both variants (:320-340); RoPE is linear, so
     # rope(k + kb) = rope(k) + rope(kb) up to rounding — keep the reference's order of operations.
     k_cross = k + kb
@@ -290,8 +293,11 @@ def attention_step(sd, pre, x, flag, cache: Optional[dict], position_ids, key_va
     q = routed(x, flag, lin("q_proj"), low("vision_q_proj"))
     k = routed(x, flag, lin("k_proj"), low("vision_k_proj"))
     v = routed(x, flag, lin("v_proj"), low("vision_v_proj"))
-    kb = routed(x, flag, low("vision_k_bridge_on_language"), low("vision_k_bridge_on_vision"))
-    vb = routed(x, flag, low("vision_v_bridge_on_language"), low("vision_v_bridge_on_vision"))
+    if pre + "vision_k_bridge_on_language.weight_A" in sd:
+        kb = routed(x, flag, low("vision_k_bridge_on_language"), low("vision_k_bridge_on_vision"))
+        vb = routed(x, flag, low("vision_v_bridge_on_language"), low("vision_v_bridge_on_vision"))
+    else:                                          # use_bridge = False
+        kb, vb = torch.zeros_like(k), torch.zeros_like(v)
     hd = lambda t: t.view(B, q_len, heads, d).transpose(1, 2)
     q, k_same, k_cross, v, vb = hd(q), hd(k), hd(k + kb), hd(v), hd(vb)
     q = apply_rope(q, cos, sin, position_ids)

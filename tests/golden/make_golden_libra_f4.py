@@ -1,6 +1,6 @@
 """Golden fixtures for the alternative decoder configurations from the REFERENCE's own LibraForCausalLM:
-`use_2d_rope` (modeling_libra.py:43-49, :576-587, :663-678), `unified_head` (:1054-1064) and `vision_prediction_mode="2d"`
-(:942-1014), each on libra_tiny's inputs and weights (the 2d-prediction heads have their own [18, 2*256] weights, stored).
+`use_2d_rope` (modeling_libra.py:43-49, :576-587, :663-678), `unified_head` (:1054-1064), `vision_prediction_mode="2d"`
+(:942-1014) and `use_bridge=False` (:258, :311-317, :394), each on libra_tiny's inputs and weights (the 2d-prediction heads have their own [18, 2*256] weights, stored).
 Stored per variant: loss, final hidden state, logits, and the reference autograd's gradients of a sample of parameters.
 Build-container only (imports /root/reference through ref_harness)."""
 import os
@@ -29,11 +29,14 @@ def main():
     ids, am, vi, sig, labels = t0["in.input_ids"], t0["in.attention_mask"], t0["in.vision_indices"], t0["in.signal"], t0["in.labels"]
     out_t, meta = {}, dict(cfg=mg.TINY, variants={})
     for name, over in (("rope2d", dict(use_2d_rope=True)), ("unified", dict(unified_head=True)),
-                       ("pred2d", dict(vision_prediction_mode="2d")), ("rope2d_pred2d", dict(use_2d_rope=True, vision_prediction_mode="2d"))):
+                       ("pred2d", dict(vision_prediction_mode="2d")), ("rope2d_pred2d", dict(use_2d_rope=True, vision_prediction_mode="2d")),
+                       ("nobridge", dict(use_bridge=False))):
         cfg = cfgm.LibraConfig(**dict(mg.TINY, **over))
         torch.manual_seed(0)
         model = ml.LibraForCausalLM(cfg).eval()
         sd = dict(w)
+        if over.get("use_bridge") is False:                               # :258 - the layer has no bridge parameters at all
+            sd = {k: v for k, v in sd.items() if "_bridge_on_" not in k}
         if over.get("vision_prediction_mode") == "2d":                    # heads take cat(up, left): [Vv, 2 * hidden]
             g = torch.Generator().manual_seed(17)
             for q in range(2):
@@ -50,7 +53,7 @@ def main():
         out_t[f"{name}.logits"] = out.logits.detach()
         grads = dict(model.named_parameters())
         for n in SAMPLE:
-            if grads[n].grad is not None:
+            if n in grads and grads[n].grad is not None:
                 out_t[f"{name}.grad.{n}"] = grads[n].grad.detach().clone()
         if over.get("vision_prediction_mode") == "2d":
             for q in range(2):
