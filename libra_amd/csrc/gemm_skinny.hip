@@ -29,10 +29,16 @@ __device__ __forceinline__ float dot8(const u32x4 a, const u32x4 b, float c) {
     return c;
 }
 
-// MR = rows held per lane (8 or 16), NC = columns per wave (MR * NC = 64 accumulators)
-template <int MR, int NC>
-__global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyArgs p) {
-    const int lane = threadIdx.x;
+// MR = rows held per lane (8 or 16), NC = columns per workgroup (MR * NC = 64 accumulators per lane), KS = waves per workgroup:
+// the waves of a workgroup take every KS-th 512-element pass of the SAME NC columns and their sums are folded through LDS.
+// [Round 3: one wave per 8 columns gave N / 8 waves - 512 for the o / down projections, two per CU - each walking K serially
+//  with an exposed L2 round trip for its A chunk per pass: 1.6-2.8 TB/s on the N = 4096 shapes.  Splitting K over the waves of a
+//  workgroup multiplies the loads in flight by KS and shortens every wave's serial chain to K / (512 KS) passes.]
+template <int MR, int NC, int KS>
+__global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const SkinnyArgs p) {
+    __shared__ float red[KS > 1 ? KS : 1][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * NC;
     long arow[MR];
 #pragma unroll
@@ -55,16 +61,17 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyArgs p) {
         wrow[c] = p.B + (long)n * p.ldb;
     }
     u32x4 w[NC];
-    int k0 = lane * 8;
+    int k0 = (wave * 64 + lane) * 8;
+    constexpr int KSTEP = 512 * KS;
     if (k0 < p.K) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) w[c] = __builtin_nontemporal_load((const u32x4*)(wrow[c] + k0));
     }
-    for (; k0 < p.K; k0 += 512) {
+    for (; k0 < p.K; k0 += KSTEP) {
         u32x4 a[MR], wn[NC];
 #pragma unroll
         for (int m = 0; m < MR; ++m) a[m] = *(const u32x4*)(p.A + arow[m] + k0);
-        const int k1 = k0 + 512 < p.K ? k0 + 512 : k0;                        // (the last pass re-requests its own chunk: no branch)
+        const int k1 = k0 + KSTEP < p.K ? k0 + KSTEP : k0;                    // (the last pass re-requests its own chunk: no branch)
 #pragma unroll
         for (int c = 0; c < NC; ++c) wn[c] = __builtin_nontemporal_load((const u32x4*)(wrow[c] + k1));
 #pragma unroll
@@ -75,7 +82,8 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyArgs p) {
         for (int c = 0; c < NC; ++c) w[c] = wn[c];
     }
     // 16 sums at a time: v[16] = (MR = 8: two columns x 8 rows | MR = 16: one column x 16 rows); afterwards lane row rho
-    // (lane >> 4) holds the totals of v[e + 4 rho] in rs[e]
+    // (lane >> 4) holds the totals of v[e + 4 rho] in rs[e].  With KS > 1 every wave parks its 64 lane-reduced sums in LDS
+    // (slot = c * MR + m) and wave 0 folds the waves in index order before the single bf16 rounding.
     constexpr int CPG = 16 / MR;                                              // columns per group of 16 sums
 #pragma unroll
     for (int c = 0; c < NC; c += CPG) {
@@ -87,13 +95,32 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const SkinnyArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int idx = e + 4 * (lane >> 4);
-                const int n = n0 + c + idx / MR, m = idx % MR;
-                if (m < p.M && n < p.N) {
-                    const long crow = p.c_rows ? p.c_rows[m] : m;
-                    float r = rs[e];
-                    if (p.resid) r += bf2f(p.resid[crow * p.ldr + n]);
-                    p.C[crow * p.ldc + n] = f2bf(r);
+                const int cc = c + idx / MR, m = idx % MR;
+                if (KS > 1) {
+                    red[wave][cc * MR + m] = rs[e];
+                } else {
+                    const int n = n0 + cc;
+                    if (m < p.M && n < p.N) {
+                        const long crow = p.c_rows ? p.c_rows[m] : m;
+                        float r = rs[e];
+                        if (p.resid) r += bf2f(p.resid[crow * p.ldr + n]);
+                        p.C[crow * p.ldc + n] = f2bf(r);
+                    }
                 }
+            }
+        }
+    }
+    if (KS > 1) {
+        __syncthreads();
+        if (wave == 0) {                                                      // lane = c * MR + m
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) r += red[k][lane];
+            const int n = n0 + lane / MR, m = lane % MR;
+            if (m < p.M && n < p.N) {
+                const long crow = p.c_rows ? p.c_rows[m] : m;
+                if (p.resid) r += bf2f(p.resid[crow * p.ldr + n]);
+                p.C[crow * p.ldc + n] = f2bf(r);
             }
         }
     }
@@ -111,9 +138,18 @@ extern "C" int libra_gemm_skinny_launch_(const void* A, int64_t lda, const void*
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C; p.resid = (const bf16_t*)resid;
     p.a_rows = a_rows; p.c_rows = c_rows; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
-    if (M <= 8)
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, 8>), dim3((unsigned)((N + 7) / 8)), dim3(64), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((gemm_skinny_kernel<16, 4>), dim3((unsigned)((N + 3) / 4)), dim3(64), 0, (hipStream_t)stream, p);
+    // waves per workgroup: enough workgroup-waves to cover the chip ~4 times over, never more K slices than 512-element passes
+    const long groups = M <= 8 ? (N + 7) / 8 : (N + 3) / 4;
+    const long passes = (K + 511) / 512;
+    int ks = 1;
+    while (ks < 8 && groups * ks < 4096 && ks * 2 <= passes) ks *= 2;
+    const dim3 grid((unsigned)groups);
+#define LIBRA_SKINNY(MR_, NC_, KS_) hipLaunchKernelGGL((gemm_skinny_kernel<MR_, NC_, KS_>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, p)
+    if (M <= 8) {
+        if (ks == 1) LIBRA_SKINNY(8, 8, 1); else if (ks == 2) LIBRA_SKINNY(8, 8, 2); else if (ks == 4) LIBRA_SKINNY(8, 8, 4); else LIBRA_SKINNY(8, 8, 8);
+    } else {
+        if (ks == 1) LIBRA_SKINNY(16, 4, 1); else if (ks == 2) LIBRA_SKINNY(16, 4, 2); else if (ks == 4) LIBRA_SKINNY(16, 4, 4); else LIBRA_SKINNY(16, 4, 8);
+    }
+#undef LIBRA_SKINNY
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
