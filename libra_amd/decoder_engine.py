@@ -41,6 +41,11 @@ class DecDims:
     pred_2d: bool = False          # config.vision_prediction_mode == "2d" (:942-1014)
     res: int = 0                   # config.image_feature_resolution (max_vision_len == res * res + 2)
     bridge: bool = True            # config.use_bridge (:258); False: no bridge parameters, K_cross = K_same, V_cross = V_same
+    concat: bool = True            # config.concat_signals (:556-562); False: processor(signal) is ADDED to the embeddings (:753-754)
+    norm_sig: bool = True          # config.norm_signals (with concat): RMSNorm over [codebook embeddings | signal] (:558, :641-644)
+    vis_pos: bool = False          # config.use_vision_position_embedding (:564-566, :636-638)
+    addition: bool = False         # config.addition_mode (cal_language_vision :111-127): the q / k / v / o language projections run on
+                                   # EVERY row and the vision low-rank projections are added on the vision rows (MLP, norms, bridges stay routed)
 
     @property
     def r(self):
@@ -191,33 +196,58 @@ def route(vision_indices: torch.Tensor, attention_mask: torch.Tensor, d: DecDims
             first.contiguous() if left else None)
 
 
-def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None):
-    """get_inputs_embeds_from_multicodebook (modeling_libra.py:625-661) -> x [N, H]."""
+def embed(sd, d: DecDims, input_ids, flag, lang_idx, vis_idx, signal, sv=None, vision_indices=None):
+    """get_inputs_embeds_from_multicodebook (modeling_libra.py:625-661) -> x [N, H].  The recipes' configuration (signal
+    concatenated to the codebook embeddings, RMSNorm, one Linear) is the tuned path; `norm_sig` False skips the norm, `concat`
+    False projects the signal on its own and adds it to every row (:753-754), `vis_pos` adds a learned embedding of the in-image
+    index to the codebook embeddings (:636-638; `vision_indices` [B, S] int64 then needed)."""
     Q, B, S = input_ids.shape
     N, H = B * S, d.hidden
     dev = input_ids.device
     x = torch.empty((N, H), dtype=BF16, device=dev)
     ids0 = input_ids[0].reshape(-1)
     n_l, n_v = lang_idx.numel(), vis_idx.numel()
+    save = sv is not None
     if n_l:
         tmp = torch.empty((n_l, H), dtype=BF16, device=dev)
         K.gather_rows(sd["model.embed_tokens.weight"], ids0, 0, lang_idx, n_l, tmp, 0)
         x.index_copy_(0, lang_idx.long(), tmp)              # plumbing copy; language rows only
+    Cs = d.signal
     if n_v:
-        Cs = d.signal
-        ve = torch.empty((n_v, H + Cs), dtype=BF16, device=dev)
+        # codebook embeddings [n_v, H]: straight into their final place unless the position embedding has to be added first
+        ve = (K.alloc_rows(n_v, H + Cs, dev)[:n_v] if save and not d.norm_sig else torch.empty((n_v, H + Cs), dtype=BF16, device=dev)) \
+            if d.concat else None
+        direct = ve if (d.concat and not d.vis_pos) else torch.empty((n_v, H), dtype=BF16, device=dev)
         for q in range(Q):
-            K.gather_rows(sd[f"model.vision_embed_tokens.{q}.weight"], input_ids[q].reshape(-1), d.vocab, vis_idx, n_v, ve,
+            K.gather_rows(sd[f"model.vision_embed_tokens.{q}.weight"], input_ids[q].reshape(-1), d.vocab, vis_idx, n_v, direct,
                           q * (H // Q))
-        if signal is not None:
-            K.copy_rows(signal.reshape(N, Cs).to(BF16), vis_idx, n_v, ve, H)
+        if d.vis_pos:
+            pe = torch.empty((n_v, H), dtype=BF16, device=dev)
+            K.gather_rows(sd["model.vision_position_embedding.weight"], vision_indices.reshape(-1), 0, vis_idx, n_v, pe, 0)
+            K.add_(direct, pe)                              # bf16 add, as the reference's `vision_concat + vision_position_embedding`
+            if d.concat:
+                K.copy_rows(direct, None, n_v, ve, 0)
+        if d.concat:
+            if signal is not None:
+                K.copy_rows(signal.reshape(N, Cs).to(BF16), vis_idx, n_v, ve, H)
+            else:
+                ve[:, H:].zero_()
+            rstd_e = None
+            if d.norm_sig:
+                ven = _rows(n_v, H + Cs, dev, save)             # (once per step: not worth an arena slot)
+                _, rstd_e = K.rmsnorm_routed(ve, sd["model.vision_signal_norm.weight"], None, None, d.eps, out=ven, save_rstd=True)
+            else:
+                ven = ve
+            K.gemm_nt(ven, sd["model.vision_contiguous_signal_processor.weight"], out=x, c_rows=vis_idx)
+            if save:
+                sv.update(ve=ve, ven=ven, rstd_e=rstd_e)
         else:
-            ve[:, H:].zero_()
-        ven = _rows(n_v, H + Cs, dev, sv is not None)          # (once per step: not worth an arena slot)
-        _, rstd_e = K.rmsnorm_routed(ve, sd["model.vision_signal_norm.weight"], None, None, d.eps, out=ven, save_rstd=True)
-        K.gemm_nt(ven, sd["model.vision_contiguous_signal_processor.weight"], out=x, c_rows=vis_idx)
-        if sv is not None:
-            sv.update(ve=ve, ven=ven, rstd_e=rstd_e)
+            x.index_copy_(0, vis_idx.long(), direct)        # plumbing copy; vision rows
+    if not d.concat and signal is not None:                 # inputs_embeds + processor(contiguous_signal), every position (:753-754)
+        sig2 = signal.reshape(N, Cs).to(BF16).contiguous()
+        K.gemm_nt(sig2, sd["model.vision_contiguous_signal_processor.weight"], out=x, resid=x)
+        if save:
+            sv.update(sig_all=sig2)
     return x
 
 
@@ -322,16 +352,23 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     qkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)       # [q | k | v | bridge low-rank activations t_k t_v 0..]
     qkv, tb = qkvt[:, :3 * H], qkvt[:, 3 * H:]
     t = None
-    if n_l:
+    if d.addition:
+        K.gemm_nt(h, pk["wqkv_ab"], out=qkvt)                        # language projections (+ language bridge A) on every row
+    elif n_l:
         K.gemm_nt(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)
     if n_v:
         t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save, "t_ext"))      # [n_v, 3r + 64]
         t = t_ext[:, :3 * r]
-        tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])          # 64 columns of the vision rows: plumbing copy
-        # the three rank-r expansions share one launch (each alone is 1.2 waves of 256^2 tiles)
-        K.gemm_nt_grouped([t[:, j * r:(j + 1) * r] for j in range(3)],
-                          [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
-                          [qkv[:, j * H:(j + 1) * H] for j in range(3)], c_rows=vis_idx)
+        tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])          # 64 columns of the vision rows: plumbing copy (the bridges stay routed)
+        if d.addition:                                               # language[vis] + vision (:126): accumulate on the vision rows
+            for j, nm in enumerate(("q", "k", "v")):
+                col = qkv[:, j * H:(j + 1) * H]
+                K.gemm_nt(t[:, j * r:(j + 1) * r], sd[a + f"vision_{nm}_proj.weight_B"], out=col, c_rows=vis_idx, resid=col)
+        else:
+            # the three rank-r expansions share one launch (each alone is 1.2 waves of 256^2 tiles)
+            K.gemm_nt_grouped([t[:, j * r:(j + 1) * r] for j in range(3)],
+                              [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
+                              [qkv[:, j * H:(j + 1) * H] for j in range(3)], c_rows=vis_idx)
     if positions is None:
         kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
     else:
@@ -354,11 +391,13 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
                                       (H // d.heads) ** -0.5, kv_start=kv_start), None
     x_mid = torch.empty_like(x)
     to = None
-    if n_l:
+    if d.addition:
+        K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, resid=x)    # every row
+    elif n_l:
         K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x)
     if n_v:
         to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save, "to"))
-        K.gemm_nt(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x)
+        K.gemm_nt(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x_mid if d.addition else x)
     # ---- MLP block
     h2, rstd2 = K.rmsnorm_routed(x_mid, sd[pre + "post_attention_layernorm.weight"],
                                  sd[pre + "vision_post_attention_layernorm.weight"], flag, d.eps, save_rstd=True)
@@ -476,7 +515,7 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     check_ids(input_ids, flag.view(B, S).bool(), d)
     cos, sin = rope_tables(d.hidden // d.heads, rope_rows(d, S), dev)
     saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
-    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None)
+    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None, vision_indices=vision_indices)
     hs = [x] if want_hidden_states else None
     # per-layer saved row buffers come from the model's arena unless an earlier saved forward still waits for its backward
     global _ARENA, _ARENA_PREFIX
@@ -544,7 +583,8 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
         loss = loss / Q
     if save:
         saved.update(x_last=x, rstd_f=rstd_f, hidden=hidden, tgts=tgts, counts=counts, cos=cos, sin=sin, lens=lens, B=B, S=S,
-                     Q=Q, input_ids=input_ids, positions=positions, unified=unified, src2d=src2d, feats=feats)
+                     Q=Q, input_ids=input_ids, positions=positions, unified=unified, src2d=src2d, feats=feats,
+                     vision_indices=vision_indices)
     return dict(hidden=hidden.view(B, S, d.hidden), flag=flag, lang_idx=lang_idx, vis_idx=vis_idx, z_lang=z_lang,
                 z_vis=z_vis, z_all=z_all, loss=loss, hidden_states=hs, saved=saved)
 
@@ -557,7 +597,7 @@ def _decode_core(sd, packed, d: DecDims, cache: KVCache, st: dict):
     dev = flag.device
     cos, sin = rope_tables(d.hidden // d.heads, rope_rows(d, cache.capacity), dev)
     cache.flag.index_copy_(1, st["slot"], flag.view(B, 1))
-    x = embed(sd, d, st["ids"], flag, lang_idx, vis_idx, None)
+    x = embed(sd, d, st["ids"], flag, lang_idx, vis_idx, None, vision_indices=st["vi"].view(B, 1))
     for i in range(d.layers):
         x = layer_forward(sd, packed[i], i, d, x, flag, lang_idx, vis_idx, st["kv_len"], cos, sin, B, 1, None, cache=cache,
                           positions=st["positions"], slot=st["slot"], kv_start=cache.start)
@@ -845,16 +885,25 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
 
     # ---- embeddings (modeling_libra.py:625-661)
     e = sv["emb"]
+    proc = "model.vision_contiguous_signal_processor.weight"
+    if not d.concat and "sig_all" in e and w(proc):         # x += processor(signal) on every row: dW = dx^T signal
+        allr = torch.arange(N, dtype=torch.int32, device=dev)
+        g[proc] = _wg(_compact(dx, allr), _compact(e["sig_all"], allr), name=proc)
     if n_v:
-        proc = "model.vision_contiguous_signal_processor.weight"
-        dven = K.gemm_nt(dx, sd[proc], b_t=True, a_rows=vis_idx)                                   # [n_v, H+Cs]
-        if w(proc):
-            g[proc] = _wg(_compact(dx, vis_idx), e["ven"], name=proc)
-        dve = K.rmsnorm_routed_bwd(dven, e["ve"], sd["model.vision_signal_norm.weight"], None, None, e["rstd_e"])
-        if w("model.vision_signal_norm.weight"):
-            dn = f32(H + d.signal)
-            K.rmsnorm_routed_wgrad(dven, e["ve"], e["rstd_e"], None, dn, None)
-            g["model.vision_signal_norm.weight"] = K.f32_to_bf16(dn)
+        if d.concat:
+            dven = K.gemm_nt(dx, sd[proc], b_t=True, a_rows=vis_idx)                                   # [n_v, H+Cs]
+            if w(proc):
+                g[proc] = _wg(_compact(dx, vis_idx), e["ven"], name=proc)
+            if d.norm_sig:
+                dve = K.rmsnorm_routed_bwd(dven, e["ve"], sd["model.vision_signal_norm.weight"], None, None, e["rstd_e"])
+                if w("model.vision_signal_norm.weight"):
+                    dn = f32(H + d.signal)
+                    K.rmsnorm_routed_wgrad(dven, e["ve"], e["rstd_e"], None, dn, None)
+                    g["model.vision_signal_norm.weight"] = K.f32_to_bf16(dn)
+            else:
+                dve = dven
+        else:
+            dve = dx.index_select(0, vis_idx.long())                                                   # plumbing gather
         ids = sv["input_ids"]
         for q in range(Q):
             name = f"model.vision_embed_tokens.{q}.weight"
@@ -864,6 +913,11 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
                 tok = (ids[q].reshape(-1).index_select(0, vis_idx.long()) - d.vocab)
                 acc.index_add_(0, tok, dve[:, q * (H // Q):(q + 1) * (H // Q)].float())
                 g[name] = acc.to(BF16)
+        name = "model.vision_position_embedding.weight"
+        if d.vis_pos and w(name):                           # same scatter-add, by the in-image index
+            acc = torch.zeros(sd[name].shape, dtype=torch.float32, device=dev)
+            acc.index_add_(0, sv["vision_indices"].reshape(-1).index_select(0, vis_idx.long()), dve[:, :H].float())
+            g[name] = acc.to(BF16)
     if n_l and w("model.embed_tokens.weight"):
         acc = torch.zeros(sd["model.embed_tokens.weight"].shape, dtype=torch.float32, device=dev)
         tok = sv["input_ids"][0].reshape(-1).index_select(0, lang_idx.long())

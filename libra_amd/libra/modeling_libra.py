@@ -5,7 +5,7 @@ LibraDecoderLayer :416-435, LibraModel :524-600, MultiLMHead :834-843, LibraForC
 The sub-modules only own the parameters (same names and shapes as the reference checkpoints: SURVEY §8b); the
 compute is the kernel schedule in ``libra_amd/decoder_engine.py`` (forward and hand-written backward, exposed to
 autograd through one ``torch.autograd.Function``), parity-tested against the reference fixtures.
-Built: use_bridge on / off, concat + norm signals, dropout 0, with 1d or 2d RoPE (`use_2d_rope`), routed or unified heads
+Built: use_bridge on / off, concatenated (normed or not) or added signals, vision position embedding, dropout 0, with 1d or 2d RoPE (`use_2d_rope`), routed or unified heads
 (`unified_head`), 1d or 2d vision prediction (`vision_prediction_mode`); anything else raises NotImplementedError rather
 than silently diverging.
 """
@@ -100,8 +100,14 @@ class LibraModel(_EngineOwned):            # modeling_libra.py:524-600 (paramete
         self.vision_embed_tokens = nn.ModuleList([nn.Embedding(c.vision_vocab_size, c.hidden_size // c.vision_codebook_num)
                                                   for _ in range(c.vision_codebook_num)])
         self.vision_norm = LlamaRMSNorm(c.hidden_size, eps=c.rms_norm_eps)
-        self.vision_contiguous_signal_processor = nn.Linear(c.contiguous_signal_size + c.hidden_size, c.hidden_size, bias=False)
-        self.vision_signal_norm = LlamaRMSNorm(c.contiguous_signal_size + c.hidden_size, eps=c.rms_norm_eps)
+        if c.concat_signals:               # :556-562 - the signal rides next to the codebook embeddings through one Linear ...
+            self.vision_contiguous_signal_processor = nn.Linear(c.contiguous_signal_size + c.hidden_size, c.hidden_size, bias=False)
+            if c.norm_signals:
+                self.vision_signal_norm = LlamaRMSNorm(c.contiguous_signal_size + c.hidden_size, eps=c.rms_norm_eps)
+        else:                              # ... or is projected on its own and added to the embeddings (:753-754)
+            self.vision_contiguous_signal_processor = nn.Linear(c.contiguous_signal_size, c.hidden_size, bias=False)
+        if c.use_vision_position_embedding:                                  # :564-566
+            self.vision_position_embedding = nn.Embedding(c.max_vision_token_length, c.hidden_size)
         # modeling_libra.py:597 - PreTrainedModel.gradient_checkpointing_enable() flips it (both recipes do:
         # libra_pretrain.yaml:120); the engine then keeps only each layer's input and recomputes the layer in backward
         self.gradient_checkpointing = False
@@ -154,11 +160,10 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
     def __init__(self, config: LibraConfig):
         super().__init__(config)
         c = config
-        if (not c.concat_signals or not c.norm_signals or c.addition_mode
-                or c.use_vision_position_embedding or c.vision_prediction_mode not in ("1d", "2d")):
-            raise NotImplementedError("built: bridge on / off, concat + norm signals, 1d / 2d prediction, 1d / 2d RoPE, routed / "
-                                      "unified heads; not built: addition_mode, un-normed / un-concatenated signals, "
-                                      "use_vision_position_embedding (DESIGN.md §7 row f4)")
+        if c.addition_mode or c.vision_prediction_mode not in ("1d", "2d"):
+            raise NotImplementedError("built: bridge on / off, concatenated (normed or not) or added signals, vision position "
+                                      "embedding, 1d / 2d prediction, 1d / 2d RoPE, routed / unified heads; not built: addition_mode "
+                                      "(DESIGN.md §7 row f4)")
         pred_2d = c.vision_prediction_mode == "2d"
         if pred_2d and c.unified_head:
             raise NotImplementedError("unified_head with vision_prediction_mode='2d' (the reference asserts it away, :1055)")
@@ -184,7 +189,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                                 signal=c.contiguous_signal_size, rank=c.bridge_rank, down_ratio=c.vision_down_ratio,
                                 eps=c.rms_norm_eps, max_pos=c.max_position_embeddings, rope_2d=bool(c.use_2d_rope),
                                 unified_head=bool(c.unified_head), pred_2d=pred_2d, res=int(c.image_feature_resolution),
-                                bridge=bool(c.use_bridge))
+                                bridge=bool(c.use_bridge), concat=bool(c.concat_signals),
+                                norm_sig=bool(c.concat_signals and c.norm_signals), vis_pos=bool(c.use_vision_position_embedding))
         self._packed: Optional[DE.PackedOperands] = None
         self.post_init()
 

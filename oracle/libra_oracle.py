@@ -167,8 +167,12 @@ def decoder_layer(sd, i, x, flag, mask, position_ids, heads, eps, cos, sin):
     return x + mlp(sd, pre + "mlp.", h, flag)
 
 
-def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Optional[torch.Tensor], vocab: int, eps: float):
-    """get_inputs_embeds_from_multicodebook (concat_signals & norm_signals on, no vision position embedding)."""
+def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Optional[torch.Tensor], vocab: int, eps: float,
+                 vision_indices: Optional[torch.Tensor] = None):
+    """get_inputs_embeds_from_multicodebook (:625-661) + the un-concatenated signal path of LibraModel.forward (:753-754).  The
+    configuration is read off the state dict, as the reference's constructor shapes it (:553-566): a `vision_position_embedding`
+    table = use_vision_position_embedding; a `vision_signal_norm` weight = concat_signals and norm_signals; a processor whose
+    input width is the signal width alone = concat_signals False."""
     Q = input_ids.shape[0]
     lang_ids = torch.where(flag, torch.zeros_like(input_ids[0]), input_ids[0])
     lang = F.embedding(lang_ids, sd["model.embed_tokens.weight"])
@@ -177,11 +181,23 @@ def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Option
         vid = torch.where(flag, input_ids[q] - vocab, torch.zeros_like(input_ids[q]))
         vis.append(F.embedding(vid, sd[f"model.vision_embed_tokens.{q}.weight"]))
     vis = torch.cat(vis, dim=-1)
-    if signal is None:
-        signal = vis.new_zeros(vis.shape[:-1] + (sd["model.vision_signal_norm.weight"].shape[0] - vis.shape[-1],))
-    ve = rms_norm(torch.cat([vis, signal.to(vis.dtype)], dim=-1), sd["model.vision_signal_norm.weight"], eps)
-    ve = F.linear(ve, sd["model.vision_contiguous_signal_processor.weight"])
-    return torch.where(flag.unsqueeze(-1), ve, lang)
+    if "model.vision_position_embedding.weight" in sd:                         # :636-638
+        pos = torch.where(flag, vision_indices, torch.zeros_like(vision_indices))
+        vis = vis + F.embedding(pos, sd["model.vision_position_embedding.weight"])
+    wp = sd["model.vision_contiguous_signal_processor.weight"]
+    concat = wp.shape[1] > vis.shape[-1]                                        # Linear(Cs + H -> H) vs Linear(Cs -> H), :556-562
+    if concat:
+        if signal is None:
+            signal = vis.new_zeros(vis.shape[:-1] + (wp.shape[1] - vis.shape[-1],))          # :646-653
+        ve = torch.cat([vis, signal.to(vis.dtype)], dim=-1)
+        if "model.vision_signal_norm.weight" in sd:
+            ve = rms_norm(ve, sd["model.vision_signal_norm.weight"], eps)
+        ve = F.linear(ve, wp)
+        return torch.where(flag.unsqueeze(-1), ve, lang)
+    x = torch.where(flag.unsqueeze(-1), vis, lang)
+    if signal is not None:                                                      # :753-754, every position (the signal is 0 off-image)
+        x = x + F.linear(signal.to(x.dtype), wp)
+    return x
 
 
 def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, layers: int, heads: int, vocab: int,
@@ -193,7 +209,7 @@ def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, laye
     flag = vision_indices < max_vision_token_length                      # :1118
     assert torch.equal(flag, input_ids[0] >= vocab)                        # :707-710
     B, S = input_ids.shape[1:]
-    x = input_embeds(sd, input_ids, flag, signal, vocab, eps)
+    x = input_embeds(sd, input_ids, flag, signal, vocab, eps, vision_indices)
     d = x.shape[-1] // heads
     if rope_2d_res is not None:
         pos = position_ids_2d(vision_indices, max_vision_token_length, rope_2d_res)
@@ -323,7 +339,7 @@ def model_step(sd, input_ids, vision_indices, signal, caches: Optional[list], po
     """One cached forward over the NEW tokens input_ids [Q,B,q]: -> (hidden [B,q,H], flag [B,q], caches)."""
     flag = vision_indices < max_vision_token_length
     assert torch.equal(flag, input_ids[0] >= vocab)
-    x = input_embeds(sd, input_ids, flag, signal, vocab, eps)               # signal None -> zeros (:646-653)
+    x = input_embeds(sd, input_ids, flag, signal, vocab, eps, vision_indices)   # signal None -> zeros (:646-653)
     cos, sin = rope_tables(x.shape[-1] // heads, max(max_pos, int(position_ids.max()) + 1), dtype=x.dtype)
     out_caches = []
     for i in range(layers):

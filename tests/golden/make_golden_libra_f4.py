@@ -1,6 +1,7 @@
 """Golden fixtures for the alternative decoder configurations from the REFERENCE's own LibraForCausalLM:
 `use_2d_rope` (modeling_libra.py:43-49, :576-587, :663-678), `unified_head` (:1054-1064), `vision_prediction_mode="2d"`
-(:942-1014) and `use_bridge=False` (:258, :311-317, :394), each on libra_tiny's inputs and weights (the 2d-prediction heads have their own [18, 2*256] weights, stored).
+(:942-1014), `use_bridge=False` (:258, :311-317, :394) and the embedding-stage switches `use_vision_position_embedding` (:564-566,
+:636-638), `norm_signals=False` (:558, :641-644), `concat_signals=False` (:561-562, :753-754), each on libra_tiny's inputs and weights (the 2d-prediction heads have their own [18, 2*256] weights, stored).
 Stored per variant: loss, final hidden state, logits, and the reference autograd's gradients of a sample of parameters.
 Build-container only (imports /root/reference through ref_harness)."""
 import os
@@ -30,13 +31,25 @@ def main():
     out_t, meta = {}, dict(cfg=mg.TINY, variants={})
     for name, over in (("rope2d", dict(use_2d_rope=True)), ("unified", dict(unified_head=True)),
                        ("pred2d", dict(vision_prediction_mode="2d")), ("rope2d_pred2d", dict(use_2d_rope=True, vision_prediction_mode="2d")),
-                       ("nobridge", dict(use_bridge=False))):
+                       ("nobridge", dict(use_bridge=False)), ("vispos", dict(use_vision_position_embedding=True)),
+                       ("nonorm", dict(norm_signals=False)), ("noconcat", dict(concat_signals=False))):
         cfg = cfgm.LibraConfig(**dict(mg.TINY, **over))
         torch.manual_seed(0)
         model = ml.LibraForCausalLM(cfg).eval()
         sd = dict(w)
         if over.get("use_bridge") is False:                               # :258 - the layer has no bridge parameters at all
             sd = {k: v for k, v in sd.items() if "_bridge_on_" not in k}
+        extra = {}
+        gx = torch.Generator().manual_seed(23)
+        H_, Cs_, L_ = mg.TINY["hidden_size"], mg.TINY["contiguous_signal_size"], mg.TINY["max_vision_token_length"]
+        if over.get("use_vision_position_embedding"):                     # :564-566 Embedding(max_vision_token_length, hidden)
+            extra["model.vision_position_embedding.weight"] = torch.randn(L_, H_, generator=gx) * 0.5
+        if over.get("norm_signals") is False:                             # :558 - no vision_signal_norm module
+            sd.pop("model.vision_signal_norm.weight")
+        if over.get("concat_signals") is False:                           # :561-562 Linear(contiguous_signal_size -> hidden), no norm
+            sd.pop("model.vision_signal_norm.weight")
+            extra["model.vision_contiguous_signal_processor.weight"] = torch.randn(H_, Cs_, generator=gx) * Cs_ ** -0.5
+        sd.update(extra)
         if over.get("vision_prediction_mode") == "2d":                    # heads take cat(up, left): [Vv, 2 * hidden]
             g = torch.Generator().manual_seed(17)
             for q in range(2):
@@ -59,6 +72,10 @@ def main():
             for q in range(2):
                 out_t[f"{name}.w.vision_lm_head.heads.{q}.weight"] = sd[f"vision_lm_head.heads.{q}.weight"]
             out_t[f"{name}.w.vision_hidden_placeholder"] = sd["vision_hidden_placeholder"]
+        for k_, v_ in extra.items():
+            out_t[f"{name}.w.{k_}"] = v_
+            if grads[k_].grad is not None:
+                out_t[f"{name}.grad.{k_}"] = grads[k_].grad.detach().clone()
         if over.get("use_2d_rope"):
             out_t[f"{name}.position_ids"] = model.model.get_2d_position_ids(vi)
         meta["variants"][name] = over

@@ -1,4 +1,5 @@
-"""SURVEY §8f-4 on device: use_2d_rope, unified_head, vision_prediction_mode="2d" (and 2d RoPE + 2d prediction together) against
+"""SURVEY §8f-4 on device: use_2d_rope, unified_head, vision_prediction_mode="2d" (and 2d RoPE + 2d prediction together), use_bridge=False
+and the embedding-stage switches (use_vision_position_embedding, norm_signals=False, concat_signals=False) against
 the fixture produced by the reference's own forward + autograd (tests/golden/make_golden_libra_f4.py) and the fp32 oracle on the
 same bf16-rounded weights; the cached generation path of each variant against the uncached forward."""
 import pytest
@@ -8,7 +9,7 @@ from helpers import load_golden, parity_report, rel_err, sub
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-VARIANTS = ("rope2d", "unified", "pred2d", "rope2d_pred2d", "nobridge")
+VARIANTS = ("rope2d", "unified", "pred2d", "rope2d_pred2d", "nobridge", "vispos", "nonorm", "noconcat")
 
 
 def _build(name):
@@ -19,6 +20,8 @@ def _build(name):
     w = dict(sub(t0, "w."))
     if over.get("use_bridge") is False:                                    # no bridge parameters in the state dict (:258)
         w = {k: v for k, v in w.items() if "_bridge_on_" not in k}
+    if over.get("norm_signals") is False or over.get("concat_signals") is False:      # no vision_signal_norm module (:558)
+        w.pop("model.vision_signal_norm.weight")
     w.update(sub(t, f"{name}.w."))
     m = LibraForCausalLM(LibraConfig(**dict(meta["cfg"], **over)))
     m.load_state_dict(w, strict=True)

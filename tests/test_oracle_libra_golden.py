@@ -159,6 +159,8 @@ def test_f4_variants_match_reference():
         sd = {k: v.clone() for k, v in sub(t0, "w.").items()}
         if over.get("use_bridge") is False:                    # the reference layer then has no bridge parameters (:258)
             sd = {k: v for k, v in sd.items() if "_bridge_on_" not in k}
+        if over.get("norm_signals") is False or over.get("concat_signals") is False:      # no vision_signal_norm module (:558)
+            sd.pop("model.vision_signal_norm.weight")
         for k, v in sub(t, f"{name}.w.").items():
             sd[k] = v.clone()
         sd = {k: v.requires_grad_(True) for k, v in sd.items()}
@@ -185,6 +187,8 @@ def test_f4_variants_match_reference():
             assert rel_err(sd[k].grad, g) < 2e-4, (name, k, rel_err(sd[k].grad, g))
             n += 1
         assert n >= (10 if over.get("use_bridge") is False else 11), (name, n)
+        for k in sub(t, f"{name}.w."):                           # the variant's own extra weights have their reference gradient too
+            assert f"{name}.grad.{k}" in t or "placeholder" in k or "heads" in k, (name, k)
 
 
 # ---- tiny width x FULL depth (32 layers): SURVEY §8c(i) ------------------------------------------------------------------
