@@ -1016,7 +1016,12 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     # ================= attention: x_mid = x + o_proj(attn(rope(q), K_same/K_cross, V_same/V_cross)) =================
     o = sv["o"]
     do = torch.empty((N, H), dtype=BF16, device=dev)
-    if n_l:
+    add = d.addition               # addition_mode: the language q / k / v / o projections saw every row; vision terms ACCUMULATE
+    if add:
+        K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, out=do)
+        if w(a + "o_proj.weight"):
+            g[a + "o_proj.weight"] = _wg(dx_mid, o, name=a + "o_proj.weight")
+    elif n_l:
         K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do)
         if w(a + "o_proj.weight"):
             g[a + "o_proj.weight"] = _wg(_compact(dx_mid, lang_idx, "dxm_l"), _compact(o, lang_idx, "o_l"), name=a + "o_proj.weight")
@@ -1025,7 +1030,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=_arows("b.dto", n_v, r, dev))
         if w(a + "vision_o_proj.weight_B"):
             g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"], name=a + "vision_o_proj.weight_B")
-        K.gemm_nt(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx)
+        K.gemm_nt(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx, resid=do if add else None)
         if w(a + "vision_o_proj.weight_A"):
             g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx, "o_v"), name=a + "vision_o_proj.weight_A")
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
@@ -1064,12 +1069,21 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
                 if w(nv):
                     g[nv] = _wg(_compact(dvb, idx, "dvb_" + which), tbc[:, 8:16], post=lambda o: o[:, :d.rank].contiguous())
     dh = torch.empty((N, H), dtype=BF16, device=dev)
-    if n_l:
-        K.gemm_nt(dqkvt, pk["wqkv_ab"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)       # K = 3H + 64
+    dt_ext = None
+    if n_v:
+        dt_ext = _arows("b.dt_ext", n_v, 3 * r + 64, dev)            # [dt_q | dt_k | dt_v | dt_bridge], mirrors the forward's t_ext
+        K.copy_rows(dtb, vis_idx, n_v, dt_ext, 3 * r)                # the vision rows' 64 bridge columns
+        if add:                    # the vision rows' bridge columns belong to the VISION bridge A only: with them zeroed, one GEMM /
+            dtb.index_fill_(0, vis_idx.long(), 0)                    # wgrad over every row serves q / k / v (all rows) + language bridge A
+    if add or n_l:
+        if add:
+            K.gemm_nt(dqkvt, pk["wqkv_ab"], b_t=True, out=dh)                                       # K = 3H + 64, every row
+        else:
+            K.gemm_nt(dqkvt, pk["wqkv_ab"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)   # K = 3H + 64
         nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
         if any_l([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]):
-            hl = _compact(h, lang_idx, "h_l")
-            dw, gk, gv = _wg(_compact(dqkvt, lang_idx, "dqkvt_l"), hl,                              # [3H + 64, H]
+            hl = h if add else _compact(h, lang_idx, "h_l")
+            dw, gk, gv = _wg(dqkvt if add else _compact(dqkvt, lang_idx, "dqkvt_l"), hl,            # [3H + 64, H]
                              post=lambda o: (o, o[3 * H:3 * H + d.rank].contiguous(), o[3 * H + 8:3 * H + 8 + d.rank].contiguous()))
             for j, nm in enumerate(("q", "k", "v")):
                 g[a + f"{nm}_proj.weight"] = dw[j * H:(j + 1) * H]
@@ -1086,7 +1100,6 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     if n_v:
         t = sv["t"]
         dqkv_v = _compact(dqkv, vis_idx, "dqkv_v")                                                    # [n_v, 3H]
-        dt_ext = _arows("b.dt_ext", n_v, 3 * r + 64, dev)            # [dt_q | dt_k | dt_v | dt_bridge], mirrors the forward's t_ext
         dt = dt_ext[:, :3 * r]
         K.gemm_nt_grouped([dqkv_v[:, j * H:(j + 1) * H] for j in range(3)],
                           [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
@@ -1094,8 +1107,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         for j, nm in enumerate(("q", "k", "v")):
             if w(a + f"vision_{nm}_proj.weight_B"):
                 g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r], name=a + f"vision_{nm}_proj.weight_B")
-        K.copy_rows(dtb, vis_idx, n_v, dt_ext, 3 * r)                # the vision rows' 64 bridge columns
-        K.gemm_nt(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx)                   # K = 3r + 64
+        K.gemm_nt(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx, resid=dh if add else None)   # K = 3r + 64
         nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
         want_a = any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"])
         if want_a or w(nk) or w(nv):

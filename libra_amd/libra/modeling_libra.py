@@ -160,10 +160,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
     def __init__(self, config: LibraConfig):
         super().__init__(config)
         c = config
-        if c.addition_mode or c.vision_prediction_mode not in ("1d", "2d"):
-            raise NotImplementedError("built: bridge on / off, concatenated (normed or not) or added signals, vision position "
-                                      "embedding, 1d / 2d prediction, 1d / 2d RoPE, routed / unified heads; not built: addition_mode "
-                                      "(DESIGN.md §7 row f4)")
+        if c.vision_prediction_mode not in ("1d", "2d"):
+            raise ValueError(f"vision_prediction_mode={c.vision_prediction_mode!r}: '1d' or '2d' (modeling_libra.py:857-861)")
         pred_2d = c.vision_prediction_mode == "2d"
         if pred_2d and c.unified_head:
             raise NotImplementedError("unified_head with vision_prediction_mode='2d' (the reference asserts it away, :1055)")
@@ -190,7 +188,8 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                                 eps=c.rms_norm_eps, max_pos=c.max_position_embeddings, rope_2d=bool(c.use_2d_rope),
                                 unified_head=bool(c.unified_head), pred_2d=pred_2d, res=int(c.image_feature_resolution),
                                 bridge=bool(c.use_bridge), concat=bool(c.concat_signals),
-                                norm_sig=bool(c.concat_signals and c.norm_signals), vis_pos=bool(c.use_vision_position_embedding))
+                                norm_sig=bool(c.concat_signals and c.norm_signals), vis_pos=bool(c.use_vision_position_embedding),
+                                addition=bool(c.addition_mode))
         self._packed: Optional[DE.PackedOperands] = None
         self.post_init()
 
@@ -198,7 +197,7 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         std = self.config.initializer_range
         if isinstance(module, LibraLinear):
             module.weight_A.data.normal_(mean=0.0, std=std)
-            if module.rank is not None:
+            if module.rank is not None or self.config.addition_mode:
                 module.weight_B.data.zero_()
             else:
                 module.weight_B.data.normal_(mean=0.0, std=std)

@@ -43,10 +43,11 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * xf.to(dt)
 
 
-def routed(x: torch.Tensor, flag: torch.Tensor, f_lang, f_vis) -> torch.Tensor:
-    """cal_language_vision (addition_mode off): language fn on ~flag rows, vision fn on flag rows."""
+def routed(x: torch.Tensor, flag: torch.Tensor, f_lang, f_vis, addition: bool = False) -> torch.Tensor:
+    """cal_language_vision (modeling_libra.py:111-137): language fn on ~flag rows, vision fn on flag rows; with addition_mode
+    (:112-127, the q / k / v / o projections only) the language fn on EVERY row and the vision fn added on the flag rows."""
     yl, yv = f_lang(x), f_vis(x)
-    return torch.where(flag.unsqueeze(-1), yv, yl)
+    return torch.where(flag.unsqueeze(-1), yl + yv if addition else yv, yl)
 
 
 def libra_linear(x, sd, pre):
@@ -112,12 +113,12 @@ def additive_mask(attention_mask: torch.Tensor, S: int, dtype) -> torch.Tensor:
     return pad + causal[None, None]
 
 
-def attention(sd, pre, x, flag, mask, position_ids, heads: int, cos, sin) -> torch.Tensor:
+def attention(sd, pre, x, flag, mask, position_ids, heads: int, cos, sin, addition: bool = False) -> torch.Tensor:
     B, S, Hd = x.shape
     d = Hd // heads
-    q = routed(x, flag, lambda t: F.linear(t, sd[pre + "q_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_q_proj."))
-    k = routed(x, flag, lambda t: F.linear(t, sd[pre + "k_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_k_proj."))
-    v = routed(x, flag, lambda t: F.linear(t, sd[pre + "v_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_v_proj."))
+    q = routed(x, flag, lambda t: F.linear(t, sd[pre + "q_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_q_proj."), addition)
+    k = routed(x, flag, lambda t: F.linear(t, sd[pre + "k_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_k_proj."), addition)
+    v = routed(x, flag, lambda t: F.linear(t, sd[pre + "v_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_v_proj."), addition)
     if pre + "vision_k_bridge_on_language.weight_A" in sd:
         kb = routed(x, flag, lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_language."),
                     lambda t: libra_linear(t, sd, pre + "vision_k_bridge_on_vision."))
@@ -143,7 +144,7 @@ def attention(sd, pre, x, flag, mask, position_ids, heads: int, cos, sin) -> tor
     p = torch.softmax(s, dim=-1, dtype=torch.float32 if s.dtype != torch.float64 else torch.float64).to(q.dtype)
     o = p @ v + (p * cross.to(p.dtype)) @ vb                                    # attn_with_bridge :267-296
     o = o.transpose(1, 2).reshape(B, S, Hd)
-    return routed(o, flag, lambda t: F.linear(t, sd[pre + "o_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_o_proj."))
+    return routed(o, flag, lambda t: F.linear(t, sd[pre + "o_proj.weight"]), lambda t: libra_linear(t, sd, pre + "vision_o_proj."), addition)
 
 
 def mlp(sd, pre, x, flag):
@@ -157,11 +158,11 @@ def mlp(sd, pre, x, flag):
     return routed(x, flag, lang, vis)
 
 
-def decoder_layer(sd, i, x, flag, mask, position_ids, heads, eps, cos, sin):
+def decoder_layer(sd, i, x, flag, mask, position_ids, heads, eps, cos, sin, addition: bool = False):
     pre = f"model.layers.{i}."
     h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "input_layernorm.weight"], eps),
                lambda t: rms_norm(t, sd[pre + "vision_input_layernorm.weight"], eps))
-    x = x + attention(sd, pre + "self_attn.", h, flag, mask, position_ids, heads, cos, sin)
+    x = x + attention(sd, pre + "self_attn.", h, flag, mask, position_ids, heads, cos, sin, addition)
     h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "post_attention_layernorm.weight"], eps),
                lambda t: rms_norm(t, sd[pre + "vision_post_attention_layernorm.weight"], eps))
     return x + mlp(sd, pre + "mlp.", h, flag)
@@ -202,7 +203,7 @@ def input_embeds(sd, input_ids: torch.Tensor, flag: torch.Tensor, signal: Option
 
 def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, layers: int, heads: int, vocab: int,
                   max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048, rope_2d_res: Optional[int] = None,
-                  hidden_states: Optional[list] = None):
+                  hidden_states: Optional[list] = None, addition: bool = False):
     """LibraForCausalLM up to the final routed norm: -> hidden [B,S,H], vision_flag.  `rope_2d_res` = image_feature_resolution
     switches on use_2d_rope (position ids from `position_ids_2d`, :731-733).  `hidden_states` (a list) receives the reference's
     `output_hidden_states` tuple: the embeddings and every layer's output, before the final norm (:781-807)."""
@@ -221,7 +222,7 @@ def model_forward(sd, input_ids, attention_mask, vision_indices, signal, *, laye
     if hidden_states is not None:
         hidden_states.append(x)
     for i in range(layers):
-        x = decoder_layer(sd, i, x, flag, mask, pos, heads, eps, cos, sin)
+        x = decoder_layer(sd, i, x, flag, mask, pos, heads, eps, cos, sin, addition)
         if hidden_states is not None:
             hidden_states.append(x)
     x = routed(x, flag, lambda t: rms_norm(t, sd["model.norm.weight"], eps),
@@ -299,16 +300,16 @@ def vl_logits_2d(sd, hidden, flag, Q: int, max_vision_token_length: int, res: in
 # Pinned by tests/test_oracle_libra_golden.py against tests/golden/libra_tiny_decode.safetensors
 # (tests/golden/make_golden_libra_decode.py runs the reference's own cached forward).
 
-def attention_step(sd, pre, x, flag, cache: Optional[dict], position_ids, key_valid, heads: int, cos, sin):
+def attention_step(sd, pre, x, flag, cache: Optional[dict], position_ids, key_valid, heads: int, cos, sin, addition: bool = False):
     """x [B,q,H] = the NEW tokens (q = prompt length at prefill, 1 afterwards), flag [B,q], position_ids [B,q],
     key_valid [B, past + q] bool (the attention_mask).  -> (out [B,q,H], new cache)."""
     B, q_len, Hd = x.shape
     d = Hd // heads
     lin = lambda name: (lambda t: F.linear(t, sd[pre + name + ".weight"]))
     low = lambda name: (lambda t: libra_linear(t, sd, pre + name + "."))
-    q = routed(x, flag, lin("q_proj"), low("vision_q_proj"))
-    k = routed(x, flag, lin("k_proj"), low("vision_k_proj"))
-    v = routed(x, flag, lin("v_proj"), low("vision_v_proj"))
+    q = routed(x, flag, lin("q_proj"), low("vision_q_proj"), addition)
+    k = routed(x, flag, lin("k_proj"), low("vision_k_proj"), addition)
+    v = routed(x, flag, lin("v_proj"), low("vision_v_proj"), addition)
     if pre + "vision_k_bridge_on_language.weight_A" in sd:
         kb = routed(x, flag, low("vision_k_bridge_on_language"), low("vision_k_bridge_on_vision"))
         vb = routed(x, flag, low("vision_v_bridge_on_language"), low("vision_v_bridge_on_vision"))
@@ -331,11 +332,11 @@ def attention_step(sd, pre, x, flag, cache: Optional[dict], position_ids, key_va
     p = torch.softmax(s, dim=-1, dtype=torch.float32 if s.dtype != torch.float64 else torch.float64).to(q.dtype)
     o = p @ new["v"] + (p * cross.to(p.dtype)) @ new["vb"]
     o = o.transpose(1, 2).reshape(B, q_len, Hd)
-    return routed(o, flag, lin("o_proj"), low("vision_o_proj")), new
+    return routed(o, flag, lin("o_proj"), low("vision_o_proj"), addition), new
 
 
 def model_step(sd, input_ids, vision_indices, signal, caches: Optional[list], position_ids, key_valid, *, layers: int, heads: int,
-               vocab: int, max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048):
+               vocab: int, max_vision_token_length: int, eps: float = 1e-6, max_pos: int = 2048, addition: bool = False):
     """One cached forward over the NEW tokens input_ids [Q,B,q]: -> (hidden [B,q,H], flag [B,q], caches)."""
     flag = vision_indices < max_vision_token_length
     assert torch.equal(flag, input_ids[0] >= vocab)
@@ -347,7 +348,7 @@ def model_step(sd, input_ids, vision_indices, signal, caches: Optional[list], po
         h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "input_layernorm.weight"], eps),
                    lambda t: rms_norm(t, sd[pre + "vision_input_layernorm.weight"], eps))
         a, c = attention_step(sd, pre + "self_attn.", h, flag, None if caches is None else caches[i], position_ids, key_valid,
-                              heads, cos, sin)
+                              heads, cos, sin, addition)
         out_caches.append(c)
         x = x + a
         h = routed(x, flag, lambda t: rms_norm(t, sd[pre + "post_attention_layernorm.weight"], eps),
@@ -490,11 +491,11 @@ def valid_image_scores(ids_q: torch.Tensor, scores_q: torch.Tensor, *, valid_ima
 
 def greedy_generate(sd, input_ids, attention_mask, vision_indices, signal, *, steps: int, Q: int, layers: int, heads: int, vocab: int,
                     max_vision_token_length: int, newline_token_id: int, pad_token_id: int, eos_token_id: int, image_rule: dict,
-                    eps: float = 1e-6, max_pos: int = 2048):
+                    eps: float = 1e-6, max_pos: int = 2048, addition: bool = False):
     """-> (sequences [Q,B,S+steps], processed scores [steps,Q,B,V']).  position_ids = attention_mask.cumsum(-1) - 1 (pads -> 1,
     modeling_libra.py:1204-1207); the vision index of a new token counts up inside an image and stays at L otherwise (:1270-1278);
     finished sequences emit pad, codebook by codebook (modeling_libra_utils.py:276-296)."""
-    kw = dict(layers=layers, heads=heads, vocab=vocab, max_vision_token_length=max_vision_token_length, eps=eps, max_pos=max_pos)
+    kw = dict(layers=layers, heads=heads, vocab=vocab, max_vision_token_length=max_vision_token_length, eps=eps, max_pos=max_pos, addition=addition)
     am, vi, ids = attention_mask.clone(), vision_indices.clone(), input_ids.clone()
     B = ids.shape[1]
     unfinished = torch.ones(B, dtype=torch.long)

@@ -1,7 +1,7 @@
 """Golden fixtures for the alternative decoder configurations from the REFERENCE's own LibraForCausalLM:
 `use_2d_rope` (modeling_libra.py:43-49, :576-587, :663-678), `unified_head` (:1054-1064), `vision_prediction_mode="2d"`
 (:942-1014), `use_bridge=False` (:258, :311-317, :394) and the embedding-stage switches `use_vision_position_embedding` (:564-566,
-:636-638), `norm_signals=False` (:558, :641-644), `concat_signals=False` (:561-562, :753-754), each on libra_tiny's inputs and weights (the 2d-prediction heads have their own [18, 2*256] weights, stored).
+:636-638), `norm_signals=False` (:558, :641-644), `concat_signals=False` (:561-562, :753-754), and `addition_mode` (cal_language_vision :111-127 on the q / k / v / o projections), each on libra_tiny's inputs and weights (the 2d-prediction heads have their own [18, 2*256] weights, stored).
 Stored per variant: loss, final hidden state, logits, and the reference autograd's gradients of a sample of parameters.
 Build-container only (imports /root/reference through ref_harness)."""
 import os
@@ -32,7 +32,8 @@ def main():
     for name, over in (("rope2d", dict(use_2d_rope=True)), ("unified", dict(unified_head=True)),
                        ("pred2d", dict(vision_prediction_mode="2d")), ("rope2d_pred2d", dict(use_2d_rope=True, vision_prediction_mode="2d")),
                        ("nobridge", dict(use_bridge=False)), ("vispos", dict(use_vision_position_embedding=True)),
-                       ("nonorm", dict(norm_signals=False)), ("noconcat", dict(concat_signals=False))):
+                       ("nonorm", dict(norm_signals=False)), ("noconcat", dict(concat_signals=False)),
+                       ("addition", dict(addition_mode=True))):
         cfg = cfgm.LibraConfig(**dict(mg.TINY, **over))
         torch.manual_seed(0)
         model = ml.LibraForCausalLM(cfg).eval()
@@ -65,7 +66,11 @@ def main():
         out_t[f"{name}.hidden"] = out.hidden_states[-1].detach()
         out_t[f"{name}.logits"] = out.logits.detach()
         grads = dict(model.named_parameters())
-        for n in SAMPLE:
+        more = ["model.layers.1.self_attn.o_proj.weight", "model.layers.0.self_attn.vision_o_proj.weight_A",
+                "model.layers.0.self_attn.v_proj.weight", "model.layers.1.self_attn.vision_q_proj.weight_B",
+                "model.layers.0.self_attn.vision_k_bridge_on_language.weight_A",
+                "model.layers.0.input_layernorm.weight", "model.layers.1.vision_input_layernorm.weight"] if name == "addition" else []
+        for n in SAMPLE + more:
             if n in grads and grads[n].grad is not None:
                 out_t[f"{name}.grad.{n}"] = grads[n].grad.detach().clone()
         if over.get("vision_prediction_mode") == "2d":

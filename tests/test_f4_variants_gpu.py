@@ -1,5 +1,5 @@
 """SURVEY §8f-4 on device: use_2d_rope, unified_head, vision_prediction_mode="2d" (and 2d RoPE + 2d prediction together), use_bridge=False
-and the embedding-stage switches (use_vision_position_embedding, norm_signals=False, concat_signals=False) against
+the embedding-stage switches (use_vision_position_embedding, norm_signals=False, concat_signals=False) and addition_mode against
 the fixture produced by the reference's own forward + autograd (tests/golden/make_golden_libra_f4.py) and the fp32 oracle on the
 same bf16-rounded weights; the cached generation path of each variant against the uncached forward."""
 import pytest
@@ -9,7 +9,7 @@ from helpers import load_golden, parity_report, rel_err, sub
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-VARIANTS = ("rope2d", "unified", "pred2d", "rope2d_pred2d", "nobridge", "vispos", "nonorm", "noconcat")
+VARIANTS = ("rope2d", "unified", "pred2d", "rope2d_pred2d", "nobridge", "vispos", "nonorm", "noconcat", "addition")
 
 
 def _build(name):
@@ -51,7 +51,7 @@ def test_f4_forward_backward_vs_reference_fixture(name):
     sdf = {k: v.to(BF).float().requires_grad_(True) for k, v in w.items()}
     kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
               max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"],
-              rope_2d_res=c["image_feature_resolution"] if over.get("use_2d_rope") else None)
+              rope_2d_res=c["image_feature_resolution"] if over.get("use_2d_rope") else None, addition=bool(over.get("addition_mode")))
     hid, flag = LO.model_forward(sdf, t0["in.input_ids"], t0["in.attention_mask"], t0["in.vision_indices"],
                                  t0["in.signal"].to(BF).float(), **kw)
     z = _oracle_logits(LO, sdf, hid, flag, over, c)

@@ -146,7 +146,7 @@ def test_greedy_generation_matches_reference_greedy_search():
 
 
 def test_f4_variants_match_reference():
-    """§8f-4: use_2d_rope, unified_head, vision_prediction_mode='2d' (and 2d rope + 2d prediction together), use_bridge=False - the oracle's
+    """§8f-4: use_2d_rope, unified_head, vision_prediction_mode='2d' (and 2d rope + 2d prediction together), use_bridge=False, the embedding-stage switches, addition_mode - the oracle's
     restatements against the reference's own forward + autograd (tests/golden/make_golden_libra_f4.py)."""
     t, meta = load_golden("libra_tiny_f4.safetensors")
     t0, _ = load_golden("libra_tiny.safetensors")
@@ -164,7 +164,8 @@ def test_f4_variants_match_reference():
         for k, v in sub(t, f"{name}.w.").items():
             sd[k] = v.clone()
         sd = {k: v.requires_grad_(True) for k, v in sd.items()}
-        hid, flag = LO.model_forward(sd, ids, am, vi, sig, rope_2d_res=res if over.get("use_2d_rope") else None, **kw)
+        hid, flag = LO.model_forward(sd, ids, am, vi, sig, rope_2d_res=res if over.get("use_2d_rope") else None,
+                                     addition=bool(over.get("addition_mode")), **kw)
         if over.get("use_2d_rope"):
             assert torch.equal(LO.position_ids_2d(vi, L, res), t[f"{name}.position_ids"])
         if over.get("unified_head"):
