@@ -733,6 +733,17 @@ def _compact(t2d: torch.Tensor, idx: torch.Tensor, tag: Optional[str] = None) ->
     return buf
 
 
+def _padded(t2d: torch.Tensor, tag: str) -> torch.Tensor:
+    """A sequence-order tensor as a reduction-major wgrad operand over ALL its rows: itself when its row count is a multiple of
+    64 (every training shape), otherwise a zero-padded arena copy."""
+    n = t2d.shape[0]
+    if n % 64 == 0:
+        return t2d
+    buf = _arows("b." + tag, n, t2d.shape[1], t2d.device)
+    buf.copy_(t2d)
+    return buf
+
+
 def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None, name: Optional[str] = None):
     """dW[out, in] = sum_tokens dy[t, out] x[t, in]; both operands token-major, padded (LIBRA_GEMM_A_T | _B_T).
     `name`: the parameter this gradient belongs to as a whole - when a data-parallel gradient store is capturing, the GEMM
@@ -1020,7 +1031,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     if add:
         K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, out=do)
         if w(a + "o_proj.weight"):
-            g[a + "o_proj.weight"] = _wg(dx_mid, o, name=a + "o_proj.weight")
+            g[a + "o_proj.weight"] = _wg(_padded(dx_mid, "dxm_a"), _padded(o, "o_a"), name=a + "o_proj.weight")
     elif n_l:
         K.gemm_nt(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do)
         if w(a + "o_proj.weight"):
@@ -1082,8 +1093,8 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
             K.gemm_nt(dqkvt, pk["wqkv_ab"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)   # K = 3H + 64
         nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
         if any_l([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"]):
-            hl = h if add else _compact(h, lang_idx, "h_l")
-            dw, gk, gv = _wg(dqkvt if add else _compact(dqkvt, lang_idx, "dqkvt_l"), hl,            # [3H + 64, H]
+            hl = _padded(h, "h_a") if add else _compact(h, lang_idx, "h_l")
+            dw, gk, gv = _wg(_padded(dqkvt, "dqkvt_a") if add else _compact(dqkvt, lang_idx, "dqkvt_l"), hl,   # [3H + 64, H]
                              post=lambda o: (o, o[3 * H:3 * H + d.rank].contiguous(), o[3 * H + 8:3 * H + 8 + d.rank].contiguous()))
             for j, nm in enumerate(("q", "k", "v")):
                 g[a + f"{nm}_proj.weight"] = dw[j * H:(j + 1) * H]

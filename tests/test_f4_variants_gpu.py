@@ -64,7 +64,9 @@ def test_f4_forward_backward_vs_reference_fixture(name):
                                    t0["in.vision_indices"], t0["in.signal"].to(BF), **kw)
     theirs = rel_err(hidb.float()[valid], hid.detach()[valid])
     assert e_h < max(1.5 * theirs, 3e-3), (name, e_h, theirs)
-    assert rel_err(out.hidden_states[-1].float().cpu()[valid], t[f"{name}.hidden"][valid]) < 2e-2
+    # against the reference's own run (fp32, UN-rounded weights): the bf16 op-by-op oracle's distance to it is the yardstick
+    floor = rel_err(hidb.float()[valid], t[f"{name}.hidden"][valid])
+    assert rel_err(out.hidden_states[-1].float().cpu()[valid], t[f"{name}.hidden"][valid]) < max(2e-2, 1.5 * floor), (name, floor)
     logits = out.logits.float().cpu()
     assert logits.shape == t[f"{name}.logits"].shape
     assert torch.equal(torch.isfinite(logits), torch.isfinite(t[f"{name}.logits"])), name
