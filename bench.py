@@ -411,6 +411,13 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img):
     gflop = sum(f for f, _ in gem) / 1e9
     gms = sum(t for _, t in gem)
     achieved = gflop / gms if gms > 0 else 0.0        # GFLOP/ms == TFLOP/s
+    shapes = {}                                       # per GEMM shape: launches, ms, TFLOP/s inside the step (the 48 largest by time)
+    for k, wk, t in recs:
+        if k == "gemm" and len(wk) > 2:
+            e = shapes.setdefault(wk[2], [0, 0.0, 0.0])
+            e[0] += 1; e[1] += t; e[2] += wk[0]
+    by_shape = [{"shape": n, "launches": c, "ms": round(ms, 2), "tflops": round(fl / 1e9 / ms, 1) if ms > 0 else 0.0}
+                for n, (c, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:48]]
     traffic, src = hbm_traffic("libra" if workload == "bridge" else "vit")
     return {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (256x256x64 tiles; + gemm_bf16_nt_kernel 128x128 tail rows, "
                                        "split-K wgrad slabs): every launch made through libra_gemm_bf16_nt*",
@@ -420,7 +427,7 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img):
             "algorithmic_bytes_per_launch": round(gbytes),
             "timing": "HIP events on the launch stream around every GEMM launch of one extra step",
             "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1), "gemm_ms_per_step": round(gms, 2),
-            "gemm_gflop_per_step": round(gflop, 1),
+            "gemm_gflop_per_step": round(gflop, 1), "by_shape": by_shape,
             "whole_step_frac": round(ips_per_gpu * gflop_step_img / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
 

@@ -178,7 +178,8 @@ def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tenso
     flags = (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0)
     prof = LaunchProfile.active
     if prof is not None:
-        ev = prof.bracket("gemm", (2.0 * M * N * Ka * G, 2.0 * G * (M * Ka + N * Ka + M * N)))
+        ev = prof.bracket("gemm", (2.0 * M * N * Ka * G, 2.0 * G * (M * Ka + N * Ka + M * N),
+                                   f"{G}x[{M}x{N}x{Ka}{' aT' if a_t else ''}{' bT' if b_t else ''}]"))
         ev[0].record()
     rc = _lib.lib().libra_gemm_bf16_nt_grouped(arr(a_list), a0.stride(0), arr(b_list), b0.stride(0), arr(outs), o0.stride(0),
                                                G, M, N, Ka, 1.0, 0, flags, _ptr(a_rows), a_phys, _ptr(c_rows), _stream())
@@ -533,7 +534,8 @@ def _gemm_flops(a, b, **kw):
     k = kw.get("k") or (a.shape[0] if a_t else a.shape[1])
     m = kw["a_rows"].numel() if kw.get("a_rows") is not None else (a.shape[1] if a_t else a.shape[0])
     n = b.shape[1] if b_t else b.shape[0]
-    return (2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))          # (FLOP, algorithmic operand + result bytes)
+    return (2.0 * m * n * k, 2.0 * (m * k + n * k + m * n),          # (FLOP, algorithmic operand + result bytes, shape tag)
+            f"{m}x{n}x{k}{' aT' if a_t else ''}{' bT' if b_t else ''}")
 
 
 gemm_nt = _profiled("gemm", _gemm_flops)(gemm_nt)
