@@ -755,6 +755,21 @@ def _wg(dy_c: torch.Tensor, x_c: torch.Tensor, post=None, name: Optional[str] = 
     return post(o) if post is not None else o
 
 
+def _wg_grouped(dys, xs, names):
+    """Up to 4 weight gradients of identical shape and operand strides as ONE launch (libra_gemm_bf16_nt_grouped): the low-rank
+    [4096 x 1024] gradients are 64 tiles of 256^2 each - a quarter of the chip per launch (0.58 PFLOP/s inside the step); three of
+    them together fill three quarters of one wave.  -> list of gradients (bucket views when a gradient store is capturing)."""
+    outs = []
+    for dy, x, n in zip(dys, xs, names):
+        o = dp.grad_out(n)
+        outs.append(o if o is not None else torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device))
+    same = lambda ts: len({(t.stride(0), tuple(t.shape)) for t in ts}) == 1
+    if not (same(outs) and same(dys) and same(xs)):
+        return [_wg(dy, x, name=n) for dy, x, n in zip(dys, xs, names)]
+    K.gemm_nt_grouped([_full(dy) for dy in dys], [_full(x) for x in xs], outs, a_t=True, b_t=True)
+    return outs
+
+
 def _norm_wgrad(dy, x, rstd, flag, lang_idx, vis_idx, want_l: bool, want_v: bool, H: int):
     """(dw_lang, dw_vis) bf16 of a routed RMSNorm.  When only one modality's weight is trainable (frozen-language pretraining)
     only that modality's rows are read (28 % of the tokens at the Libra-11B shape)."""
@@ -979,6 +994,7 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
     a, m = pre + "self_attn.", pre + "mlp."
     f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
     any_l = lambda names: any(w(n) for n in names)
+    defer_b = None                 # (dy, x, name) of vision_down_proj.weight_B until it can share a launch with vision_o_proj.weight_B
 
     # ================= MLP: x_out = x_mid + down(silu(gate(h2)) * up(h2)), routed =================
     dh2 = torch.empty((N, H), dtype=BF16, device=dev)
@@ -1001,8 +1017,8 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         tg, guv, actv, td = sv["tg"], sv["guv"], sv["actv"], sv["td"]
         dxo_v = _compact(dx_out, vis_idx, "dxo_v")
         dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=_arows("b.dtd", n_v, r, dev))
-        if w(m + "vision_down_proj.weight_B"):
-            g[m + "vision_down_proj.weight_B"] = _wg(dxo_v, td, name=m + "vision_down_proj.weight_B")
+        if w(m + "vision_down_proj.weight_B"):              # [H, r] like vision_o_proj.weight_B: both in one launch further down
+            defer_b = (dxo_v, td, m + "vision_down_proj.weight_B")
         dactv = K.gemm_nt(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True)                            # [n_v, I]
         if w(m + "vision_down_proj.weight_A"):
             g[m + "vision_down_proj.weight_A"] = _wg(dtd, actv, name=m + "vision_down_proj.weight_A")
@@ -1040,10 +1056,17 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         dxm_v = _compact(dx_mid, vis_idx, "dxm_v")
         dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=_arows("b.dto", n_v, r, dev))
         if w(a + "vision_o_proj.weight_B"):
-            g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"], name=a + "vision_o_proj.weight_B")
+            if defer_b is not None:
+                g[a + "vision_o_proj.weight_B"], g[defer_b[2]] = _wg_grouped([dxm_v, defer_b[0]], [sv["to"], defer_b[1]],
+                                                                             [a + "vision_o_proj.weight_B", defer_b[2]])
+                defer_b = None
+            else:
+                g[a + "vision_o_proj.weight_B"] = _wg(dxm_v, sv["to"], name=a + "vision_o_proj.weight_B")
         K.gemm_nt(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx, resid=do if add else None)
         if w(a + "vision_o_proj.weight_A"):
             g[a + "vision_o_proj.weight_A"] = _wg(dto, _compact(o, vis_idx, "o_v"), name=a + "vision_o_proj.weight_A")
+    if defer_b is not None:
+        g[defer_b[2]] = _wg(defer_b[0], defer_b[1], name=defer_b[2])
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
     dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
                                                sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5, out_lo=sv["o_lo"])
@@ -1115,9 +1138,15 @@ def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, l
         K.gemm_nt_grouped([dqkv_v[:, j * H:(j + 1) * H] for j in range(3)],
                           [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
                           [dt[:, j * r:(j + 1) * r] for j in range(3)], b_t=True)
-        for j, nm in enumerate(("q", "k", "v")):
-            if w(a + f"vision_{nm}_proj.weight_B"):
-                g[a + f"vision_{nm}_proj.weight_B"] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r], name=a + f"vision_{nm}_proj.weight_B")
+        bq = [a + f"vision_{nm}_proj.weight_B" for nm in ("q", "k", "v")]
+        if all(w(n) for n in bq):                                     # the three [H, r] gradients: one grouped launch
+            for n, gr in zip(bq, _wg_grouped([dqkv_v[:, j * H:(j + 1) * H] for j in range(3)],
+                                             [t[:, j * r:(j + 1) * r] for j in range(3)], bq)):
+                g[n] = gr
+        else:
+            for j, n in enumerate(bq):
+                if w(n):
+                    g[n] = _wg(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r], name=n)
         K.gemm_nt(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx, resid=dh if add else None)   # K = 3r + 64
         nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
         want_a = any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"])
