@@ -70,6 +70,7 @@ struct RopeArgs {
     const int* positions;                         // optional [N, pos_stride]: RoPE position of token n (NULL: n % S)
     int pos_stride;                               // 1, or 2 = use_2d_rope: even heads take column 0 (row position), odd heads column 1
     int max_pos;                                  // rows of cos / sin: explicit positions are clamped into the table
+    int tok;                                      // consecutive tokens per thread (ROPE_TOK; 1 for the few rows of a generation step)
 };
 
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
@@ -100,11 +101,11 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
     if (slot >= tpb || lt >= LT) return;
     const int c = lt & 15, h = lt >> 4;
     const int HD = p.H * 128;
-    const long n_first = (long)blockIdx.x * ROPE_TOK * tpb + slot;
+    const long n_first = (long)blockIdx.x * p.tok * tpb + slot;
     u32x4 wk[2][4], wv[2][4];
     int cur_mod = -1;
     int s = (int)(n_first % p.S);                             // position of the token in its sequence: one division per
-    for (int j = 0; j < ROPE_TOK; ++j, s += tpb) {            // thread, then stepped (a 64-bit modulo per token was ~100 VALU ops)
+    for (int j = 0; j < p.tok; ++j, s += tpb) {               // thread, then stepped (a 64-bit modulo per token was ~100 VALU ops)
         const long n = n_first + (long)j * tpb;
         if (n >= p.N) break;
         while (s >= p.S) s -= p.S;
@@ -325,7 +326,12 @@ static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, c
     a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
     a.positions = positions; a.pos_stride = (int)pos_stride; a.max_pos = (int)max_pos;
     const long LT = H * 16, tpb = LT >= 256 ? 1 : 256 / LT;
-    const long gx = (N + ROPE_TOK * tpb - 1) / (ROPE_TOK * tpb), gy = LT >= 256 ? (LT + 255) / 256 : 1;
+    // tokens per thread: ROPE_TOK amortises the bridge weights' registers over a run of tokens; with few rows (a generation step:
+    // one token per sequence) that serialised them - 8 dependent round trips in 2 workgroups, 14 us for 8 rows - so small problems
+    // take one token per thread and spread over the chip instead
+    const int tok = N >= 4096 ? ROPE_TOK : 1;
+    a.tok = tok;
+    const long gx = (N + tok * tpb - 1) / (tok * tpb), gy = LT >= 256 ? (LT + 255) / 256 : 1;
     if (gx > 0x7fffffffL || gy > 65535) return LIBRA_ERR_SHAPE;
     hipLaunchKernelGGL(rope_bridge_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, a);
     return launched();
