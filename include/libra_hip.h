@@ -70,6 +70,13 @@ int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* co
                                int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
                                const int32_t* c_rows, void* stream);
 
+/* The first half of LlamaMLP for a generation step (M <= 16 rows) in one launch: Y[M, I] = silu(A W_gate^T) * (A W_up^T),
+ * modeling_llama.py:199-201 (act_fn(gate_proj(x)) * up_proj(x)), W_gate_up = [2I, K] = gate rows then up rows (the packed operand
+ * the training GEMM uses).  Arithmetic = libra_gemm_bf16_nt followed by libra_swiglu, bit for bit (both products rounded to bf16,
+ * bf16(silu(g)) * u): HBM-bound weight streaming like the other M <= 16 GEMMs.  a_rows: optional row gather on A.                 */
+int libra_gemm_swiglu_skinny(const void* A, int64_t lda, const void* W_gate_up, int64_t ldw, void* Y, int64_t ldy, int64_t M,
+                             int64_t I, int64_t K, const int32_t* a_rows, int64_t a_phys_rows, void* stream);
+
 /* split-K variant for wgrad-shaped problems (small M,N, very long K; no epilogue): K slices on the 256^2
  * kernel, fp32 partial slabs in `workspace`, deterministic reduction to bf16 C.  plan() suggests the number
  * of slices for a shape (1 = use libra_gemm_bf16_nt).  N % 8 == 0; flags: LIBRA_GEMM_A_T / _B_T only.                                  */
@@ -178,6 +185,15 @@ int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, co
                           const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                           int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, const int* positions,
                           int64_t pos_stride, int64_t H, void* stream);
+/* The same for a generation step (one new token per sequence, row n = sequence n), which also stores the token's four rows
+ * K_same = rope(k), K_cross = rope(k + kb), V_same = v, V_cross = v + vb at slot *slot of the layer's caches [B, Lmax, H*128]
+ * (row / batch strides in elements; the reference's cache update, modeling_libra.py:344-361) - libra_rope_bridge_pos followed by
+ * libra_kv_cache_append in one launch.  `slot` is read on the device (capturable).                                              */
+int libra_rope_bridge_pos_append(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                                 const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                                 int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t B, const int* positions,
+                                 int64_t pos_stride, int64_t H, void* cache_k_same, void* cache_k_cross, void* cache_v_same,
+                                 void* cache_v_cross, int64_t row_stride, int64_t batch_stride, const int64_t* slot, void* stream);
 /* Append the new token of every sequence to a layer's four caches (the reference's `torch.cat` of past and present key / value
  * states, modeling_libra.py:344-361) in one launch: cache_x[b][*slot][0..W) = x[b][0..W) for x in (K_same, K_cross, V_same,
  * V_cross); x [B, W] with row strides ld_x, caches [B, Lmax, W] with row / batch strides in elements, slot = the position,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "libra_gemm_bf16_nt_routed": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
                                   _F, _I64, _I, _P, _I64, _P, _P],
     "libra_gemm_bf16_nt_grouped": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _F, _I64, _I, _P, _I64, _P, _P],
+    "libra_gemm_swiglu_skinny": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "libra_gemm_splitk_plan": [_I64, _I64, _I64],
     "libra_gemm_splitk_workspace_bytes": [_I64, _I64, _I64],
     "libra_gemm_bf16_nt_splitk": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, C.c_size_t, _P],
@@ -43,6 +44,8 @@ SIGNATURES = {
     "libra_rmsnorm_routed_fwd": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _F, _P],
     "libra_rope_bridge": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "libra_rope_bridge_pos": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, _P],
+    "libra_rope_bridge_pos_append": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _I64,
+                                     _P, _P, _P, _P, _I64, _I64, _P, _P],
     "libra_kv_cache_append": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P],
     "libra_bridge_attn_decode_workspace_bytes": [_I64, _I64],
     "libra_bridge_attn_decode": [_P, _I64, _P, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P,

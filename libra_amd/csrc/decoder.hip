@@ -71,6 +71,9 @@ struct RopeArgs {
     int pos_stride;                               // 1, or 2 = use_2d_rope: even heads take column 0 (row position), odd heads column 1
     int max_pos;                                  // rows of cos / sin: explicit positions are clamped into the table
     int tok;                                      // consecutive tokens per thread (ROPE_TOK; 1 for the few rows of a generation step)
+    // generation step (one token per sequence, token n = sequence n): also store the token's four K / V rows at cache slot *slot
+    bf16_t* cache_ks; bf16_t* cache_kc; bf16_t* cache_vs; bf16_t* cache_vc;      // [B, Lmax, H*128] each, or all null
+    long c_row, c_batch; const long long* slot;
 };
 
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
@@ -167,6 +170,13 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
             *(u32x2*)(p.qkv + n * p.ld + HD + col) = pack4(ko[hf]);
             *(u32x2*)(p.k_cross + n * p.ldc + col) = pack4(kc[hf]);
             *(u32x2*)(p.v_cross + n * p.ldc + col) = pack4(vc[hf]);
+            if (p.cache_ks) {
+                const long at = n * p.c_batch + (long)p.slot[0] * p.c_row + col;
+                *(u32x2*)(p.cache_ks + at) = pack4(ko[hf]);
+                *(u32x2*)(p.cache_kc + at) = pack4(kc[hf]);
+                *(u32x2*)(p.cache_vs + at) = pack4(v[hf]);
+                *(u32x2*)(p.cache_vc + at) = pack4(vc[hf]);
+            }
         }
     }
 }
@@ -311,8 +321,13 @@ extern "C" int libra_rmsnorm_routed_fwd(const void* x, int64_t ldx, const void* 
 static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
                            const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                            int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t N, int64_t S,
-                           int64_t H, const int* positions, int64_t pos_stride, void* stream) {
+                           int64_t H, const int* positions, int64_t pos_stride, void* stream, void* const* cache = nullptr,
+                           int64_t c_row = 0, int64_t c_batch = 0, const int64_t* slot = nullptr) {
     if (N <= 0) return LIBRA_OK;
+    if (cache) {
+        if (!slot || c_row < H * 128 || c_batch < c_row || (c_row % 8) || (c_batch % 8)) return LIBRA_ERR_SHAPE;
+        for (int i = 0; i < 4; ++i) if (!cache[i] || !al16(cache[i])) return LIBRA_ERR_ALIGN;
+    }
     if (positions && pos_stride != 1 && pos_stride != 2) return LIBRA_ERR_SHAPE;
     if (H <= 0 || S <= 0 || S > max_pos || ld < 3 * H * 128 || ldt < 16 || ldc < H * 128) return LIBRA_ERR_SHAPE;
     if ((ld % 8) || (ldt % 8) || (ldc % 8)) return LIBRA_ERR_ALIGN;
@@ -325,6 +340,9 @@ static int rope_bridge_run(void* qkv, int64_t ld, const void* tb, int64_t ldt, c
     a.flag = flag; a.cos = (const bf16_t*)cos; a.sin = (const bf16_t*)sin;
     a.k_cross = (bf16_t*)k_cross; a.v_cross = (bf16_t*)v_cross; a.ldc = ldc; a.N = N; a.S = (int)S;
     a.positions = positions; a.pos_stride = (int)pos_stride; a.max_pos = (int)max_pos;
+    a.cache_ks = cache ? (bf16_t*)cache[0] : nullptr; a.cache_kc = cache ? (bf16_t*)cache[1] : nullptr;
+    a.cache_vs = cache ? (bf16_t*)cache[2] : nullptr; a.cache_vc = cache ? (bf16_t*)cache[3] : nullptr;
+    a.c_row = c_row; a.c_batch = c_batch; a.slot = (const long long*)slot;
     const long LT = H * 16, tpb = LT >= 256 ? 1 : 256 / LT;
     // tokens per thread: ROPE_TOK amortises the bridge weights' registers over a run of tokens; with few rows (a generation step:
     // one token per sequence) that serialised them - 8 dependent round trips in 2 workgroups, 14 us for 8 rows - so small problems
@@ -352,6 +370,18 @@ extern "C" int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int6
     if (!positions) return LIBRA_ERR_ALIGN;
     return rope_bridge_run(qkv, ld, tb, ldt, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, max_pos, k_cross, v_cross, ldc, N, max_pos,
                            H, positions, pos_stride, stream);
+}
+
+extern "C" int libra_rope_bridge_pos_append(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
+                                            const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
+                                            int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t B,
+                                            const int* positions, int64_t pos_stride, int64_t H, void* cache_k_same,
+                                            void* cache_k_cross, void* cache_v_same, void* cache_v_cross, int64_t row_stride,
+                                            int64_t batch_stride, const int64_t* slot, void* stream) {
+    if (!positions) return LIBRA_ERR_ALIGN;
+    void* const cache[4] = {cache_k_same, cache_k_cross, cache_v_same, cache_v_cross};
+    return rope_bridge_run(qkv, ld, tb, ldt, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, max_pos, k_cross, v_cross, ldc, B, max_pos, H,
+                           positions, pos_stride, stream, cache, row_stride, batch_stride, slot);
 }
 
 extern "C" int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows,

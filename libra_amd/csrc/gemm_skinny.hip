@@ -15,6 +15,7 @@ struct SkinnyArgs {
     const int* a_rows; const int* c_rows;
     long lda, ldb, ldc, ldr;
     int M, N, K;
+    int I;                          // SW instantiation: B = [gate rows 0..I) ; up rows I..2I), C[M, I] = silu(A.gate^T) * (A.up^T)
 };
 
 typedef __bf16 bf16x2_sk __attribute__((ext_vector_type(2)));
@@ -34,12 +35,17 @@ __device__ __forceinline__ float dot8(const u32x4 a, const u32x4 b, float c) {
 // [Round 3: one wave per 8 columns gave N / 8 waves - 512 for the o / down projections, two per CU - each walking K serially
 //  with an exposed L2 round trip for its A chunk per pass: 1.6-2.8 TB/s on the N = 4096 shapes.  Splitting K over the waves of a
 //  workgroup multiplies the loads in flight by KS and shortens every wave's serial chain to K / (512 KS) passes.]
-template <int MR, int NC, int KS>
+// SW (the MLP's first half in one launch, LlamaMLP act_fn(gate) * up, modeling_llama.py:199-201): a workgroup owns NC / 2 output
+// columns and streams the gate row AND the up row of each; the epilogue applies swiglu_kernel's exact arithmetic (both products
+// rounded to bf16 first, bf16(silu(g)) * u) - bit-identical to the GEMM + libra_swiglu pair, one launch and one round trip of the
+// [M, 2I] intermediate less per generated token and layer.
+template <int MR, int NC, int KS, bool SW = false>
 __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const SkinnyArgs p) {
     __shared__ float red[KS > 1 ? KS : 1][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * NC;
+    constexpr int HALF = NC / 2;
+    const int n0 = blockIdx.x * (SW ? HALF : NC);
     long arow[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
@@ -57,7 +63,11 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const SkinnyArgs p
     const bf16_t* wrow[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int n = n0 + c < p.N ? n0 + c : p.N - 1;                        // clamped columns are computed and dropped
+        int n = n0 + c < p.N ? n0 + c : p.N - 1;                              // clamped columns are computed and dropped
+        if constexpr (SW) {
+            const int col = n0 + (c % HALF) < p.I ? n0 + (c % HALF) : p.I - 1;
+            n = c < HALF ? col : p.I + col;
+        }
         wrow[c] = p.B + (long)n * p.ldb;
     }
     u32x4 w[NC];
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const SkinnyArgs p
             for (int e = 0; e < 4; ++e) {
                 const int idx = e + 4 * (lane >> 4);
                 const int cc = c + idx / MR, m = idx % MR;
-                if (KS > 1) {
+                if (KS > 1 || SW) {
                     red[wave][cc * MR + m] = rs[e];
                 } else {
                     const int n = n0 + cc;
@@ -110,7 +120,20 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const SkinnyArgs p
             }
         }
     }
-    if (KS > 1) {
+    if constexpr (SW) {
+        __syncthreads();
+        if (wave == 0 && lane < HALF * MR) {                                  // lane = c * MR + m, c < HALF: gate sum here, up sum 32 lanes on
+            float g = 0.f, u = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) { g += red[k][lane]; u += red[k][lane + HALF * MR]; }
+            const int n = n0 + lane / MR, m = lane % MR;
+            if (m < p.M && n < p.I) {
+                const long crow = p.c_rows ? p.c_rows[m] : m;
+                const float gb = bf2f(f2bf(g)), ub = bf2f(f2bf(u));
+                p.C[crow * p.ldc + n] = f2bf(bf2f(f2bf(gb / (1.0f + __expf(-gb)))) * ub);
+            }
+        }
+    } else if (KS > 1) {
         __syncthreads();
         if (wave == 0) {                                                      // lane = c * MR + m
             float r = 0.f;
@@ -130,6 +153,28 @@ __global__ __launch_bounds__(64 * KS) void gemm_skinny_kernel(const SkinnyArgs p
 
 using namespace libra;
 
+static int skinny_launch(SkinnyArgs& p, void* stream) {
+    // waves per workgroup: enough workgroup-waves to cover the chip ~4 times over, never more K slices than 512-element passes
+    const bool sw = p.I > 0;
+    const long ncols = sw ? p.I : p.N;
+    const long per = p.M <= 8 ? (sw ? 4 : 8) : (sw ? 2 : 4);                  // output columns per workgroup
+    const long groups = (ncols + per - 1) / per;
+    const long passes = (p.K + 511) / 512;
+    int ks = 1;
+    while (ks < 8 && groups * ks < 4096 && ks * 2 <= passes) ks *= 2;
+    const dim3 grid((unsigned)groups);
+#define LIBRA_SKINNY(MR_, NC_, KS_) \
+    do { if (sw) hipLaunchKernelGGL((gemm_skinny_kernel<MR_, NC_, KS_, true>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, p); \
+         else hipLaunchKernelGGL((gemm_skinny_kernel<MR_, NC_, KS_, false>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, p); } while (0)
+    if (p.M <= 8) {
+        if (ks == 1) LIBRA_SKINNY(8, 8, 1); else if (ks == 2) LIBRA_SKINNY(8, 8, 2); else if (ks == 4) LIBRA_SKINNY(8, 8, 4); else LIBRA_SKINNY(8, 8, 8);
+    } else {
+        if (ks == 1) LIBRA_SKINNY(16, 4, 1); else if (ks == 2) LIBRA_SKINNY(16, 4, 2); else if (ks == 4) LIBRA_SKINNY(16, 4, 4); else LIBRA_SKINNY(16, 4, 8);
+    }
+#undef LIBRA_SKINNY
+    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+}
+
 // Internal launcher (declared in gemm_bf16.hip).  Arguments were validated there: K % 64 == 0, 16-byte aligned A / B, M <= 16.
 extern "C" int libra_gemm_skinny_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                                          int64_t N, int64_t K, const void* resid, int64_t ldr, const int32_t* a_rows,
@@ -137,19 +182,21 @@ extern "C" int libra_gemm_skinny_launch_(const void* A, int64_t lda, const void*
     SkinnyArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C; p.resid = (const bf16_t*)resid;
     p.a_rows = a_rows; p.c_rows = c_rows; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K;
-    // waves per workgroup: enough workgroup-waves to cover the chip ~4 times over, never more K slices than 512-element passes
-    const long groups = M <= 8 ? (N + 7) / 8 : (N + 3) / 4;
-    const long passes = (K + 511) / 512;
-    int ks = 1;
-    while (ks < 8 && groups * ks < 4096 && ks * 2 <= passes) ks *= 2;
-    const dim3 grid((unsigned)groups);
-#define LIBRA_SKINNY(MR_, NC_, KS_) hipLaunchKernelGGL((gemm_skinny_kernel<MR_, NC_, KS_>), grid, dim3(64 * KS_), 0, (hipStream_t)stream, p)
-    if (M <= 8) {
-        if (ks == 1) LIBRA_SKINNY(8, 8, 1); else if (ks == 2) LIBRA_SKINNY(8, 8, 2); else if (ks == 4) LIBRA_SKINNY(8, 8, 4); else LIBRA_SKINNY(8, 8, 8);
-    } else {
-        if (ks == 1) LIBRA_SKINNY(16, 4, 1); else if (ks == 2) LIBRA_SKINNY(16, 4, 2); else if (ks == 4) LIBRA_SKINNY(16, 4, 4); else LIBRA_SKINNY(16, 4, 8);
-    }
-#undef LIBRA_SKINNY
-    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.I = 0;
+    return skinny_launch(p, stream);
+}
+
+extern "C" int libra_gemm_swiglu_skinny(const void* A, int64_t lda, const void* W_gate_up, int64_t ldw, void* Y, int64_t ldy,
+                                        int64_t M, int64_t I, int64_t K, const int32_t* a_rows, int64_t a_phys_rows, void* stream) {
+    if (M <= 0 || I <= 0) return LIBRA_OK;
+    if (!A || !W_gate_up || !Y || M > 16 || K <= 0 || (K % 64) || I > (1 << 29)) return LIBRA_ERR_SHAPE;
+    if ((lda % 8) || (ldw % 8) || lda < K || ldw < K || ldy < I) return LIBRA_ERR_SHAPE;
+    if (a_rows && a_phys_rows <= 0) return LIBRA_ERR_SHAPE;
+    if ((a_rows ? a_phys_rows : M) * lda >= (1LL << 31) || 2 * I * ldw >= (1LL << 31)) return LIBRA_ERR_SHAPE;
+    if ((((uintptr_t)A | (uintptr_t)W_gate_up) & 15) || ((uintptr_t)Y & 1)) return LIBRA_ERR_ALIGN;
+    SkinnyArgs p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)W_gate_up; p.C = (bf16_t*)Y; p.resid = nullptr;
+    p.a_rows = a_rows; p.c_rows = nullptr; p.lda = lda; p.ldb = ldw; p.ldc = ldy; p.ldr = 0;
+    p.M = (int)M; p.N = (int)(2 * I); p.K = (int)K; p.I = (int)I;
+    return skinny_launch(p, stream);
 }

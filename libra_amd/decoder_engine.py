@@ -369,17 +369,19 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
             K.gemm_nt_grouped([t[:, j * r:(j + 1) * r] for j in range(3)],
                               [sd[a + f"vision_{nm}_proj.weight_B"] for nm in ("q", "k", "v")],
                               [qkv[:, j * H:(j + 1) * H] for j in range(3)], c_rows=vis_idx)
+    fused_append = cache is not None and slot is not None and positions is not None
     if positions is None:
         kc, vc = K.rope_bridge(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, S, d.heads)
-    else:
-        kc, vc = K.rope_bridge_pos(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, positions, d.heads)
+    else:                                                   # (decode step: the new token's four cache rows go out of the same launch)
+        kc, vc = K.rope_bridge_pos(qkv, tb, pk["bk_l"], pk["bk_v"], pk["bv_l"], pk["bv_v"], flag, cos, sin, positions, d.heads,
+                                   append=(cache.layers[i], slot) if fused_append else None)
     if cache is not None:                                   # the cache slots
         new_rows = (qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc)
         if slot is None:
             for buf, rows in zip(cache.layers[i], new_rows):
                 buf[:, :S].copy_(rows.view(B, S, H))         # prefill: plumbing copies
-        else:
-            K.kv_cache_append(new_rows, cache.layers[i], slot)                # decode step: the four appends in one launch
+        elif not fused_append:
+            K.kv_cache_append(new_rows, cache.layers[i], slot)
     if slot is None:
         o_lo = torch.empty((N, H), dtype=BF16, device=dev) if save else None   # rounding residual of o (the backward's D = dO.O)
         o, lse = K.bridge_attn_fwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, flag, lens, B, S, d.heads,
@@ -403,9 +405,12 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
                                  sd[pre + "vision_post_attention_layernorm.weight"], flag, d.eps, save_rstd=True)
     x_out = torch.empty_like(x) if need_out else None      # (a recompute pass stops before the last down projections)
     gu = act = tg = guv = actv = td = None
-    if n_l:
+    if n_l and n_l <= 16 and not save:                       # generation step: gate | up GEMM + SwiGLU as one weight-streaming launch
+        act = K.gemm_swiglu_skinny(h2, pk["wgu"], a_rows=lang_idx)
+    elif n_l:
         gu = K.gemm_nt(h2, pk["wgu"], a_rows=lang_idx)                                 # [n_l, 2I]
         act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save, "act"))
+    if n_l:
         if need_out:
             K.gemm_nt(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid)
     if n_v:

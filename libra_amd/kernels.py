@@ -146,6 +146,28 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     return out
 
 
+def gemm_swiglu_skinny(a: torch.Tensor, w_gate_up: torch.Tensor, *, a_rows: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """silu(a @ W_gate^T) * (a @ W_up^T) for M <= 16 rows in one launch (libra_gemm_swiglu_skinny): w_gate_up [2I, K] = gate rows
+    then up rows.  Same bits as gemm_nt + swiglu."""
+    _chk2d(a, "a"); _chk2d(w_gate_up, "w_gate_up")
+    M = a_rows.numel() if a_rows is not None else a.shape[0]
+    I, Kd = w_gate_up.shape[0] // 2, w_gate_up.shape[1]
+    if a.shape[1] != Kd or w_gate_up.shape[0] != 2 * I or M > 16:
+        raise ValueError(f"gemm_swiglu_skinny: a {tuple(a.shape)} w {tuple(w_gate_up.shape)} rows {M} (<= 16)")
+    if a_rows is not None and a_rows.dtype != torch.int32:
+        raise ValueError("gemm_swiglu_skinny: a_rows must be int32")
+    if out is None:
+        out = torch.empty((M, I), dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    if out.shape != (M, I):
+        raise ValueError("gemm_swiglu_skinny: out shape")
+    rc = _lib.lib().libra_gemm_swiglu_skinny(a.data_ptr(), a.stride(0), w_gate_up.data_ptr(), w_gate_up.stride(0), out.data_ptr(),
+                                             out.stride(0), M, I, Kd, _ptr(a_rows), a.shape[0], _stream())
+    _lib.check(rc, f"gemm_swiglu_skinny M={M} I={I} K={Kd}")
+    return out
+
+
 def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], *,
                     a_t: bool = False, b_t: bool = False, a_rows: Optional[torch.Tensor] = None,
                     c_rows: Optional[torch.Tensor] = None) -> Sequence[torch.Tensor]:
@@ -566,9 +588,10 @@ def rope_bridge(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, S: int, H: int)
     return kc, vc
 
 
-def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, H: int):
+def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, H: int, *, append=None):
     """rope_bridge with explicit int32 positions: [N] (cached decode step, left-padded prompts) or [N, 2] (use_2d_rope: even heads
-    rotate by column 0, odd heads by column 1)."""
+    rotate by column 0, odd heads by column 1).  `append` = (caches, slot): a generation step (row n = sequence n) - the four K / V
+    rows of every new token are also stored at `slot` (cuda int64 [1]) of the layer's four caches [B, Lmax, H*128] in this launch."""
     _chk2d(qkv, "qkv"); _chk2d(tb, "tb")
     N = qkv.shape[0]
     if positions.dtype != torch.int32 or positions.numel() not in (N, 2 * N) or not positions.is_contiguous():
@@ -576,10 +599,21 @@ def rope_bridge_pos(qkv, tb, bk_l, bk_v, bv_l, bv_v, flag, cos, sin, positions, 
     pstride = positions.numel() // N
     kc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
     vc = torch.empty((N, H * 128), dtype=BF16, device=qkv.device)
-    rc = _lib.lib().libra_rope_bridge_pos(qkv.data_ptr(), qkv.stride(0), tb.data_ptr(), tb.stride(0), bk_l.data_ptr(),
-                                          bk_v.data_ptr(), bv_l.data_ptr(), bv_v.data_ptr(), flag.data_ptr(), cos.data_ptr(),
-                                          sin.data_ptr(), cos.shape[0], kc.data_ptr(), vc.data_ptr(), kc.stride(0), N,
-                                          positions.data_ptr(), pstride, H, _stream())
+    args = (qkv.data_ptr(), qkv.stride(0), tb.data_ptr(), tb.stride(0), bk_l.data_ptr(), bk_v.data_ptr(), bv_l.data_ptr(),
+            bv_v.data_ptr(), flag.data_ptr(), cos.data_ptr(), sin.data_ptr(), cos.shape[0], kc.data_ptr(), vc.data_ptr(), kc.stride(0),
+            N, positions.data_ptr(), pstride, H)
+    if append is None:
+        rc = _lib.lib().libra_rope_bridge_pos(*args, _stream())
+    else:
+        caches, slot = append
+        c0 = caches[0]
+        for c in caches:
+            if c.dim() != 3 or c.shape[0] != N or c.shape[2] != H * 128 or c.stride(2) != 1 or c.dtype != BF16 or c.stride() != c0.stride():
+                raise ValueError("rope_bridge_pos: caches must be four [B, Lmax, H*128] bf16 buffers with identical strides, B = rows")
+        if slot.dtype != torch.int64 or slot.numel() != 1 or not slot.is_cuda:
+            raise ValueError("rope_bridge_pos: slot must be a cuda int64 tensor with one element")
+        rc = _lib.lib().libra_rope_bridge_pos_append(*args, caches[0].data_ptr(), caches[1].data_ptr(), caches[2].data_ptr(),
+                                                     caches[3].data_ptr(), c0.stride(1), c0.stride(0), slot.data_ptr(), _stream())
     _lib.check(rc, "rope_bridge_pos")
     return kc, vc
 

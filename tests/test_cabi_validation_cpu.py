@@ -75,6 +75,11 @@ def test_generation_entry_points_argument_validation(L):
     assert call(kc=None) == ERR_ALIGN
     assert call(ks=P(0x10008)) == ERR_ALIGN
     assert call(B=0) == OK
+    # fused gate | up + SwiGLU of a generation step: at most 16 rows, K a multiple of 64, K-contiguous operands
+    base = dict(A=FAKE, lda=4096, W=FAKE, ldw=4096, Y=FAKE, ldy=11008, M=8, I=11008, K=4096, ar=None, ap=8, st=None)
+    sw = lambda **kw: L.libra_gemm_swiglu_skinny(*[dict(base, **kw)[k] for k in base])
+    assert sw(M=17) == ERR_SHAPE and sw(K=4000) == ERR_SHAPE and sw(lda=2048) == ERR_SHAPE and sw(ldy=100) == ERR_SHAPE
+    assert sw(W=None) == ERR_SHAPE and sw(A=P(0x10008)) == ERR_ALIGN and sw(M=0) == OK and sw(ar=FAKE, ap=0) == ERR_SHAPE
 
 
 def test_splitk_plan_for_the_baseline_shapes(L):

@@ -332,6 +332,26 @@ def test_rope_bridge_bwd(K):
     assert torch.equal(dtb, torch.full((N, 64), 3.0, dtype=BF, device="cuda"))
 
 
+@pytest.mark.parametrize("M,I,K_", [(8, 11008, 4096), (1, 1002, 576), (16, 2752, 1024), (5, 4096, 11008)])
+def test_gemm_swiglu_skinny_is_the_gemm_then_swiglu_bit_for_bit(K, M, I, K_):
+    """The generation step's fused gate | up GEMM + SwiGLU (libra_gemm_swiglu_skinny) against the two launches it replaces, with and
+    without a row gather on A, plus a float reference; ragged I (not a multiple of the columns per workgroup)."""
+    a = rnd(M + 7, K_, seed=51, scale=0.5)
+    w = rnd(2 * I, K_, seed=52, scale=0.05)
+    rows = torch.randperm(M + 7, generator=torch.Generator().manual_seed(7))[:M].to(torch.int32).cuda()
+    ident = torch.arange(M, dtype=torch.int32).cuda()
+    for ar in (ident, rows):          # (row-mapped calls, as the decode step makes them: a plain M = 8 gemm_nt may take the split-K MFMA route)
+        out = K.gemm_swiglu_skinny(a, w, a_rows=ar)
+        assert out.shape == (M, I)
+        if I % 8 == 0:                # (libra_swiglu wants 16-byte rows; the ragged case is checked against the float reference below)
+            gu = K.gemm_nt(a, w, a_rows=ar)
+            ref = K.swiglu(gu[:, :I], gu[:, I:])
+            assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+    assert torch.equal(K.gemm_swiglu_skinny(a[:M], w), K.gemm_swiglu_skinny(a, w, a_rows=ident))
+    af = a[:M].float()
+    close(K.gemm_swiglu_skinny(a[:M], w), F.silu(af @ w[:I].float().t()) * (af @ w[I:].float().t()), rel=2e-2, what="swiglu skinny")
+
+
 def test_swiglu_gather_ce(K):
     rows, I = 77, 512
     gu = rnd(rows, 2 * I, seed=1)
@@ -374,6 +394,34 @@ def test_rope_bridge_with_explicit_positions(K):
     sub = qkv[pick].contiguous()
     kc2, vc2 = K.rope_bridge_pos(sub, tb[pick].contiguous(), *w, flag[pick].contiguous(), cos, sin, (pick % S).to(torch.int32), H)
     assert torch.equal(sub, full[pick]) and torch.equal(kc2, kc[pick]) and torch.equal(vc2, vc[pick])
+
+
+@pytest.mark.parametrize("B,H", [(8, 32), (3, 2)])
+def test_rope_bridge_pos_with_cache_append(K, B, H):
+    """A generation step's rope_bridge_pos(append=...) == rope_bridge_pos followed by kv_cache_append, bit for bit; the rest of the
+    caches untouched; the same for 2d positions."""
+    from oracle import libra_oracle as LO
+    D, Lmax = H * 128, 13
+    cosf, sinf = LO.rope_tables(128, 64)
+    cos, sin = cosf.to(BF).cuda(), sinf.to(BF).cuda()
+    w = [rnd(D, 8, seed=3 + i, scale=0.3) for i in range(4)]
+    flag = _flags(B, 9, "random").cuda()
+    tb = torch.zeros(B, 64, dtype=BF, device="cuda"); tb[:, :16] = rnd(B, 16, seed=2)
+    slot = torch.tensor([5], dtype=torch.int64, device="cuda")
+    for pos in (torch.arange(B, dtype=torch.int32).cuda() * 3 + 1,
+                torch.stack([torch.arange(B) * 2 + 1, torch.arange(B) + 4], 1).to(torch.int32).cuda().contiguous()):
+        qkv = rnd(B, 3 * D + 64, seed=1)[:, :3 * D]                 # a column slice of the wider activation buffer, as in the engine
+        a, b = qkv.clone(), qkv.clone()
+        caches_a = [rnd(B, Lmax, D, seed=20 + i) for i in range(4)]
+        caches_b = [c.clone() for c in caches_a]
+        kc, vc = K.rope_bridge_pos(a, tb, *w, flag, cos, sin, pos, H)
+        K.kv_cache_append((a[:, D:2 * D], kc, a[:, 2 * D:], vc), caches_a, slot)
+        kc2, vc2 = K.rope_bridge_pos(b, tb, *w, flag, cos, sin, pos, H, append=(caches_b, slot))
+        assert torch.equal(a, b) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
+        for x, y in zip(caches_a, caches_b):
+            assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        K.rope_bridge_pos(b, tb, *w, flag, cos, sin, pos, H, append=(caches_b, slot.to(torch.int32)))
 
 
 @pytest.mark.parametrize("B,H,Lmax,mode", [(1, 1, 16, "span"), (3, 2, 77, "random"), (2, 4, 300, "allvis"), (8, 32, 2048, "span")])
