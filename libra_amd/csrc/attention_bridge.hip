@@ -76,9 +76,19 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     int q = q0w + l31;
     q = q < S ? q : S - 1;
 
+    // ---- every per-lane global operand of the prologue is REQUESTED before the first wait: the query's modality byte and its Q
+    // fragments (lane (q = l31, half fk) holds Q[q][16*ks + 8*fk .. +8], ks = 0..7) ride the same memory round trip as the flag
+    // bytes of the mask pass (one workgroup per CU: nothing else covers a prologue's serial round trips - there were three)
+    const int q_vis_raw = p.flag[tok0 + q];
+    bf16x8 qf[8];
+    {
+        const bf16_t* qp = p.q + (tok0 + q) * p.ldq + h * BD + fk * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
     // ---- key-modality masks of this sequence into LDS (ballot over 32 flags) ----
     modality_masks(p.flag + tok0, S, kmask, tid, 512);
-    const bool q_vis = p.flag[tok0 + q] != 0;
+    const bool q_vis = q_vis_raw != 0;
     // block-level query modality presence (for staging decisions all waves must agree on)
     int* qpres = (int*)(kmask + 192);        // all LDS lives in the one dynamic array (a second __shared__ object
     if (tid < 2) qpres[tid] = 0;             // would make hipcc drain the direct-to-LDS queue before every ds_read)
@@ -93,13 +103,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     const bool wV = __ballot(q_vis && (q0w + l31) < S) != 0;        // this wave's query modalities
     const bool wL = __ballot(!q_vis && (q0w + l31) < S) != 0;
 
-    // ---- Q fragments: lane (q = l31, half fk) holds Q[q][16*ks + 8*fk .. +8], ks = 0..7 ----
-    bf16x8 qf[8];
-    {
-        const bf16_t* qp = p.q + (tok0 + q) * p.ldq + h * BD + fk * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
     const bf16_t* ks_base = p.k_same + tok0 * p.ldk + h * BD;
     const bf16_t* kc_base = p.k_cross + tok0 * p.ldkc + h * BD;
     const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * BD;

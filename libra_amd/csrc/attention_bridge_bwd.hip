@@ -90,16 +90,9 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
     const bool qin = q < S;
     q = qin ? q : S - 1;
 
-    modality_masks(p.flag + tok0, S, kmask, tid, 512);
-    const bool q_vis = p.flag[tok0 + q] != 0;
-    if (tid < 2) qpres[tid] = 0;
-    __syncthreads();
-    if (__ballot(qin && fk == 0 && q_vis)) if (lane == 0) atomicOr(&qpres[1], 1);
-    if (__ballot(qin && fk == 0 && !q_vis)) if (lane == 0) atomicOr(&qpres[0], 1);
-    __syncthreads();
-    const bool blkL = __builtin_amdgcn_readfirstlane(qpres[0]) != 0, blkV = __builtin_amdgcn_readfirstlane(qpres[1]) != 0;
-    const bool wV = __ballot(q_vis && qin) != 0, wL = __ballot(!q_vis && qin) != 0;
-
+    // every per-lane global operand of the prologue is requested before the first wait (one round trip instead of three: with one
+    // workgroup per CU nothing else covers them): modality byte, Q and dO fragments, L and D of this lane's query
+    const int q_vis_raw = p.flag[tok0 + q];
     bf16x8 qf[8], dof[8];
     {
         const bf16_t* qp = p.q + (tok0 + q) * p.ldq + h * D128 + fk * 8;
@@ -110,6 +103,16 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
     const long sidx = ((long)b * p.H + h) * S + q;
     float nLq2 = -p.lse[sidx] * LOG2E;
     float Dq = p.delta[sidx];
+    modality_masks(p.flag + tok0, S, kmask, tid, 512);
+    const bool q_vis = q_vis_raw != 0;
+    if (tid < 2) qpres[tid] = 0;
+    __syncthreads();
+    if (__ballot(qin && fk == 0 && q_vis)) if (lane == 0) atomicOr(&qpres[1], 1);
+    if (__ballot(qin && fk == 0 && !q_vis)) if (lane == 0) atomicOr(&qpres[0], 1);
+    __syncthreads();
+    const bool blkL = __builtin_amdgcn_readfirstlane(qpres[0]) != 0, blkV = __builtin_amdgcn_readfirstlane(qpres[1]) != 0;
+    const bool wV = __ballot(q_vis && qin) != 0, wL = __ballot(!q_vis && qin) != 0;
+
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { pin(qf[ks]); pin(dof[ks]); }   // prologue loads have landed before any LDS-DMA is in flight
     pin(nLq2); pin(Dq);
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
 constexpr int KV_RES = 4 * 16384;             // resident K_same, K_cross, V_same, V_cross: [64 keys][128 d] each
 constexpr int QD_STAGE = 2 * 16384 + 512;     // Q image, dO image (64 queries each), L[64], D[64]
 constexpr int DKV_LDS_B = KV_RES + 2 * QD_STAGE + 1024;
+// SHARE build: + the P hand-over slots of the four (dV wave, dK wave) pairs (2 slots x 2 KiB each) and their sequence words
+constexpr int DKV_XP = DKV_LDS_B;
+constexpr int DKV_LDS_SHARE = DKV_LDS_B + 4 * 2 * 2048 + 64;
 
 // resident operand tile: two N-type [64 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 16 KiB; 8 waves
 __device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, unsigned ld_b, int key0, int S, char* dst, int wave, int lane) {
@@ -305,6 +311,13 @@ __device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, uns
 
 // Lane-constant LDS addressing: every fragment address is a per-lane constant XOR a compile-time constant (one VALU op per
 // read) instead of the swizzle arithmetic rebuilt per read (the round-1 PMC profile counted 12.4 VALU per MFMA in this kernel).
+// SHARE = true: the dV wave and the dK wave of a (key sub-block, query half) pair sit on the same SIMD and used to compute the SAME
+// S = Q K^T block each (40 MFMAs per 32 x 32 block pair for 32 of arithmetic, and the dK wave - S, dP, dK - was the long pole of
+// every iteration).  Now the dV wave alone forms P (exp2, masks, variant select), hands the bf16-packed block to its partner
+// through LDS (2 KiB, a sequence word; only the two waves of the pair synchronise - their control flow is identical - the
+// workgroup barrier at the loop top covers slot reuse) and the dK wave computes dP = dO V^T meanwhile: 16 MFMAs per wave and
+// iteration on both sides.  dS = bf16(P) (dP - D): P enters in bf16, as it does in the reference (softmax(..).to(q.dtype)).
+template <bool SHARE>
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* res = smem;                                            // Ks, Kc, Vs, Vc
@@ -329,12 +342,10 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     int key = kbase_w + l31;
     const bool kin = key < S;
     key = kin ? key : S - 1;
+    // One memory round trip for the whole prologue (it was three in series, with one workgroup per CU and nothing to cover them):
+    // this lane's key modality byte, the four resident operand tiles and the first Q / dO tile (LDS-DMA) are requested first, the
+    // mask pass's own flag loads last - its wait then covers everything.
     int k_vis_i = p.flag[tok0 + key] != 0;
-    pin(k_vis_i);
-    const bool k_vis = k_vis_i != 0;
-    const bool wkV = __ballot(k_vis && kin) != 0, wkL = __ballot(!k_vis && kin) != 0;
-
-    modality_masks(p.flag + tok0, S, qmask, tid, 512);
     stage_res64(p.k_same + tok0 * p.ldk + h * D128, (unsigned)p.ldk * 2u, key0, S, res, wave, lane);
     stage_res64(p.k_cross + tok0 * p.ldkc + h * D128, (unsigned)p.ldkc * 2u, key0, S, res + 16384, wave, lane);
     stage_res64(p.v_same + tok0 * p.ldv + h * D128, (unsigned)p.ldv * 2u, key0, S, res + 32768, wave, lane);
@@ -355,12 +366,21 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     };
     const int it0 = key0 / 64;                                   // first query tile that can see this key block
     const int nqt = (S + 63) / 64;
+    // SHARE: this pair's two P slots and its sequence word (the number of P blocks published so far)
+    char* xp = smem + DKV_XP + (qh * 2 + kw) * 4096;
+    volatile int* xseq = (volatile int*)(smem + DKV_XP + 4 * 4096) + (qh * 2 + kw);
+    int npass = 0;
+    if (SHARE && tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;
     f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_s[i][r] = 0.f; acc_c[i][r] = 0.f; }
     if (it0 < nqt) stage_q(0, it0);
+    modality_masks(p.flag + tok0, S, qmask, tid, 512);
+    pin(k_vis_i);
+    const bool k_vis = k_vis_i != 0;
+    const bool wkV = __ballot(k_vis && kin) != 0, wkL = __ballot(!k_vis && kin) != 0;
 
     const char* rK = res + kw * 32 * 128;                         // this wave's 32 key rows inside each 64-row sub-tile
     // lane constants: row image (xr), resident image (xv), transposed reads (xt0 / xt1) - each read is then
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                     s[r] = (qa >= kabs && qa < S && kok) ? s[r] : 0.f;
                 }
             }
-            if (role_dk) {
+            if (!SHARE && role_dk) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 Dv = *(const f32x4*)(sD + 8 * g + 4 * fk);
@@ -455,24 +475,68 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         // one pass per variant present (a tile pair with both modalities on either side - rare - pays S twice): every
         // accumulator set is touched from exactly one place, which keeps all 128 of them in registers
         auto pass = [&](const char* rk, bool cross, f32x16* acc) {
-            f32x16 s, dp;
-            score_s(rk, s);
-            score_dp(rk, dp);
-            finish(s, dp);
-            if (mixed) {
+            union { bf16x8 v; unsigned u[4]; } pk[2];
+            if constexpr (!SHARE) {
+                f32x16 s, dp;
+                score_s(rk, s);
+                score_dp(rk, dp);
+                finish(s, dp);
+                if (mixed) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    s[r] = ((((qm >> ql) & 1u) != 0) != k_vis) == cross ? s[r] : 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                        s[r] = ((((qm >> ql) & 1u) != 0) != k_vis) == cross ? s[r] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[sx].u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
+            } else {
+                ++npass;
+                char* slot = xp + (npass & 1) * 2048 + lane * 16;
+                if (!role_dk) {                                   // producer: P (masked, variant-selected), bf16
+                    f32x16 s, none;
+                    score_s(rk, s);
+                    finish(s, none);                              // (the dP - D factor is role_dk's)
+                    if (mixed) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
+                            s[r] = ((((qm >> ql) & 1u) != 0) != k_vis) == cross ? s[r] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[sx].u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
+                    *(bf16x8*)slot = pk[0].v;
+                    *(bf16x8*)(slot + 1024) = pk[1].v;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) *xseq = npass;                 // (LDS serves one wave's operations in order: data, then the word)
+                } else {                                          // consumer: dP while P is being formed, then dS = P (dP - D)
+                    f32x16 dp;
+                    score_dp(rk, dp);
+                    int spins = 0;
+                    while (*xseq < npass && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);   // (bounded: a lost partner must not hang the GPU)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    pk[0].v = *(const bf16x8*)slot;
+                    pk[1].v = *(const bf16x8*)(slot + 1024);
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r0 = 8 * sx + 2 * j;         // accumulator rows r0, r0 + 1 <-> queries 8 (r0 >> 2) + 4 fk + (r0 & 3), + 1
+                            const float d0 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3)], d1 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3) + 1];
+                            const float p0 = __uint_as_float(pk[sx].u[j] << 16), p1 = __uint_as_float(pk[sx].u[j] & 0xffff0000u);
+                            pk[sx].u[j] = pack2bf(p0 * (dp[r0] - d0), p1 * (dp[r0 + 1] - d1));
+                        }
                 }
             }
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
-                union { bf16x8 v; unsigned u[4]; } pk;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pk.u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(st, dt, sx), pk.v, acc[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(st, dt, sx), pk[sx].v, acc[dt], 0, 0, 0);
             }
         };
         if (wsame) pass(rK, false, acc_s);
@@ -612,7 +676,8 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_SHARE);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
@@ -624,6 +689,8 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    static const int share = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 2; }();   // 2 (default) = P shared by the wave pair; 1 = both waves compute S (round 2, kept for A/B)
+    if (share == 2) hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<true>, dim3((unsigned)nblk), dim3(512), DKV_LDS_SHARE, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<false>, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
