@@ -542,37 +542,37 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         if (wsame) pass(rK, false, acc_s);
         if (wcross) pass(rK + 16384, true, acc_c);
     }
-    // ---- combine the two query halves' partial sums: waves with qh = 1 hand theirs over through LDS ----
+    // ---- combine the two query halves' partial sums through LDS: the qh = 0 wave finishes (and stores) the "same" variant, the
+    // qh = 1 wave the "cross" variant - each hands the other half of its sums over (a + b = b + a: the same bits as a one-sided sum)
     __syncthreads();
     {
         float* xch = (float*)smem + ((wave >> 2) * 2 + kw) * 8192;   // 32 KiB per (role, key sub-block) pair: [acc][reg quad][lane] x4
-        if (qh == 1) {
+        float* gdst = xch + (qh == 1 ? 0 : 4096);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 a, c;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[e] = acc_s[i][4 * g + e]; c[e] = acc_c[i][4 * g + e]; }
-                    *(f32x4*)(xch + ((i * 4 + g) * 64 + lane) * 4) = a;
-                    *(f32x4*)(xch + 4096 + ((i * 4 + g) * 64 + lane) * 4) = c;
-                }
-        }
+                for (int e = 0; e < 4; ++e) a[e] = qh == 1 ? acc_s[i][4 * g + e] : acc_c[i][4 * g + e];
+                *(f32x4*)(gdst + ((i * 4 + g) * 64 + lane) * 4) = a;
+            }
         __syncthreads();
-        if (qh == 0) {
+        const float* gsrc = xch + (qh == 0 ? 0 : 4096);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 a = *(const f32x4*)(xch + ((i * 4 + g) * 64 + lane) * 4);
-                    const f32x4 c = *(const f32x4*)(xch + 4096 + ((i * 4 + g) * 64 + lane) * 4);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *(const f32x4*)(gsrc + ((i * 4 + g) * 64 + lane) * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc_s[i][4 * g + e] += a[e]; acc_c[i][4 * g + e] += c[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    if (qh == 0) acc_s[i][4 * g + e] += a[e];
+                    else acc_c[i][4 * g + e] += a[e];
                 }
-        }
+            }
         __syncthreads();
     }
-    if (qh != 0 || kbase_w >= S) return;
+    if (kbase_w >= S) return;
     // ---- store: each wave's two [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
     constexpr int OROW = 264;
     char* so = smem + wave * (32 * OROW);
@@ -602,8 +602,8 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
             }
         }
     };
-    if (role_dk) { store(acc_s, p.scale, p.dk_same); store(acc_c, p.scale, p.dk_cross); }
-    else { store(acc_s, 1.0f, p.dv_same); store(acc_c, 1.0f, p.dv_cross); }
+    if (qh == 0) { if (role_dk) store(acc_s, p.scale, p.dk_same); else store(acc_s, 1.0f, p.dv_same); }
+    else { if (role_dk) store(acc_c, p.scale, p.dk_cross); else store(acc_c, 1.0f, p.dv_cross); }
 }
 
 // delta[b,h,s] = sum_d dO * O   (16 lanes per (token, head), head_dim 128)
