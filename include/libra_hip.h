@@ -229,8 +229,8 @@ int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_
                           int64_t B, int64_t S, int64_t H, float scale, void* stream);
 /* Backward of libra_bridge_attn_fwd (deterministic, two passes): from dO and the forward's operands / lse produce
  * dq [B*S,H*128] (w.r.t. the rotated q) and the four operand gradients dK_same, dK_cross, dV_same, dV_cross
- * ([B*S, H*128], row stride ldg).  `out` (+ optional `out_lo`) is the forward output (for D = rowsum(dO*O)); delta [B,H,S] is
- * scratch.  */
+ * ([B*S, H*128], row stride ldg).  `out` (+ optional `out_lo`) is the forward output (D = rowsum(dO*O) is formed by the dQ pass
+ * from the dO fragments it already holds and handed to the dK / dV pass through `delta` [B,H,S], scratch).  */
 int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                           int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                           const void* out, const void* out_lo, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,

@@ -33,7 +33,8 @@ struct BridgeBwdArgs {
     const bf16_t* v_same; long ldv; const bf16_t* v_cross; long ldvc;
     const bf16_t* dout; long ldo;
     const unsigned char* flag; const int* kv_len;
-    const float* lse; const float* delta;              // [B,H,S]
+    const float* lse; float* delta;                    // [B,H,S]; delta = sum_d dO.O is WRITTEN by the dQ pass and read by the dK/dV pass
+    const bf16_t* out; const bf16_t* out_lo; long ldout;   // attention output (+ its rounding residual, or null): D = dO . (O + O_lo)
     bf16_t* dq; long lddq;
     bf16_t* dk_same; bf16_t* dk_cross; bf16_t* dv_same; bf16_t* dv_cross; long ldg;   // [B*S, H*128] each
     int B, S, H, n_t;
@@ -102,8 +103,32 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
     }
     const long sidx = ((long)b * p.H + h) * S + q;
     float nLq2 = -p.lse[sidx] * LOG2E;
-    float Dq = p.delta[sidx];
+    // D = sum_d dO . O of this lane's query (the softmax-backward row term) from the dO fragments already in flight + the O row:
+    // this lane's 64 channels here, the other half one permlane swap away - the separate delta pass over dO, O and O_lo is gone;
+    // the dK / dV pass reads what the fk = 0 lanes store below
+    bf16x8 of[8], ol[8];
+    {
+        const bf16_t* op = p.out + (tok0 + q) * p.ldout + h * D128 + fk * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) of[ks] = *(const bf16x8*)(op + ks * 16);
+        if (p.out_lo) {
+            const bf16_t* lp = p.out_lo + (tok0 + q) * p.ldout + h * D128 + fk * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) ol[ks] = *(const bf16x8*)(lp + ks * 16);
+        }
+    }
     modality_masks(p.flag + tok0, S, kmask, tid, 512);
+    float Dq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = bf2f((bf16_t)of[ks][e]);
+            if (p.out_lo) o += bf2f((bf16_t)ol[ks][e]);
+            Dq = __builtin_fmaf(o, bf2f((bf16_t)dof[ks][e]), Dq);
+        }
+    Dq = half_swap_sum(Dq);
+    if (fk == 0 && qin) p.delta[sidx] = Dq;
     const bool q_vis = q_vis_raw != 0;
     if (tid < 2) qpres[tid] = 0;
     __syncthreads();
@@ -606,38 +631,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     else { if (role_dk) store(acc_c, p.scale, p.dk_cross); else store(acc_c, 1.0f, p.dv_cross); }
 }
 
-// delta[b,h,s] = sum_d dO * O   (16 lanes per (token, head), head_dim 128)
-__global__ __launch_bounds__(256) void bridge_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ o_lo, long ldo_,
-                                                           const bf16_t* __restrict__ dout, long lddo, float* __restrict__ delta,
-                                                           int S, int H, long total_chunks) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < total_chunks;
-    const int cpr = H * 16;
-    const long row = ok ? i / cpr : 0;
-    const int ch = ok ? (int)(i - row * cpr) : 0;
-    float s = 0.f;
-    if (ok) {
-        float a[8], g[8];
-        unpack8(*(const u32x4*)(o + row * ldo_ + ch * 8), a);
-        unpack8(*(const u32x4*)(dout + row * lddo + ch * 8), g);
-        if (o_lo) {                                           // O to ~16 mantissa bits (see libra_bridge_attn_fwd: out_lo)
-            float l[8];
-            unpack8(*(const u32x4*)(o_lo + row * ldo_ + ch * 8), l);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += l[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += a[e] * g[e];
-    }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-    if (ok && (ch & 15) == 0) {
-        const int hh = ch >> 4;
-        const long bb = row / S;
-        const int t = (int)(row - bb * S);
-        delta[(bb * H + hh) * S + t] = s;
-    }
-}
-
 }  // namespace libra
 
 using namespace libra;
@@ -661,15 +654,11 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
          (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk_same | (uintptr_t)dk_cross | (uintptr_t)dv_same | (uintptr_t)dv_cross) & 15)
         return LIBRA_ERR_ALIGN;
     if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
-    const long rows = B * S;
-    const long total = rows * H * 16;
-    hipLaunchKernelGGL(bridge_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)out, (const bf16_t*)out_lo, (long)ldout, (const bf16_t*)dout, (long)lddo, delta, (int)S, (int)H, total);
-    if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     BridgeBwdArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.ldk = ldk; a.k_cross = (const bf16_t*)k_cross; a.ldkc = ldkc;
     a.v_same = (const bf16_t*)v_same; a.ldv = ldv; a.v_cross = (const bf16_t*)v_cross; a.ldvc = ldvc;
     a.dout = (const bf16_t*)dout; a.ldo = lddo; a.flag = flag; a.kv_len = kv_len; a.lse = lse; a.delta = delta;
+    a.out = (const bf16_t*)out; a.out_lo = (const bf16_t*)out_lo; a.ldout = ldout;
     a.dq = (bf16_t*)dq; a.lddq = lddq; a.dk_same = (bf16_t*)dk_same; a.dk_cross = (bf16_t*)dk_cross;
     a.dv_same = (bf16_t*)dv_same; a.dv_cross = (bf16_t*)dv_cross; a.ldg = ldg;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.scale = scale; a.sl2 = scale * LOG2E;
