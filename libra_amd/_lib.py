@@ -80,7 +80,7 @@ SIGNATURES = {
     "libra_sumsq_bf16": [_P, _I64, _P, _I, _P, C.c_size_t, _P],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class LibraHipError(RuntimeError):
