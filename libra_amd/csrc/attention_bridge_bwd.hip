@@ -39,7 +39,6 @@ struct BridgeBwdArgs {
     bf16_t* dk_same; bf16_t* dk_cross; bf16_t* dv_same; bf16_t* dv_cross; long ldg;   // [B*S, H*128] each
     int B, S, H, n_t;
     float sl2, scale;
-    int dbg;                                          // LIBRA_ATTN_DKV=3: timing-only, the dK/dV pass without its query loop (prologue + epilogue)
 };
 
 // Reduction-major image of a [rows][128 d] tile: 256-byte rows, 16-byte chunk c of row r stored at position
@@ -420,12 +419,11 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
         xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
     }
-    const int nqt_run = p.dbg ? (it0 < nqt ? it0 + 1 : nqt) : nqt;
-    for (int it = it0; it < nqt_run; ++it) {
+    for (int it = it0; it < nqt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = (it - it0) & 1;
-        if (it + 1 < nqt_run) stage_q(cur ^ 1, it + 1);
+        if (it + 1 < nqt) stage_q(cur ^ 1, it + 1);
         const int q0 = it * 64 + qh * 32;
         if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
         asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
@@ -681,8 +679,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     static const int share = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 2; }();   // 2 (default) = P shared by the wave pair; 1 = both waves compute S (round 2, kept for A/B)
-    a.dbg = share == 3;
-    if (share >= 2) hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<true>, dim3((unsigned)nblk), dim3(512), DKV_LDS_SHARE, (hipStream_t)stream, a);
+    if (share == 2) hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<true>, dim3((unsigned)nblk), dim3(512), DKV_LDS_SHARE, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<false>, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
