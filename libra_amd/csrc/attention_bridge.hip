@@ -79,6 +79,16 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     // ---- every per-lane global operand of the prologue is REQUESTED before the first wait: the query's modality byte and its Q
     // fragments (lane (q = l31, half fk) holds Q[q][16*ks + 8*fk .. +8], ks = 0..7) ride the same memory round trip as the flag
     // bytes of the mask pass (one workgroup per CU: nothing else covers a prologue's serial round trips - there were three)
+    // (the first K / V tile goes out first of all, BOTH variants: which of them the tile needs is only known after the mask pass
+    //  and two barriers - one more 32 KiB per workgroup buys the loop's first wait a head start of a full round trip)
+    {
+        const bf16_t* ks0 = p.k_same + tok0 * p.ldk + h * BD;
+        const bf16_t* kc0 = p.k_cross + tok0 * p.ldkc + h * BD;
+        const bf16_t* vs0 = p.v_same + tok0 * p.ldv + h * BD;
+        const bf16_t* vc0 = p.v_cross + tok0 * p.ldvc + h * BD;
+        stage_kv(ks0, (unsigned)p.ldk * 2u, vs0, (unsigned)p.ldv * 2u, 0, S, smem, wave, lane);
+        stage_kv(kc0, (unsigned)p.ldkc * 2u, vc0, (unsigned)p.ldvc * 2u, 0, S, smem + VAR_BYTES, wave, lane);
+    }
     const int q_vis_raw = p.flag[tok0 + q];
     bf16x8 qf[8];
     {
@@ -139,8 +149,7 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
             stage_kv(kc_base, (unsigned)p.ldkc * 2u, vc_base, (unsigned)p.ldvc * 2u, t * BKV, S, dst + VAR_BYTES, wave, lane);
     };
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) pin(qf[ks]);                     // Q has landed before any LDS-DMA is in flight
-    stage(0, 0);
+    for (int ks = 0; ks < 8; ++ks) pin(qf[ks]);                     // Q has landed before the loop's LDS-DMA traffic starts
 
     // fragment addressing.  The lane-derived LDS offsets are recomputed per tile from an opaque copy of the lane id:
     // hoisted to kernel entry they are ten long-lived registers that hipcc spills around the tile loop, and a scratch

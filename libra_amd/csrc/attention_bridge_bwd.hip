@@ -93,6 +93,13 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
 
     // every per-lane global operand of the prologue is requested before the first wait (one round trip instead of three: with one
     // workgroup per CU nothing else covers them): modality byte, Q and dO fragments, L and D of this lane's query
+    // (the first K / V tile goes out first of all, both variants - see bridge_attn_fwd_kernel)
+    {
+        stage_t64(p.k_same + tok0 * p.ldk + h * D128, (unsigned)p.ldk * 2u, 0, S, smem, wave, lane);
+        stage_t64(p.v_same + tok0 * p.ldv + h * D128, (unsigned)p.ldv * 2u, 0, S, smem + 16384, wave, lane);
+        stage_t64(p.k_cross + tok0 * p.ldkc + h * D128, (unsigned)p.ldkc * 2u, 0, S, smem + DQ_VAR, wave, lane);
+        stage_t64(p.v_cross + tok0 * p.ldvc + h * D128, (unsigned)p.ldvc * 2u, 0, S, smem + DQ_VAR + 16384, wave, lane);
+    }
     const int q_vis_raw = p.flag[tok0 + q];
     bf16x8 qf[8], dof[8];
     {
@@ -175,7 +182,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
             stage_t64(vc_base, (unsigned)p.ldvc * 2u, t * 64, S, dst + DQ_VAR + 16384, wave, lane);
         }
     };
-    stage(0, 0);
     int xr = 0, xt0 = 0, xt1 = 0;
     {
         const int pp = lane & 15, g16 = (lane >> 4) & 1;
