@@ -1,5 +1,7 @@
 """The decode step's four weight-streaming GEMMs at M = 8 rows, each over a POOL of distinct weight buffers (2.9 GB per shape at most:
-the Infinity Cache cannot hold them, as in a real step where every layer has its own weights).  Reports us and TB/s of weight bytes."""
+the Infinity Cache cannot hold them, as in a real step where every layer has its own weights).  Reports us and TB/s of weight bytes.
+(profiles/r03_skinny_probe.txt also holds timing-only builds selected by LIBRA_SKINNY_DBG - 1 = no A loads, 2 = no dot products - that
+were not kept in the kernel; with the shipped library every run is the dbg=0 line.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
