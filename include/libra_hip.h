@@ -230,13 +230,16 @@ int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_
 /* Backward of libra_bridge_attn_fwd (deterministic, two passes): from dO and the forward's operands / lse produce
  * dq [B*S,H*128] (w.r.t. the rotated q) and the four operand gradients dK_same, dK_cross, dV_same, dV_cross
  * ([B*S, H*128], row stride ldg).  `out` (+ optional `out_lo`) is the forward output (D = rowsum(dO*O) is formed by the dQ pass
- * from the dO fragments it already holds and handed to the dK / dV pass through `delta` [B,H,S], scratch).  */
+ * from the dO fragments it already holds and handed to the dK / dV pass through `delta` [B,H,S], scratch).
+ * err_word (device int32, 4-byte aligned, or NULL): sticky error bits OR-ed in by the kernels, never cleared by them - bit 0 =
+ * a bounded in-workgroup wait of the dK / dV pass ran out (its results are then undefined).  The launch itself still returns
+ * LIBRA_OK (the library never synchronises); the caller reads the word when it next reads from the device anyway.          */
 int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                           int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                           const void* out, const void* out_lo, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
                           const int32_t* kv_len, const float* lse, float* delta, void* dq, int64_t lddq,
                           void* dk_same, void* dk_cross, void* dv_same, void* dv_cross, int64_t ldg, int64_t B,
-                          int64_t S, int64_t H, float scale, void* stream);
+                          int64_t S, int64_t H, float scale, int32_t* err_word, void* stream);
 /* y = bf16(silu(gate)) * up  (LlamaMLP, models/llama/modeling_llama.py:199-201)                          */
 int libra_swiglu(const void* gate, const void* up, int64_t ldgu, void* y, int64_t ldy, int64_t rows, int64_t I,
                  void* stream);

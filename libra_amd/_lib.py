@@ -52,7 +52,7 @@ SIGNATURES = {
                                  C.c_size_t, _P],
     "libra_bridge_attn_fwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _P],
     "libra_bridge_attn_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64,
-                              _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P],
+                              _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, _P],
     "libra_swiglu": [_P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_gather_rows": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _P],
     "libra_copy_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P],
@@ -80,7 +80,7 @@ SIGNATURES = {
     "libra_sumsq_bf16": [_P, _I64, _P, _I, _P, C.c_size_t, _P],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class LibraHipError(RuntimeError):

@@ -15,7 +15,6 @@
 // transpose load (ds_read_b64_tr_b16) — no V^T copy exists; keys beyond the causal diagonal or the
 // sequence's valid length are masked; work-groups are ordered heaviest-first (causal imbalance).
 #include <atomic>
-#include <cstdlib>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
 #include "attention_bridge_args.hpp"
@@ -372,11 +371,6 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.n_qt = (int)((S + BQ - 1) / BQ);
     a.sl2 = scale * 1.4426950408889634f;
-    // two structures of the same kernel contract: 1 = the 8-wave LDS-DMA structure below (default: equal at S = 2048, 25 % faster at
-    // S = 700, profiles/r03_attn_fwd_anatomy.md); 2 = 4-wave workgroups, two per CU, register-staged single-variant units
-    // (attention_bridge_fwd2.hip).  LIBRA_ATTN_FWD selects (A/B runs, the timing-anatomy builds live in structure 2).
-    static const int structure = [] { const char* e = getenv("LIBRA_ATTN_FWD"); return e && e[0] == '2' ? 2 : 1; }();
-    if (structure == 2) return bridge_attn_fwd2_launch(a, (hipStream_t)stream);
     const long nblk = (long)B * H * a.n_qt;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)

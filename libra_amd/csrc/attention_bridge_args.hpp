@@ -1,4 +1,4 @@
-// Argument block shared by the bridge-attention forward structures (attention_bridge.hip, attention_bridge_fwd2.hip).
+// Argument block of the bridge-attention forward (attention_bridge.hip).
 #pragma once
 #include "hip_common.hpp"
 
@@ -19,7 +19,5 @@ struct BridgeArgs {
     int B, S, H, n_qt;
     float sl2;
 };
-
-int bridge_attn_fwd2_launch(BridgeArgs a, hipStream_t stream);      // attention_bridge_fwd2.hip
 
 }  // namespace libra

@@ -16,7 +16,6 @@
 //              resident in LDS (64 KiB); Q / dO tiles of 32 queries stream through a double buffer in BOTH
 //              images (row image for the first-stage A operand, reduction-major image for the transpose reads).
 #include <atomic>
-#include <cstdlib>
 #include <type_traits>
 #include "hip_common.hpp"
 #include "gemm_tiles.hpp"
@@ -39,6 +38,7 @@ struct BridgeBwdArgs {
     bf16_t* dk_same; bf16_t* dk_cross; bf16_t* dv_same; bf16_t* dv_cross; long ldg;   // [B*S, H*128] each
     int B, S, H, n_t;
     float sl2, scale;
+    int* err;                                          // sticky device-side error word (or null): bit 0 = a dK/dV P hand-over timed out
 };
 
 // Reduction-major image of a [rows][128 d] tile: 256-byte rows, 16-byte chunk c of row r stored at position
@@ -323,10 +323,9 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
 // sub-blocks of 32 x 2 query halves of the streamed tile; the two query halves' partial sums meet in LDS at the end.
 constexpr int KV_RES = 4 * 16384;             // resident K_same, K_cross, V_same, V_cross: [64 keys][128 d] each
 constexpr int QD_STAGE = 2 * 16384 + 512;     // Q image, dO image (64 queries each), L[64], D[64]
-constexpr int DKV_LDS_B = KV_RES + 2 * QD_STAGE + 1024;
-// SHARE build: + the P hand-over slots of the four (dV wave, dK wave) pairs (2 slots x 2 KiB each) and their sequence words
-constexpr int DKV_XP = DKV_LDS_B;
-constexpr int DKV_LDS_SHARE = DKV_LDS_B + 4 * 2 * 2048 + 64;
+// + the P hand-over slots of the four (dV wave, dK wave) pairs (2 slots x 2 KiB each) and their sequence words
+constexpr int DKV_XP = KV_RES + 2 * QD_STAGE + 1024;
+constexpr int DKV_LDS_B = DKV_XP + 4 * 2 * 2048 + 64;
 
 // resident operand tile: two N-type [64 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 16 KiB; 8 waves
 __device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, unsigned ld_b, int key0, int S, char* dst, int wave, int lane) {
@@ -342,13 +341,12 @@ __device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, uns
 
 // Lane-constant LDS addressing: every fragment address is a per-lane constant XOR a compile-time constant (one VALU op per
 // read) instead of the swizzle arithmetic rebuilt per read (the round-1 PMC profile counted 12.4 VALU per MFMA in this kernel).
-// SHARE = true: the dV wave and the dK wave of a (key sub-block, query half) pair sit on the same SIMD and used to compute the SAME
+// The dV wave and the dK wave of a (key sub-block, query half) pair sit on the same SIMD and used to compute the SAME
 // S = Q K^T block each (40 MFMAs per 32 x 32 block pair for 32 of arithmetic, and the dK wave - S, dP, dK - was the long pole of
-// every iteration).  Now the dV wave alone forms P (exp2, masks, variant select), hands the bf16-packed block to its partner
+// every iteration; round 2, A/B in profiles/r03_attn_dkv_shared_p_ab.txt).  Now the dV wave alone forms P (exp2, masks, variant select), hands the bf16-packed block to its partner
 // through LDS (2 KiB, a sequence word; only the two waves of the pair synchronise - their control flow is identical - the
 // workgroup barrier at the loop top covers slot reuse) and the dK wave computes dP = dO V^T meanwhile: 16 MFMAs per wave and
 // iteration on both sides.  dS = bf16(P) (dP - D): P enters in bf16, as it does in the reference (softmax(..).to(q.dtype)).
-template <bool SHARE>
 __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* res = smem;                                            // Ks, Kc, Vs, Vc
@@ -397,11 +395,11 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     };
     const int it0 = key0 / 64;                                   // first query tile that can see this key block
     const int nqt = (S + 63) / 64;
-    // SHARE: this pair's two P slots and its sequence word (the number of P blocks published so far)
+    // this pair's two P slots and its sequence word (the number of P blocks published so far)
     char* xp = smem + DKV_XP + (qh * 2 + kw) * 4096;
     volatile int* xseq = (volatile int*)(smem + DKV_XP + 4 * 4096) + (qh * 2 + kw);
     int npass = 0;
-    if (SHARE && tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;
+    if (tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;
     f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -474,8 +472,8 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq + 16384, ks), rd_res(rk + 32768, ks), dp, 0, 0, 0);
             }
         };
-        // s <- P = exp2(S*sl2 - L) (dV waves) or dS = P (dP - D) (dK waves)
-        auto finish = [&](f32x16& s, const f32x16& dp) {
+        // s <- P = exp2(S*sl2 - L), masked (dV waves; the dK waves apply (dP - D) to the bf16 P they are handed)
+        auto finish = [&](f32x16& s) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = 8 * g + 4 * fk;
@@ -492,14 +490,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                     s[r] = (qa >= kabs && qa < S && kok) ? s[r] : 0.f;
                 }
             }
-            if (!SHARE && role_dk) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 Dv = *(const f32x4*)(sD + 8 * g + 4 * fk);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[4 * g + e] *= dp[4 * g + e] - Dv[e];
-                }
-            }
         };
         const char* st = role_dk ? sq : sq + 16384;               // Q^T fragments (dK) or dO^T fragments (dV)
         const bool mixed = wsame && wcross;
@@ -507,11 +497,12 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
         // accumulator set is touched from exactly one place, which keeps all 128 of them in registers
         auto pass = [&](const char* rk, bool cross, f32x16* acc) {
             union { bf16x8 v; unsigned u[4]; } pk[2];
-            if constexpr (!SHARE) {
-                f32x16 s, dp;
+            ++npass;
+            char* slot = xp + (npass & 1) * 2048 + lane * 16;
+            if (!role_dk) {                                       // producer: P (masked, variant-selected), bf16
+                f32x16 s;
                 score_s(rk, s);
-                score_dp(rk, dp);
-                finish(s, dp);
+                finish(s);
                 if (mixed) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -523,46 +514,36 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
                 for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pk[sx].u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
-            } else {
-                ++npass;
-                char* slot = xp + (npass & 1) * 2048 + lane * 16;
-                if (!role_dk) {                                   // producer: P (masked, variant-selected), bf16
-                    f32x16 s, none;
-                    score_s(rk, s);
-                    finish(s, none);                              // (the dP - D factor is role_dk's)
-                    if (mixed) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                            s[r] = ((((qm >> ql) & 1u) != 0) != k_vis) == cross ? s[r] : 0.f;
-                        }
+                *(bf16x8*)slot = pk[0].v;
+                *(bf16x8*)(slot + 1024) = pk[1].v;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) *xseq = npass;                     // (LDS serves one wave's operations in order: data, then the word)
+            } else {                                              // consumer: dP while P is being formed, then dS = P (dP - D)
+                f32x16 dp;
+                score_dp(rk, dp);
+                // Bounded wait (a lost partner must not hang the GPU).  The two waves of a pair run the same control flow on the
+                // same wave-uniform conditions, so the bound is never reached by design; if it ever is, the cold branch raises the
+                // sticky error word of the launch (the host checks it once per backward) instead of silently using a stale P.
+                int spins = 0;
+                while (*xseq < npass) {
+                    if (++spins >= (1 << 22)) {
+                        if (lane == 0 && p.err) atomicOr(p.err, 1);
+                        break;
                     }
-#pragma unroll
-                    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pk[sx].u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
-                    *(bf16x8*)slot = pk[0].v;
-                    *(bf16x8*)(slot + 1024) = pk[1].v;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) *xseq = npass;                 // (LDS serves one wave's operations in order: data, then the word)
-                } else {                                          // consumer: dP while P is being formed, then dS = P (dP - D)
-                    f32x16 dp;
-                    score_dp(rk, dp);
-                    int spins = 0;
-                    while (*xseq < npass && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);   // (bounded: a lost partner must not hang the GPU)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    pk[0].v = *(const bf16x8*)slot;
-                    pk[1].v = *(const bf16x8*)(slot + 1024);
-#pragma unroll
-                    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int r0 = 8 * sx + 2 * j;         // accumulator rows r0, r0 + 1 <-> queries 8 (r0 >> 2) + 4 fk + (r0 & 3), + 1
-                            const float d0 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3)], d1 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3) + 1];
-                            const float p0 = __uint_as_float(pk[sx].u[j] << 16), p1 = __uint_as_float(pk[sx].u[j] & 0xffff0000u);
-                            pk[sx].u[j] = pack2bf(p0 * (dp[r0] - d0), p1 * (dp[r0 + 1] - d1));
-                        }
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                pk[0].v = *(const bf16x8*)slot;
+                pk[1].v = *(const bf16x8*)(slot + 1024);
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r0 = 8 * sx + 2 * j;             // accumulator rows r0, r0 + 1 <-> queries 8 (r0 >> 2) + 4 fk + (r0 & 3), + 1
+                        const float d0 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3)], d1 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3) + 1];
+                        const float p0 = __uint_as_float(pk[sx].u[j] << 16), p1 = __uint_as_float(pk[sx].u[j] & 0xffff0000u);
+                        pk[sx].u[j] = pack2bf(p0 * (dp[r0] - d0), p1 * (dp[r0 + 1] - d1));
+                    }
             }
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
@@ -646,7 +627,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
                                      const void* out, const void* out_lo, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
                                      const int32_t* kv_len, const float* lse, float* delta, void* dq, int64_t lddq,
                                      void* dk_same, void* dk_cross, void* dv_same, void* dv_cross, int64_t ldg, int64_t B,
-                                     int64_t S, int64_t H, float scale, void* stream) {
+                                     int64_t S, int64_t H, float scale, int32_t* err_word, void* stream) {
     if (B <= 0 || S <= 0) return LIBRA_OK;
     const int64_t HD = H * D128;
     if (ldq >= (1 << 18) || ldk >= (1 << 18) || ldkc >= (1 << 18) || ldv >= (1 << 18) || ldvc >= (1 << 18) || lddo >= (1 << 18))
@@ -660,6 +641,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
          (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk_same | (uintptr_t)dk_cross | (uintptr_t)dv_same | (uintptr_t)dv_cross) & 15)
         return LIBRA_ERR_ALIGN;
     if (out_lo && ((uintptr_t)out_lo & 15)) return LIBRA_ERR_ALIGN;
+    if ((uintptr_t)err_word & 3) return LIBRA_ERR_ALIGN;
     BridgeBwdArgs a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k_same = (const bf16_t*)k_same; a.ldk = ldk; a.k_cross = (const bf16_t*)k_cross; a.ldkc = ldkc;
     a.v_same = (const bf16_t*)v_same; a.ldv = ldv; a.v_cross = (const bf16_t*)v_cross; a.ldvc = ldvc;
@@ -668,11 +650,11 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.dq = (bf16_t*)dq; a.lddq = lddq; a.dk_same = (bf16_t*)dk_same; a.dk_cross = (bf16_t*)dk_cross;
     a.dv_same = (bf16_t*)dv_same; a.dv_cross = (bf16_t*)dv_cross; a.ldg = ldg;
     a.B = (int)B; a.S = (int)S; a.H = (int)H; a.scale = scale; a.sl2 = scale * LOG2E;
+    a.err = err_word;
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_SHARE);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
@@ -684,8 +666,6 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    static const int share = [] { const char* e = getenv("LIBRA_ATTN_DKV"); return e ? atoi(e) : 2; }();   // 2 (default) = P shared by the wave pair; 1 = both waves compute S (round 2, kept for A/B)
-    if (share == 2) hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<true>, dim3((unsigned)nblk), dim3(512), DKV_LDS_SHARE, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel<false>, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

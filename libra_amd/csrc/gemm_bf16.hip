@@ -268,10 +268,12 @@ static double cost128(double tiles, double kt) {
                                                                           : 5.8 + 1.245 * kt);
 }
 static int64_t plan_rows256(int64_t M, int64_t N, int64_t K, int64_t groups = 1) {
-    static int mode = -1;                          // LIBRA_GEMM_KERNEL = 128 | 256 forces a structure (benchmarks)
+#ifdef LIBRA_BENCH_HOOKS        // tools-only build (make bench-hooks): LIBRA_GEMM_KERNEL = 128 | 256 forces a tile structure; the product
+    static int mode = -1;      // library is built without it and reads no environment variable
     if (mode < 0) { const char* e = getenv("LIBRA_GEMM_KERNEL"); mode = e ? atoi(e) : 0; }
     if (mode == 128) return 0;
     if (mode == 256) return M;
+#endif
     if (M < 256 || N < 256 || K < 256) return 0;
     const double kt = (double)K / 64.0;
     const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256 * groups, tn128 = (N + 127) / 128 * groups;   // per tile row, all groups

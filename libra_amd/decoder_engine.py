@@ -497,6 +497,8 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     dev = input_ids.device
     if labels is not None and labels.dtype != torch.int64:
         raise TypeError(f"labels must be int64 (torch.long), got {labels.dtype}")
+    if save:
+        K.errors.check(dev)                     # the previous backward's device error word (copied back asynchronously): raises if set
     flag, lang_idx, vis_idx, lens, starts = route(vision_indices, attention_mask, d, allow_left=not save)
     positions = None
     if d.rope_2d:                               # (row, column) positions; the mask only matters for left-padded generation prompts
@@ -525,7 +527,8 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
     # per-layer saved row buffers come from the model's arena unless an earlier saved forward still waits for its backward
     global _ARENA, _ARENA_PREFIX
     arena = getattr(packed, "arena", None) if save and not recompute else None
-    if arena is not None and arena.busy:
+    if arena is not None and arena.busy:            # an earlier saved forward is still alive: fresh buffers for this one
+        arena.warn_busy()
         arena = None
     try:
         _ARENA = arena
@@ -541,9 +544,8 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
                 hs.append(x)
     finally:
         _ARENA, _ARENA_PREFIX = None, ""
-    if arena is not None:
-        arena.busy = True
-        saved["arena_owner"] = True
+    if arena is not None:                           # the lease lives (and dies) with this forward's saved state
+        saved["arena_lease"] = arena.lease()
     if cache is not None:
         cache.flag[:, :S] = flag.view(B, S)
         cache.length = S
@@ -911,8 +913,9 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
             dp.emit_new(g, emitted)            # data parallel: this layer's gradients start their all-reduce now
     finally:
         _ARENA, _ARENA_PREFIX = None, ""
-        if arena is not None and sv.get("arena_owner"):
-            arena.busy = False
+        if arena is not None:
+            arena.release(sv.pop("arena_lease", None))
+        K.errors.poll_async(dev)               # sticky device error word of the bounded in-kernel waits: read back without a stall
 
     # ---- embeddings (modeling_libra.py:625-661)
     e = sv["emb"]

@@ -9,6 +9,9 @@ from __future__ import annotations
 from typing import Optional, Sequence
 
 import ctypes as C
+import warnings
+import weakref
+
 import torch
 
 from . import _lib
@@ -46,16 +49,49 @@ def alloc_rows(rows: int, cols: int, device) -> torch.Tensor:
     return buf
 
 
+class _ArenaLease:
+    """Ownership token of a RowArena's per-layer tags: it lives in the `saved` state of ONE forward."""
+    __slots__ = ("__weakref__",)
+
+
 class RowArena:
     """Reusable zero-padded row buffers for one model: `rows(tag, n, c)` behaves like `alloc_rows(n, c)[:n]` but hands out the
     SAME storage for the same tag every time, so the pad rows are zeroed once instead of once per call (the decoder step made
     ~800 five-microsecond fill launches for them, and the caching allocator round trips on top).  Only for buffers whose lifetime
     is bounded by the caller's own schedule: per-layer temporaries of a backward (one tag serves all layers, the stream orders
-    the reuse) and per-layer saved activations (one tag per layer, reused by the next step)."""
+    the reuse) and per-layer saved activations (one tag per layer, reused by the next step).
+
+    The per-layer tags belong to at most one saved forward at a time.  Ownership is a LEASE held by that forward's saved state and
+    tracked through a weak reference: it ends when the backward releases it OR when the saved state is dropped without a backward
+    (an evaluation forward outside `no_grad`, `float(model(**kw).loss)`, an exception between forward and backward) - a bool
+    flag cleared only by backward() stayed set for good in those cases and silently sent every later step to fresh allocations."""
 
     def __init__(self):
         self.bufs = {}
-        self.busy = False          # a saved forward that has not met its backward yet owns the per-layer tags
+        self._lease = None         # weakref to the _ArenaLease of the saved forward that owns the per-layer tags, or None
+        self._warned = False
+
+    @property
+    def busy(self) -> bool:
+        return self._lease is not None and self._lease() is not None
+
+    def lease(self) -> "_ArenaLease":
+        tok = _ArenaLease()
+        self._lease = weakref.ref(tok)
+        return tok
+
+    def release(self, tok) -> None:
+        if tok is not None and self._lease is not None and self._lease() is tok:
+            self._lease = None
+
+    def warn_busy(self) -> None:
+        """A training forward found the arena leased to an earlier forward that is still alive (two graphs in flight): it falls
+        back to fresh buffers - correct, but the step then holds a second set of saved activations."""
+        if not self._warned:
+            self._warned = True
+            warnings.warn("libra_amd: a second grad-enabled forward started while the previous one still holds its saved "
+                          "activations; it uses freshly allocated buffers (activation memory roughly doubles). Run evaluation "
+                          "forwards under torch.no_grad() or drop the earlier output first.", RuntimeWarning, stacklevel=3)
 
     def rows(self, tag: str, rows: int, cols: int, device) -> torch.Tensor:
         rp = round_up(rows, 64)
@@ -73,6 +109,54 @@ class RowArena:
 
     def nbytes(self) -> int:
         return sum(b.numel() * b.element_size() for b, _ in self.bufs.values())
+
+
+class DeviceErrors:
+    """Sticky device-side error word of kernels with bounded in-kernel waits (`err_word` of libra_bridge_attn_bwd).  The library
+    never synchronises, so the word is polled WITHOUT a stall: `poll_async` queues a 4-byte copy into pinned memory behind the
+    work just launched, `check` (called at the start of the next forward, or with wait=True where the caller synchronises anyway)
+    raises LibraHipError once the copy has completed and shows a non-zero word."""
+
+    def __init__(self):
+        self._st = {}
+
+    def _state(self, device):
+        dev = torch.device(device)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        st = self._st.get(key)
+        if st is None:
+            d = torch.device("cuda", key)
+            st = dict(word=torch.zeros(1, dtype=torch.int32, device=d), host=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                      event=torch.cuda.Event(), pending=False)
+            self._st[key] = st
+        return st
+
+    def word(self, device) -> torch.Tensor:
+        return self._state(device)["word"]
+
+    def poll_async(self, device) -> None:
+        st = self._state(device)
+        st["host"].copy_(st["word"], non_blocking=True)
+        st["event"].record()
+        st["pending"] = True
+
+    def check(self, device, wait: bool = False) -> None:
+        st = self._state(device)
+        if wait:
+            self.poll_async(device)
+            st["event"].synchronize()
+        elif not st["pending"] or not st["event"].query():
+            return
+        st["pending"] = False
+        bits = int(st["host"][0])
+        if bits:
+            st["word"].zero_()
+            st["host"].zero_()
+            raise _lib.LibraHipError(f"device-side error word = {bits:#x}: a bounded in-kernel wait of the bridge-attention backward "
+                                     "(dK/dV P hand-over) ran out; the gradients of that step are invalid")
+
+
+errors = DeviceErrors()
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None,
@@ -731,7 +815,7 @@ def bridge_attn_bwd(q, k_same, k_cross, v_same, v_cross, out, dout, flag, kv_len
                                           v_cross.stride(0), out.data_ptr(), _ptr(out_lo), out.stride(0), dout.data_ptr(), dout.stride(0),
                                           flag.data_ptr(), _ptr(kv_len), lse.data_ptr(), delta.data_ptr(), g[0].data_ptr(),
                                           g[0].stride(0), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(),
-                                          HD, B, S, H, float(scale), _stream())
+                                          HD, B, S, H, float(scale), errors.word(dev).data_ptr(), _stream())
     _lib.check(rc, "bridge_attn_bwd")
     return tuple(g)
 

@@ -66,6 +66,26 @@ def test_host_prototypes_match_header(lib_path):
     _lib.load()
 
 
+def test_shipped_library_reads_no_environment_variable(lib_path):
+    """Round-3 review: experiment switches (`LIBRA_ATTN_FWD`, `LIBRA_ATTN_DBG`, `LIBRA_ATTN_DKV`, `LIBRA_GEMM_KERNEL`) selected
+    structures - some with deliberately wrong results - inside the product library.  The shipped .so must not import getenv at
+    all and must carry no LIBRA_* variable name; the tools-only hooks need `make bench-hooks` (a different file)."""
+    allow = set()                                                     # environment variables the product library may read: none
+    nm = subprocess.run(["nm", "-D", "--undefined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    env_syms = [l.split()[-1] for l in nm.splitlines() if re.search(r"\b(secure_)?getenv\b", l)]
+    assert not env_syms, f"liblibra_hip.so imports {env_syms}"
+    blob = open(lib_path, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"LIBRA_[A-Z][A-Z0-9_]{2,}(?=\x00)", blob))
+    # (error-code / flag macros are compile-time integers and leave no strings; anything that remains would be a getenv key)
+    assert names <= allow, f"environment-variable-like names in the shipped library: {sorted(names - allow)}"
+    srcs = os.path.join(ROOT, "libra_amd", "csrc")
+    for f in sorted(os.listdir(srcs)):
+        if f.endswith((".hip", ".hpp")):
+            txt = open(os.path.join(srcs, f)).read()
+            body = re.sub(r"#ifdef LIBRA_BENCH_HOOKS.*?#endif", "", txt, flags=re.S)
+            assert "getenv" not in body, f"{f}: getenv outside a LIBRA_BENCH_HOOKS block"
+
+
 def test_product_path_has_no_oracle_or_cpu_fallback():
     """The shipped package must never import the oracle or fall back to torch math."""
     for dp, _, files in os.walk(os.path.join(ROOT, "libra_amd")):

@@ -288,6 +288,41 @@ def test_packed_operands_refresh_policy():
     assert po.refresh(sd, force=True) == n_slices
 
 
+def test_row_arena_lease_follows_the_lifetime_of_the_saved_forward():
+    """the arena's ownership flag was cleared only by backward(); a grad-enabled forward whose graph was
+    dropped (an evaluation without no_grad, `float(model(**kw).loss)`, an exception before backward) left it set for good and
+    every later step fell back to fresh allocations.  Ownership is now a lease that dies with the saved state."""
+    import gc
+    import warnings
+    from libra_amd import kernels as K
+
+    arena = K.RowArena()
+    assert not arena.busy
+    saved = {"arena_lease": arena.lease()}                 # what decoder_engine.forward puts into `saved`
+    assert arena.busy
+    other = arena.lease.__self__                           # (same object; a second forward meanwhile must see it busy)
+    assert other.busy
+    arena.release(saved.pop("arena_lease"))                # backward() ran
+    assert not arena.busy
+    saved = {"arena_lease": arena.lease()}                 # a forward whose graph is dropped without backward
+    assert arena.busy
+    del saved
+    gc.collect()
+    assert not arena.busy, "a dropped saved state must free the arena"
+    stale = {"arena_lease": arena.lease()}
+    newer = {"arena_lease": arena.lease()}                 # (not reachable through forward(): it refuses a busy arena - but a stale
+    arena.release(stale.pop("arena_lease"))                #  token must never release a newer owner's lease)
+    assert arena.busy
+    arena.release(newer.pop("arena_lease"))
+    assert not arena.busy
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        arena.warn_busy(); arena.warn_busy()
+    assert len(w) == 1 and "no_grad" in str(w[0].message)  # said once
+    buf = arena.rows("L0.t", 70, 8, "cpu")                 # the buffers themselves: 64-row padded, zero pads, same storage per tag
+    assert buf.shape == (70, 8) and arena.rows("L0.t", 70, 8, "cpu").data_ptr() == buf.data_ptr()
+
+
 def test_gradient_emission_groups_are_rank_independent_and_cover_the_2d_placeholder():
     """decoder_engine.emit_group / want_groups: the backward-order groups the data-parallel buckets are laid out by - heads and final
     norms first, decoder layers last-to-first, the embedding stage last; `vision_hidden_placeholder` gets a gradient (group 0) only

@@ -29,7 +29,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
-res = {"fwd_structure": os.environ.get("LIBRA_ATTN_FWD", "default"), "bwd_structure": os.environ.get("LIBRA_ATTN_BWD", "default")}
+res = {}
 o_lo = torch.empty_like(q) if os.environ.get("ATTN_LO", "1") == "1" else None      # the training step asks for the residual too
 o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, sc, need_lse=True, out_lo=o_lo)
 if which in ("all", "fwd"):

@@ -1,5 +1,8 @@
-"""Time one bf16 GEMM shape: python tools/gemm_one.py M N K [a_t b_t] [iters]"""
+"""Time one bf16 GEMM shape: python tools/gemm_one.py M N K [a_t b_t] [iters]
+(LIBRA_GEMM_KERNEL=128|256|... forces a tile structure through the bench-hooks build, tools/_hooks.py)"""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _hooks  # noqa: F401
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from libra_amd import kernels as K
