@@ -61,14 +61,29 @@ int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void* B, int64_t
                               int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
                               const int32_t* c_rows, void* stream);
 
+/* The same with the tile structure chosen by the caller instead of the library's cost model (speed only - every structure
+ * computes the same contract, bit for bit per output element up to the fp32 summation order inside a K tile, which is equal too):
+ * AUTO = as libra_gemm_bf16_nt_routed; 128 = 128x128 tiles, two workgroups per CU; 256 = 256x256 tiles, one workgroup per CU
+ * (falls back to 128 when M or N < 256); W = 256x128 tiles, 4 waves, two workgroups per CU (gemm_bf16_w.hip).  For tests (every
+ * structure against the oracle on every shape) and for tools/gemm_sweep.py, which fits the cost model.                          */
+#define LIBRA_GEMM_TILE_AUTO 0
+#define LIBRA_GEMM_TILE_128 1
+#define LIBRA_GEMM_TILE_256 2
+#define LIBRA_GEMM_TILE_W 3
+int libra_gemm_bf16_nt_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                            int64_t M, int64_t N, int64_t K, const void* bias, const void* resid, int64_t ldr,
+                            const void* aux, int64_t ldaux, void* preact, int64_t ldpre, float alpha,
+                            int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
+                            const int32_t* c_rows, int tile, void* stream);
+
 /* Grouped launch: `groups` (<= 4) GEMMs of identical shape, strides, flags (A_T / B_T only) and row maps but different
  * operand pointers run as ONE launch (blockIdx.z = group), so that several mid-sized problems fill whole waves of
  * workgroups together - e.g. the three low-rank vision projections LibraLinear.weight_B of q, k, v (modeling_libra.py:64-90),
- * each 1.19 waves of 256^2 tiles on their own.  No fused epilogue operands.                                          */
+ * each 1.19 waves of 256^2 tiles on their own.  No fused epilogue operands.  tile: LIBRA_GEMM_TILE_* as above (0 = cost model).                                          */
 int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* const* B, int64_t ldb, void* const* C,
                                int64_t ldc, int64_t groups, int64_t M, int64_t N, int64_t K, float alpha,
                                int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
-                               const int32_t* c_rows, void* stream);
+                               const int32_t* c_rows, int tile, void* stream);
 
 /* The first half of LlamaMLP for a generation step (M <= 16 rows) in one launch: Y[M, I] = silu(A W_gate^T) * (A W_up^T),
  * modeling_llama.py:199-201 (act_fn(gate_proj(x)) * up_proj(x)), W_gate_up = [2I, K] = gate rows then up rows (the packed operand

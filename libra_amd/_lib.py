@@ -22,7 +22,9 @@ SIGNATURES = {
                            _F, _I64, _I, _P],
     "libra_gemm_bf16_nt_routed": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
                                   _F, _I64, _I, _P, _I64, _P, _P],
-    "libra_gemm_bf16_nt_grouped": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _F, _I64, _I, _P, _I64, _P, _P],
+    "libra_gemm_bf16_nt_tile": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
+                                _F, _I64, _I, _P, _I64, _P, _I, _P],
+    "libra_gemm_bf16_nt_grouped": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _F, _I64, _I, _P, _I64, _P, _I, _P],
     "libra_gemm_swiglu_skinny": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "libra_gemm_splitk_plan": [_I64, _I64, _I64],
     "libra_gemm_splitk_workspace_bytes": [_I64, _I64, _I64],

@@ -255,42 +255,67 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
                                          float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
                                          int64_t a_phys_rows, const int32_t* c_rows, void* stream);
 
-// Tile-structure choice (speed only).  The 256^2 8-phase kernel is ~1.5x faster per FLOP on full waves of workgroups but
-// runs 1 workgroup / CU (256 slots, a partly filled last wave costs a whole one) against 2 / CU (512 slots) for the 128^2
-// kernel.  The plan gives the leading `rows256` output rows (whole waves of 256^2 tiles) to the big kernel and the
-// remaining rows - the would-be partial wave - to the small one as a second launch: e.g. M=18464, N=1024 (ViT-L proj / fc2
-// at bs 32) = 73 x 4 tiles = 1.14 waves becomes one full wave + 136 small tiles instead of two waves.
-// Costs are microseconds fitted on MI355X (tools/prim.sh + tools/gemm_bench.py); kt = K / 64.
+extern "C" int libra_gemmw_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                   int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                   int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                   float alpha, int64_t alpha_cols, int flags, float* slab, int splitk,
+                                   const int* a_rows, const int* c_rows, void* stream, int groups,
+                                   const void* const* Ag, const void* const* Bg, void* const* Cg);
+
+// Tile-structure choice (speed only).  Three structures share one contract:
+//   256  gemm_bf16_256.hip  256 x 256 tiles, 8 waves, ONE workgroup / CU (256 slots): ~1.5x faster per FLOP than 128 on full waves of
+//        workgroups, but a partly filled last wave costs a whole one and nothing overlaps a tile's ~9 us epilogue;
+//   W    gemm_bf16_w.hip    256 x 128 tiles, 4 waves, TWO workgroups / CU (512 slots): the same per-wave block as 256, half the
+//        quantisation step, one workgroup's epilogue / barrier waits under the other's MFMAs;
+//   128  this file          128 x 128 tiles, 4 waves, two workgroups / CU: small problems.
+// The plan gives the leading `rows_big` output rows (whole waves of 256^2 tiles) to the 256 kernel and the remaining rows - the
+// would-be partial wave - to `rest` as a second launch: e.g. M=18464, N=1024 (ViT-L proj / fc2 at bs 32) = 73 x 4 tiles = 1.14
+// waves becomes one full wave + the rest instead of two waves.
+// Costs are microseconds fitted on MI355X (tools/gemm_sweep.py, profiles/r04_gemm_tile_fit.txt); kt = K / 64.
+enum { KIND_128 = 128, KIND_256 = 256, KIND_W = 1 };
+struct TilePlan { int64_t rows_big; int rest; };        // rows [0, rows_big) on the 256 kernel, the others on `rest` (KIND_128 / KIND_W)
+
 static double cost256(double tiles, double kt) { return 8.6 + ceil(tiles / 256.0) * (1.48 * kt + 5.3); }   // (re-fitted round 2: DMA between MFMAs)
 static double cost128(double tiles, double kt) {
     const double full = floor(tiles / 512.0), rest = tiles - full * 512.0;
     return full * (5.8 + 1.245 * kt) + (rest <= 0 ? 0.0 : rest <= 256.0 ? 4.8 + 0.606 * kt      // <= 1 block / CU: it owns the CU
                                                                           : 5.8 + 1.245 * kt);
 }
-static int64_t plan_rows256(int64_t M, int64_t N, int64_t K, int64_t groups = 1) {
-#ifdef LIBRA_BENCH_HOOKS        // tools-only build (make bench-hooks): LIBRA_GEMM_KERNEL = 128 | 256 forces a tile structure; the product
-    static int mode = -1;      // library is built without it and reads no environment variable
-    if (mode < 0) { const char* e = getenv("LIBRA_GEMM_KERNEL"); mode = e ? atoi(e) : 0; }
-    if (mode == 128) return 0;
-    if (mode == 256) return M;
-#endif
-    if (M < 256 || N < 256 || K < 256) return 0;
+// 256 x 128 tiles, two per CU: a round of 512 tiles shares each CU's matrix pipe between two workgroups (CW_PAIR us per K tile for
+// the pair); a last round of <= 256 tiles has the CUs to itself (CW_LONE per K tile)
+constexpr double CW_FIX = 7.0, CW_PAIR = 1.60, CW_LONE = 0.95, CW_EPI = 3.0;
+static double costw(double tiles, double kt) {
+    const double full = floor(tiles / 512.0), rest = tiles - full * 512.0;
+    return CW_FIX + full * (CW_PAIR * kt + CW_EPI) + (rest <= 0 ? 0.0 : rest <= 256.0 ? CW_LONE * kt + CW_EPI : CW_PAIR * kt + CW_EPI);
+}
+static TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int64_t groups, int force) {
+    if (force == LIBRA_GEMM_TILE_128) return {0, KIND_128};        // caller-chosen structure (libra_gemm_bf16_nt_tile: tests, tools)
+    if (force == LIBRA_GEMM_TILE_256) return M >= 256 && N >= 256 ? TilePlan{M, KIND_128} : TilePlan{0, KIND_128};
+    if (force == LIBRA_GEMM_TILE_W) return {0, KIND_W};
+    if (K < 256) return {0, KIND_128};
     const double kt = (double)K / 64.0;
     const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256 * groups, tn128 = (N + 127) / 128 * groups;   // per tile row, all groups
-    double best = cost128((double)((M + 127) / 128) * tn128, kt);            // everything on the small kernel
-    int64_t rows = 0;
-    const double all256 = cost256((double)(tm * tn), kt);
-    if (all256 <= best) { best = all256; rows = M; }
-    // j full waves on the big kernel, then the small one.  Only worth a second launch (~10 us of boundary + cold start)
-    // when the partial wave is a large share of the problem, i.e. for few waves.
-    for (int64_t j = (tm * tn) / 256; j >= 1 && j <= 2; --j) {
-        const int64_t r = (256 * j) / tn;
-        if (r <= 0 || r >= tm) continue;
-        const int64_t rem = M - r * 256;
-        const double c = cost256((double)(r * tn), kt) + cost128((double)((rem + 127) / 128) * tn128, kt) + 10.0;
-        if (c < 0.95 * best) { best = c; rows = r * 256; }
+    auto rest_cost = [&](int64_t rows, int& kind) {           // cheapest two-per-CU structure for `rows` output rows
+        const double c128 = cost128((double)((rows + 127) / 128) * tn128, kt), cw = costw((double)((rows + 255) / 256) * tn128, kt);
+        kind = cw < c128 ? KIND_W : KIND_128;
+        return cw < c128 ? cw : c128;
+    };
+    TilePlan best{0, KIND_128};
+    double bc = rest_cost(M, best.rest);                       // everything on one two-per-CU structure
+    if (M >= 256 && N >= 256) {
+        const double all256 = cost256((double)(tm * tn), kt);
+        if (all256 <= bc) { bc = all256; best = {M, KIND_128}; }
+        // j full waves on the big kernel, then the rest.  Only worth a second launch (~10 us of boundary + cold start)
+        // when the partial wave is a large share of the problem, i.e. for few waves.
+        for (int64_t j = (tm * tn) / 256; j >= 1 && j <= 2; --j) {
+            const int64_t r = (256 * j) / tn;
+            if (r <= 0 || r >= tm) continue;
+            int kind;
+            const double c = cost256((double)(r * tn), kt) + rest_cost(M - r * 256, kind) + 10.0;
+            if (c < 0.95 * bc) { bc = c; best = {r * 256, kind}; }
+        }
     }
-    return rows;
+    return best;
 }
 
 // ---- split-K (wgrad-shaped problems: small M,N, very long K): the 256^2 kernel over K slices + a deterministic
@@ -353,9 +378,9 @@ static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     int64_t K, const void* bias, const void* resid, int64_t ldr, const void* aux, int64_t ldaux, void* preact,
                     int64_t ldpre, float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
                     const int32_t* c_rows, void* stream, int groups, const void* const* Ag_in, const void* const* Bg_in,
-                    void* const* Cg_in) {
+                    void* const* Cg_in, int tile = LIBRA_GEMM_TILE_AUTO) {
     if (M <= 0 || N <= 0) return LIBRA_OK;                       // empty problem: nothing to do
-    if (!A || !B || !C || K <= 0 || (K % BK) != 0) return LIBRA_ERR_SHAPE;
+    if (!A || !B || !C || K <= 0 || (K % BK) != 0 || tile < LIBRA_GEMM_TILE_AUTO || tile > LIBRA_GEMM_TILE_W) return LIBRA_ERR_SHAPE;
     const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
     if ((lda % 8) || (ldb % 8) || ldc < N) return LIBRA_ERR_SHAPE;
     if (a_rows && (at || a_phys_rows <= 0)) return LIBRA_ERR_SHAPE;               // row gather: K-contiguous A only
@@ -382,8 +407,9 @@ static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void
         return libra_gemm_skinny_launch_(A, lda, B, ldb, C, ldc, M, N, K, (flags & LIBRA_GEMM_RESIDUAL) ? resid : nullptr, ldr,
                                          a_rows, c_rows, stream);
 
-    // ---- leading rows on the 256^2 kernel, the rest (if any) on the 128^2 kernel below ----
-    const int64_t rows256 = plan_rows256(M, N, K, groups);
+    // ---- leading rows on the 256^2 kernel, the rest (if any) on a two-per-CU structure: W here, 128^2 below ----
+    const TilePlan plan = plan_tiles(M, N, K, groups, tile);
+    const int64_t rows256 = plan.rows_big;
     if (rows256 > 0) {
         const int rc = libra_gemm256_launch_(A, lda, B, ldb, C, ldc, rows256, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre,
                                              alpha, alpha_cols, flags, nullptr, 1, a_rows, c_rows, stream, groups, Ag, Bg, Cg);
@@ -405,6 +431,9 @@ static int gemm_run(const void* A, int64_t lda, const void* B, int64_t ldb, void
         }
         M -= m0;
     }
+    if (plan.rest == KIND_W)
+        return libra_gemmw_launch_(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha, alpha_cols,
+                                   flags, nullptr, 1, a_rows, c_rows, stream, groups, Ag, Bg, Cg);
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
     p.bias = (const bf16_t*)bias; p.resid = (const bf16_t*)resid; p.aux = (const bf16_t*)aux; p.preact = (bf16_t*)preact;
@@ -437,13 +466,22 @@ extern "C" int libra_gemm_bf16_nt_routed(const void* A, int64_t lda, const void*
                     a_rows, a_phys_rows, c_rows, stream, 1, nullptr, nullptr, nullptr);
 }
 
+extern "C" int libra_gemm_bf16_nt_tile(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                       int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
+                                       int64_t ldr, const void* aux, int64_t ldaux, void* preact, int64_t ldpre,
+                                       float alpha, int64_t alpha_cols, int flags, const int32_t* a_rows,
+                                       int64_t a_phys_rows, const int32_t* c_rows, int tile, void* stream) {
+    return gemm_run(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, aux, ldaux, preact, ldpre, alpha, alpha_cols, flags,
+                    a_rows, a_phys_rows, c_rows, stream, 1, nullptr, nullptr, nullptr, tile);
+}
+
 extern "C" int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* const* B, int64_t ldb, void* const* C,
                                           int64_t ldc, int64_t groups, int64_t M, int64_t N, int64_t K, float alpha,
                                           int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
-                                          const int32_t* c_rows, void* stream) {
+                                          const int32_t* c_rows, int tile, void* stream) {
     if (groups <= 0) return LIBRA_OK;
     if (groups > 4 || !A || !B || !C) return LIBRA_ERR_SHAPE;
     if (flags & ~(LIBRA_GEMM_A_T | LIBRA_GEMM_B_T)) return LIBRA_ERR_SHAPE;          // no fused epilogue operands in a grouped launch
     return gemm_run(A[0], lda, B[0], ldb, C[0], ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, alpha, alpha_cols,
-                    flags, a_rows, a_phys_rows, c_rows, stream, (int)groups, A + 1, B + 1, C + 1);
+                    flags, a_rows, a_phys_rows, c_rows, stream, (int)groups, A + 1, B + 1, C + 1, tile);
 }

@@ -17,6 +17,7 @@ import torch
 from . import _lib
 
 GEMM_BIAS, GEMM_QUICK_GELU, GEMM_RESIDUAL, GEMM_MUL_QGELU_GRAD, GEMM_STORE_PREACT, GEMM_A_T, GEMM_B_T = 1, 2, 4, 8, 16, 32, 64
+GEMM_TILE_AUTO, GEMM_TILE_128, GEMM_TILE_256, GEMM_TILE_W = 0, 1, 2, 3      # include/libra_hip.h LIBRA_GEMM_TILE_*
 BF16 = torch.bfloat16
 
 
@@ -163,10 +164,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, quick_gelu: bool = False,
             qgelu_grad_of: Optional[torch.Tensor] = None, preact_out: Optional[torch.Tensor] = None,
             alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None, a_t: bool = False,
-            b_t: bool = False, a_rows: Optional[torch.Tensor] = None, c_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+            b_t: bool = False, a_rows: Optional[torch.Tensor] = None, c_rows: Optional[torch.Tensor] = None,
+            tile: int = 0) -> torch.Tensor:
     """out[M,N] = epi(A @ B^T) with A = a [M,K] (or a^T when a_t: a is [K,M], reduction-major) and
     B = b [N,K] (or b^T when b_t: b is [K,N]).  `k` limits the contraction to the first k reduction steps.
-    The reduction length must be a multiple of 64 (reduction-major operands: allocate with alloc_rows)."""
+    The reduction length must be a multiple of 64 (reduction-major operands: allocate with alloc_rows).
+    `tile` (GEMM_TILE_128 / _256 / _W; 0 = the library's cost model) pins the tile structure and disables the split-K path:
+    for the parity tests (every structure on every shape) and for tools/gemm_sweep.py."""
     _chk2d(a, "a"); _chk2d(b, "b")
     (Ka, M) = a.shape if a_t else a.shape[::-1]
     a_phys = a.shape[0]
@@ -188,7 +192,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         raise ValueError(f"gemm_nt: out is {tuple(out.shape)}, expected {(M, N)}")
     plain = (bias is None and resid is None and not quick_gelu and qgelu_grad_of is None and preact_out is None
              and alpha_cols == 0 and a_rows is None and c_rows is None)
-    if plain and M > 0 and N > 0:
+    if plain and tile == 0 and M > 0 and N > 0:
         splits = _lib.lib().libra_gemm_splitk_plan(M, N, K)
         if splits > 1:
             nbytes = _lib.lib().libra_gemm_splitk_workspace_bytes(M, N, splits)
@@ -222,10 +226,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         flags |= GEMM_STORE_PREACT; ldpre = preact_out.stride(0)
     if quick_gelu:
         flags |= GEMM_QUICK_GELU
-    rc = _lib.lib().libra_gemm_bf16_nt_routed(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                              out.stride(0), M, N, K, _ptr(bias), _ptr(resid), ldr,
-                                              _ptr(qgelu_grad_of), ldaux, _ptr(preact_out), ldpre, float(alpha),
-                                              int(alpha_cols), flags, _ptr(a_rows), a_phys, _ptr(c_rows), _stream())
+    rc = _lib.lib().libra_gemm_bf16_nt_tile(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                            out.stride(0), M, N, K, _ptr(bias), _ptr(resid), ldr,
+                                            _ptr(qgelu_grad_of), ldaux, _ptr(preact_out), ldpre, float(alpha),
+                                            int(alpha_cols), flags, _ptr(a_rows), a_phys, _ptr(c_rows), int(tile), _stream())
     _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
     return out
 
@@ -254,7 +258,7 @@ def gemm_swiglu_skinny(a: torch.Tensor, w_gate_up: torch.Tensor, *, a_rows: Opti
 
 def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], *,
                     a_t: bool = False, b_t: bool = False, a_rows: Optional[torch.Tensor] = None,
-                    c_rows: Optional[torch.Tensor] = None) -> Sequence[torch.Tensor]:
+                    c_rows: Optional[torch.Tensor] = None, tile: int = 0) -> Sequence[torch.Tensor]:
     """outs[g] = A_g @ B_g^T for up to 4 problems of identical shape / strides / row maps in ONE launch (the groups
     share whole waves of workgroups).  Same operand conventions as gemm_nt; no fused epilogue operands."""
     G = len(a_list)
@@ -288,7 +292,7 @@ def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tenso
                                    f"{G}x[{M}x{N}x{Ka}{' aT' if a_t else ''}{' bT' if b_t else ''}]"))
         ev[0].record()
     rc = _lib.lib().libra_gemm_bf16_nt_grouped(arr(a_list), a0.stride(0), arr(b_list), b0.stride(0), arr(outs), o0.stride(0),
-                                               G, M, N, Ka, 1.0, 0, flags, _ptr(a_rows), a_phys, _ptr(c_rows), _stream())
+                                               G, M, N, Ka, 1.0, 0, flags, _ptr(a_rows), a_phys, _ptr(c_rows), int(tile), _stream())
     if prof is not None:
         ev[1].record()
     _lib.check(rc, f"gemm_nt_grouped G={G} M={M} N={N} K={Ka}")

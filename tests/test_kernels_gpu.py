@@ -125,6 +125,72 @@ def test_gemm_row_split_dispatch(K):
     assert float(cbig[untouched].abs().max()) == 0.0
 
 
+TILES = {"128": 1, "256": 2, "W": 3}      # include/libra_hip.h LIBRA_GEMM_TILE_*
+
+
+@pytest.mark.parametrize("tile", ["128", "256", "W"])
+@pytest.mark.parametrize("M,N,K_,a_t,b_t", [(256, 128, 64, False, False), (300, 264, 192, False, False), (1000, 1024, 1024, False, False),
+                                            (4624, 1024, 1024, False, False), (4624, 4096, 1024, False, True),
+                                            (1024, 1024, 4672, True, True), (2752, 520, 1152, True, False), (130, 136, 192, True, True),
+                                            (976, 4096, 2048, False, True), (577, 200, 128, False, False), (8, 72, 64, False, False)])
+def test_gemm_every_tile_structure(K, M, N, K_, a_t, b_t, tile):
+    """The three tile structures (128^2 x two per CU, 256^2 x one per CU, W = 256x128 x two per CU) share one contract; the
+    caller-pinned entry point runs each of them on ragged, transposed and multi-K-tile problems against fp32 math.  The three
+    also accumulate every output element in the same order (K tiles ascending, 16-deep MFMA steps ascending), so their results
+    are bit-identical - which pins the W kernel's fragment / accumulator mapping to the two older structures'."""
+    a, b = rnd(M, K_, seed=61), rnd(N, K_, seed=62)
+    aa = a.t().contiguous() if a_t else a
+    bb = b.t().contiguous() if b_t else b
+    out = K.gemm_nt(aa, bb, a_t=a_t, b_t=b_t, tile=TILES[tile])
+    close(out, a.float() @ b.float().t(), what=f"gemm[{tile}] {M}x{N}x{K_} a_t={a_t} b_t={b_t}")
+    assert torch.equal(out, K.gemm_nt(aa, bb, a_t=a_t, b_t=b_t, tile=TILES["128"])), f"tile {tile} != tile 128 bitwise"
+
+
+@pytest.mark.parametrize("tile", ["128", "256", "W"])
+def test_gemm_every_tile_structure_fused_operands(K, tile):
+    """Epilogue operands, row maps, strided views and grouped launches through each pinned structure (the W kernel shares the
+    256^2 kernel's per-wave epilogue code: gemm_epilogue.hpp)."""
+    t = TILES[tile]
+    M, N, K_ = 1100, 776, 320                                  # 5 x 7 W tiles with ragged last row / column tiles
+    a, b = rnd(M, K_, seed=3), rnd(N, K_, seed=4, scale=0.2)
+    bias, res, aux = rnd(N, seed=5), rnd(M, N, seed=6), rnd(M, N, seed=7)
+    base = a.float() @ b.float().t()
+    close(K.gemm_nt(a, b, bias=bias, resid=res, tile=t), base + bias.float() + res.float(), what="bias+resid")
+    sc = torch.ones(N); sc[:100] = 0.125
+    close(K.gemm_nt(a, b, bias=bias, alpha=0.125, alpha_cols=100, tile=t), (base + bias.float()) * sc.cuda(), what="alpha")
+    pre = torch.empty(M, N, dtype=BF, device="cuda")
+    out = K.gemm_nt(a, b, bias=bias, quick_gelu=True, preact_out=pre, tile=t)
+    close(pre, base + bias.float(), what="preact")
+    close(out, pre.float() * torch.sigmoid(1.702 * pre.float()), what="quick_gelu(bf16 preact)")
+    x = aux.float(); sg = torch.sigmoid(1.702 * x)
+    close(K.gemm_nt(a, b, qgelu_grad_of=aux, tile=t), base * (sg * (1 + 1.702 * x * (1 - sg))), what="qgelu_grad")
+    wide = torch.zeros(M, N + 64, dtype=BF, device="cuda")
+    K.gemm_nt(a, b, out=wide[:, 64:], tile=t)
+    close(wide[:, 64:], base, what="strided out")
+    assert float(wide[:, :64].abs().max()) == 0.0
+    # routed: gather A rows from a taller buffer, scatter C rows into a taller buffer with a residual read there
+    g = torch.Generator().manual_seed(5)
+    phys = M + 333
+    rows = torch.randperm(phys, generator=g)[:M].to(torch.int32).cuda()
+    abig, rbig = rnd(phys, K_, seed=26, scale=0.5), rnd(phys, N, seed=27)
+    cbig = torch.zeros(phys, N, dtype=BF, device="cuda")
+    K.gemm_nt(abig, b, out=cbig, a_rows=rows, c_rows=rows, resid=rbig, tile=t)
+    close(cbig[rows.long()], abig[rows.long()].float() @ b.float().t() + rbig[rows.long()].float(), what="routed")
+    untouched = torch.ones(phys, dtype=torch.bool, device="cuda"); untouched[rows.long()] = False
+    assert float(cbig[untouched].abs().max()) == 0.0
+    # grouped: three problems in one launch, reduction-major B, scatter map
+    G = 3
+    ag = rnd(M, G * K_, seed=31, scale=0.5)
+    a_list = [ag[:, i * K_:(i + 1) * K_] for i in range(G)]
+    b_list = [rnd(K_, N, seed=40 + i, scale=0.2) for i in range(G)]
+    cg = torch.zeros(phys, G * N, dtype=BF, device="cuda")
+    outs = [cg[:, i * N:(i + 1) * N] for i in range(G)]
+    K.gemm_nt_grouped(a_list, b_list, outs, b_t=True, c_rows=rows, tile=t)
+    for i in range(G):
+        close(outs[i][rows.long()], a_list[i].float() @ b_list[i].float(), what=f"grouped group {i}")
+    assert float(cg[untouched].abs().max()) == 0.0
+
+
 def test_gemm_rejects_bad_shapes(K):
     a, b = rnd(64, 96), rnd(64, 96)
     with pytest.raises(ValueError):
