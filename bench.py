@@ -321,16 +321,37 @@ def cpu_baseline(seq=2048, workload="bridge"):
     return out
 
 
+def gemm_sources_sha():
+    """Fingerprint of the sources that decide the GEMM kernels' memory traffic (tile structures, planner, launch order): written
+    into the traffic file by tools/hbm_traffic.py and compared here, so a traffic number measured on OTHER kernels says so."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libra_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("gemm_") or f == "hip_common.hpp":
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(workload):
-    """Mean HBM bytes per GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/); None if absent."""
-    for rnd in ("r03", "r02", "r01"):
+    """Mean HBM bytes per GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/) -> (bytes, file name,
+    provenance dict); (None, None, None) if absent.  The PMC passes cannot run inside the timed command (they serialise kernels),
+    so the number is read from the newest committed file and marked `stale` when the GEMM sources changed since it was measured."""
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{workload}.json")
         try:
             with open(path) as f:
-                return round(json.load(f)["gemm_bytes_per_launch"]), os.path.basename(path)
+                d = json.load(f)
+            now = gemm_sources_sha()
+            prov = {"file": os.path.basename(path), "measured_at_gemm_sources_sha": d.get("gemm_sources_sha"),
+                    "measured_at_head": d.get("head"), "running_gemm_sources_sha": now,
+                    "stale": d.get("gemm_sources_sha") != now}
+            return round(d["gemm_bytes_per_launch"]), os.path.basename(path), prov
         except (OSError, KeyError, ValueError):
             continue
-    return None, None
+    return None, None, None
 
 
 def self_launch(n: int) -> int:
@@ -418,12 +439,13 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img):
             e[0] += 1; e[1] += t; e[2] += wk[0]
     by_shape = [{"shape": n, "launches": c, "ms": round(ms, 2), "tflops": round(fl / 1e9 / ms, 1) if ms > 0 else 0.0}
                 for n, (c, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:48]]
-    traffic, src = hbm_traffic("libra" if workload == "bridge" else "vit")
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (256x256x64 tiles; + gemm_bf16_nt_kernel 128x128 tail rows, "
-                                       "split-K wgrad slabs): every launch made through libra_gemm_bf16_nt*",
+    traffic, src, prov = hbm_traffic("libra" if workload == "bridge" else "vit")
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (256x256x64 tiles; + gemm_bf16_nt_w_kernel 256x128 two per CU / "
+                                       "gemm_bf16_nt_kernel 128x128 for tail rows and small problems, split-K wgrad slabs): every "
+                                       "launch made through libra_gemm_bf16_nt*",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": f"HBM bytes / launch (PMC, profiles/{src})" if src else None,
+            "traffic_unit": f"HBM bytes / launch (PMC, profiles/{src})" if src else None, "traffic_provenance": prov,
             "algorithmic_bytes_per_launch": round(gbytes),
             "timing": "HIP events on the launch stream around every GEMM launch of one extra step",
             "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1), "gemm_ms_per_step": round(gms, 2),

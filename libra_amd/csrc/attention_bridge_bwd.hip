@@ -397,7 +397,9 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     const int nqt = (S + 63) / 64;
     // this pair's two P slots and its sequence word (the number of P blocks published so far)
     char* xp = smem + DKV_XP + (qh * 2 + kw) * 4096;
-    volatile int* xseq = (volatile int*)(smem + DKV_XP + 4 * 4096) + (qh * 2 + kw);
+    // (an LDS-space pointer: through a generic `volatile int*` the poll compiled to `flat_load_dword .. sc0 sc1` + `s_waitcnt vmcnt(0)`,
+    //  which also drained the next tile's direct-to-LDS queue in every iteration of the dK waves)
+    volatile LIBRA_LDS int* xseq = (volatile LIBRA_LDS int*)(LIBRA_LDS char*)(smem + DKV_XP + 4 * 4096) + (qh * 2 + kw);
     int npass = 0;
     if (tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;
     f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]

@@ -282,8 +282,11 @@ static double cost128(double tiles, double kt) {
                                                                           : 5.8 + 1.245 * kt);
 }
 // 256 x 128 tiles, two per CU: a round of 512 tiles shares each CU's matrix pipe between two workgroups (CW_PAIR us per K tile for
-// the pair); a last round of <= 256 tiles has the CUs to itself (CW_LONE per K tile)
-constexpr double CW_FIX = 7.0, CW_PAIR = 1.60, CW_LONE = 0.95, CW_EPI = 3.0;
+// the pair: 1.17 PFLOP/s in the loop against the 256^2 kernel's 1.45 - two unsynchronised workgroups do not interleave as well as
+// its two staggered wave groups, but one's epilogue does run under the other's MFMAs); a last round of <= 256 tiles has the CUs to
+// itself (CW_LONE per K tile).  Fitted on profiles/r04_gemm_experiments/sweep_w_v2.txt: 11760x4096x{4096,11008}, 4624x1024x{4096,
+// 11008}, 4624x4096x1024; checked on 11760x22016x4096 (1854 predicted / 1870 us) and 18464x1024x4096 (177 / 166).
+constexpr double CW_FIX = 4.7, CW_PAIR = 1.84, CW_LONE = 0.79, CW_EPI = 2.0;
 static double costw(double tiles, double kt) {
     const double full = floor(tiles / 512.0), rest = tiles - full * 512.0;
     return CW_FIX + full * (CW_PAIR * kt + CW_EPI) + (rest <= 0 ? 0.0 : rest <= 256.0 ? CW_LONE * kt + CW_EPI : CW_PAIR * kt + CW_EPI);

@@ -10,16 +10,20 @@
 // while this one reads fragments, waits at its barrier or runs its epilogue.  Half-size tiles also halve the quantisation step
 // of a partly filled last wave (512 slots instead of 256).
 //
-//   * LDS: five 16-KiB units (80 KiB; 2 x 80 = the CU's 160 KiB): A is double buffered (A_lo, A_hi of the even / odd K tile),
-//     B (128 lines) is SINGLE buffered and released in the middle of the K tile: a wave reads ALL its B fragments and its first
-//     A half at the top of the tile, and after barrier #1 (every wave's B reads retired) the unit takes B(t+1).
+//   * LDS: five 16-KiB units (80 KiB; 2 x 80 = the CU's 160 KiB): A is double buffered as A1st / A2nd of the even / odd K tile -
+//     A1st holds the FIRST 64 rows of both 128-row wave blocks (tile rows 0-63, 128-191), A2nd the second 64 (the split is made
+//     by the source addressing, gemm_tiles.hpp stage_src<.., SPLIT>), so that A2nd is first read in the SECOND half of a K tile;
+//     B (128 lines) is SINGLE buffered and released in the middle of the K tile: a wave reads ALL its B fragments and its
+//     A1st fragments at the top of the tile, and after barrier #1 (every wave's B reads retired) the unit takes B(t+1).
 //   * K tile = 4 quadrants of the wave's block, 8 MFMAs each: (A0,B0) (A0,B1) | read A1 | (A1,B1) (A1,B0).  The 12 direct-to-LDS
-//     pieces of K tile t+1 are issued BETWEEN the MFMAs of quadrants 1-3 (A_lo(t+1), then - behind barrier #1 - B(t+1), then
-//     A_hi(t+1)); quadrant 4 carries none, so the youngest piece has >= 8 MFMAs to land before the tile's only drain
-//     (`vmcnt(0)` + barrier #2, which also frees both A units of tile t).
-//   * hazards: RAW - every piece of tile t+1 is waited for by its issuing wave before barrier #2 and read after it; WAR -
-//     A(t+1) goes to the buffer last read in tile t-1 (before barrier #2 of t-1), B(t+1) is issued after barrier #1 of tile t,
-//     which every wave reaches with `lgkmcnt(0)` (its B(t) fragments are in registers).
+//     pieces of K tile t+1 are issued BETWEEN the MFMAs of quadrants 1-3: A1st(t+1), then - behind barrier #1 - B(t+1), then
+//     A2nd(t+1).  The loop never drains: barrier #2 (end of tile t) is preceded by `vmcnt(4)` = everything but the four youngest
+//     pieces (A2nd(t+1)) has landed, barrier #1 of tile t+1 by `vmcnt(4)` again = A2nd(t+1) has landed, A1st(t+2) may fly.
+//   * hazards: RAW - a piece is waited for by its issuing wave before a barrier every reader passes before its read (A1st,
+//     B: barrier #2; A2nd: barrier #1 of the tile that reads it); WAR - A(t+1) goes to the buffers last read in tile t-1 (before
+//     barrier #2 of t-1), B(t+1) is issued after barrier #1 of tile t, which every wave reaches with `lgkmcnt(0)` (its B(t)
+//     fragments are in registers).  (First version, one drain per tile with A split lo / hi: 13-15 % behind the 256^2 kernel on
+//     the text shapes, profiles/r04_gemm_experiments.)
 #include <atomic>
 #include <type_traits>
 #include "hip_common.hpp"
@@ -63,19 +67,19 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
     unsigned srcA[2][4], srcB[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        srcA[0][j] = stage_src<AT>(wave * 4 + j, lane, m0, p.M, p.lda, p.a_rows);
-        srcA[1][j] = stage_src<AT>(wave * 4 + j, lane, m0 + 128, p.M, p.lda, p.a_rows);
+        srcA[0][j] = stage_src<AT, true>(wave * 4 + j, lane, m0, p.M, p.lda, p.a_rows);          // A1st: rows 0-63, 128-191
+        srcA[1][j] = stage_src<AT, true>(wave * 4 + j, lane, m0 + 64, p.M, p.lda, p.a_rows);     // A2nd: rows 64-127, 192-255
         srcB[j] = stage_src<BT>(wave * 4 + j, lane, n0, p.N, p.ldb);
     }
     const long kstepA = ktile_stride<AT>(p.lda), kstepB = ktile_stride<BT>(p.ldb);
     const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;       // (one address-space cast, not one per piece)
     const unsigned ldst = lds0 + (unsigned)(wave * 4096);                        // this wave's 4 pieces inside any unit
-    // unit map: A(kt) half h at ((kt & 1) * 2 + h) * WU, B at 4 * WU
+    // unit map: A1st / A2nd (h = 0 / 1) of K tile kt at ((kt & 1) * 2 + h) * WU, B at 4 * WU
     auto pieceA = [&](int h, int kt, int j) { glds16_at(Ap + kt * kstepA + srcA[h][j], ldst + (unsigned)(((kt & 1) * 2 + h) * WU + j * 1024)); };
     auto pieceB = [&](int kt, int j) { glds16_at(Bp + kt * kstepB + srcB[j], ldst + (unsigned)(4 * WU + j * 1024)); };
 
     const FragAddr fa = make_frag_addr(lane);
-    const int toA[4] = {frag_toff<AT>(lane, 0), frag_toff<AT>(lane, 1), frag_toff<AT>(lane, 2), frag_toff<AT>(lane, 3)};
+    const int toA[2] = {frag_toff<AT>(lane, wr * 2), frag_toff<AT>(lane, wr * 2 + 1)};      // this wave's 64 lines inside either A unit
     const int toB[2] = {frag_toff<BT>(lane, wc * 2), frag_toff<BT>(lane, wc * 2 + 1)};
 
     f32x16 acc[4][2];
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
     // one K tile; STEADY = K tile kt+1 exists (every iteration but the last): no tests between the MFMAs
     auto ktile = [&](const int kt, auto steady) {
         constexpr bool STEADY = decltype(steady)::value;
-        const char* sa = smem + ((kt & 1) * 2 + wr) * WU;
+        const char* sa = smem + (kt & 1) * 2 * WU;                  // A1st; A2nd at + WU
         const char* sb = smem + 4 * WU;
-        // ---- top: all B fragments of this tile + the first A half
+        // ---- top: all B fragments of this tile + the A1st fragments
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) b0[ks] = load_frag<BT>(sb, fa, toB[0], ks);
 #pragma unroll
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) b1[ks] = load_frag<BT>(sb, fa, toB[1], ks);
         __builtin_amdgcn_sched_barrier(0);
-        // ================= quadrant (0,0): A_lo(kt+1) =================
+        // ================= quadrant (0,0): A1st(kt+1) =================
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -126,8 +130,9 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        LIBRA_LGKMCNT0();            // this wave's B fragments of the tile are in registers ...
-        __builtin_amdgcn_s_barrier();   // #1 ... and every other wave's too: the B unit may take B(kt+1)
+        LIBRA_LGKMCNT0();            // this wave's B fragments of the tile are in registers,
+        if (STEADY) { LIBRA_VMCNT(4); } else { LIBRA_VMCNT(0); }     // its A2nd(kt) pieces have landed (A1st(kt+1) may fly) ...
+        __builtin_amdgcn_s_barrier();   // #1 ... and every other wave's too: the B unit may take B(kt+1), A2nd(kt) may be read
         __builtin_amdgcn_sched_barrier(0);
         // ================= quadrant (0,1): B(kt+1) =================
         __builtin_amdgcn_s_setprio(1);
@@ -143,13 +148,13 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- second A half (the registers of the first are free now)
+        // ---- A2nd fragments (the registers of the A1st fragments are free now)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[i][ks] = load_frag<AT>(sa, fa, toA[2 + i], ks);
+            for (int ks = 0; ks < 4; ++ks) a[i][ks] = load_frag<AT>(sa + WU, fa, toA[i], ks);
         __builtin_amdgcn_sched_barrier(0);
-        // ================= quadrant (1,1): A_hi(kt+1) =================
+        // ================= quadrant (1,1): A2nd(kt+1) =================
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
                 }
             }
         }
-        // ================= quadrant (1,0): no pieces - the youngest one lands under these MFMAs =================
+        // ================= quadrant (1,0): no pieces =================
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        LIBRA_VMCNT(0);              // K tile kt+1 has landed (this wave's pieces) ...
+        if (STEADY) { LIBRA_VMCNT(4); }   // A1st(kt+1) and B(kt+1) have landed (this wave's pieces; the four A2nd(kt+1) pieces fly on) ...
         __builtin_amdgcn_s_barrier();   // #2 ... everywhere, and nobody reads the A units of tile kt any more
         __builtin_amdgcn_sched_barrier(0);
     };

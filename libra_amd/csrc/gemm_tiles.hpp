@@ -65,20 +65,22 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, const FragAddr& f,
 // piece index `pc` counts 1-KiB pieces of the 16-KiB tile (0..15).
 //   N-type piece = 8 lines x 128 B: line = 8*pc + lane/8, LDS position lane%8
 //   T-type piece = 4 k-rows x 256 B: row = 4*pc + lane/16, LDS position lane%16
-template <bool T>
+template <bool T, bool SPLIT = false>
 __device__ __forceinline__ unsigned stage_src(int pc, int lane, int line0, int nlines, long ld,
                                               const int* __restrict__ rows = nullptr) {
+    // SPLIT: the tile's 128 lines are two 64-line runs 128 operand lines apart (lines 0-63 <-> line0 + 0..63, lines 64-127 <->
+    // line0 + 128..191): gemm_bf16_w.hip's A units, which hold the FIRST (or second) 64 rows of both 128-row wave blocks
     if constexpr (!T) {
         const int r = pc * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int g = line0 + r;
+        int g = line0 + (SPLIT ? (r & 63) + ((r >> 6) << 7) : r);
         g = g < nlines ? g : nlines - 1;                 // clamp the tail (masked at the store)
         if (rows) g = rows[g];                           // routed gather: logical line -> physical row
         return (unsigned)g * (unsigned)ld + c * 8;
     } else {
         const int r = pc * 4 + (lane >> 4);
         const int c = (lane & 15) ^ ((r & 3) << 2);
-        int col = line0 + c * 8;
+        int col = line0 + (SPLIT ? (c & 7) * 8 + ((c >> 3) << 7) : c * 8);
         col = col + 8 <= nlines ? col : nlines - 8;       // clamp (nlines % 8 == 0, >= 8)
         return (unsigned)r * (unsigned)ld + col;
     }

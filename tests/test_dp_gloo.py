@@ -361,3 +361,94 @@ def test_global_norm_clipping_and_optimizer_state_roundtrip_world2(mode):
     for k in p0:
         assert np.array_equal(p0[k], p1[k]), k
         assert np.allclose(p0[k], r0[k], atol=0, rtol=2 ** -7), k
+
+
+def _worker_world8(rank, world, port, q):
+    """configs[3] / [4] on one node = 8 ranks: ZeRO-1-style sharded AdamW with clipping, 2 accumulation micro-steps per step, one rank
+    whose micro-batches have no vision token (it never emits the 'vision' members), odd-sized members so that every bucket is
+    padded to world * ALIGN, and a checkpoint round trip in the middle."""
+    _init(rank, world, port)
+    from helpers import torch_adamw_update, torch_sumsq
+    from libra_amd import dp
+    torch.manual_seed(3)
+    params = {n: torch.nn.Parameter(torch.randn(p.shape).to(torch.bfloat16)) for n, p in _params().items()}
+    ref = {n: p.detach().float().clone().requires_grad_(True) for n, p in params.items()}
+    nodecay = [n for n, p in params.items() if p.ndim < 2]
+    opt_ref = torch.optim.AdamW([{"params": [ref[n] for n in ref if n not in nodecay], "weight_decay": 0.1},
+                                 {"params": [ref[n] for n in nodecay], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    vision_members = ("layers.1.w", "layers.1.norm")
+    text_only_rank = 5
+    mk = lambda ps: (dp.GradBuckets(ps.items(), bucket_bytes=1024, group_fn=_group, mode="zero1"),)
+    (st,) = mk(params)
+    opt = dp.FlatAdamW(st, params.items(), lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
+                       update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    layout = [(tuple(b.names), b.flat.numel()) for b in st.buckets]
+
+    def micro_grads(step, k):
+        gens = [torch.Generator().manual_seed(10000 * step + 100 * k + r) for r in range(world)]
+        allg = [{n: torch.randn(p.shape, generator=gens[r]).to(torch.bfloat16) for n, p in params.items()} for r in range(world)]
+        for n in vision_members:                            # the text-only rank contributes zeros there (it emits nothing)
+            allg[text_only_rank][n].zero_()
+        return allg
+
+    def run_step(st_, opt_, step):
+        tot = None
+        for k in range(2):                                  # gradient accumulation: only the last micro-step communicates
+            allg = micro_grads(step, k)
+            with st_.capture(sync=(k == 1)):
+                g, seen = {}, set()
+                for n in sorted(params, key=_group):
+                    if rank == text_only_rank and n in vision_members:
+                        continue
+                    out = dp.grad_out(n)
+                    g[n] = allg[rank][n] if out is None else out.copy_(allg[rank][n])
+                    dp.emit_new(g, seen)
+            st_.finish()
+            tot = allg if tot is None else [{n: a[n].float() + b[n].float() for n in a} for a, b in zip(tot, allg)]
+        opt_.step()
+        return tot
+
+    for step in range(2):
+        tot = run_step(st, opt, step)
+        for n in ref:                                       # expectation: mean over ranks of the accumulated gradients, clipped fp32 AdamW
+            ref[n].grad = (sum(t[n].float() for t in tot) / world).to(torch.bfloat16).float()
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        opt_ref.step()
+    snap = _np(params)
+    # checkpoint / resume on 8 ranks: every rank saves and reloads ITS shard; a fresh optimizer continues bit for bit
+    sd = opt.state_dict()
+    params2 = {n: torch.nn.Parameter(torch.zeros_like(p)) for n, p in params.items()}
+    (st2,) = mk(params2)
+    opt2 = dp.FlatAdamW(st2, params2.items(), lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
+                        update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    opt2.load_state_dict(sd)
+    same_after_load = all(torch.equal(params[n], params2[n]) for n in params)
+    run_step(st, opt, 2)
+    # (run_step reads `params` only for shapes / names, so the same closure drives the second optimizer)
+    run_step(st2, opt2, 2)
+    same_after_step = all(torch.equal(params[n], params2[n]) for n in params) and opt.t == opt2.t == 3
+    state_elems = sum(s["master"].numel() for s in opt.state)
+    q.put((rank, snap, _np({n: r.detach().to(torch.bfloat16) for n, r in ref.items()}), layout, state_elems,
+           sum(b.flat.numel() for b in st.buckets), same_after_load, same_after_step))
+    dist.destroy_process_group()
+
+
+def test_world8_zero1_accumulation_text_only_rank_and_checkpoint():
+    """Round-3 review item 7(i): the node-sized world.  Eight gloo ranks, `zero1` + clipping + accumulation, a rank with a text-only
+    batch, uneven shard padding; every rank ends with the same bf16 parameters, they track the unsharded fp32-master AdamW on the
+    mean gradient, each rank holds 1/8 of the optimizer state, and a state_dict round trip resumes bit for bit."""
+    res = _run(_worker_world8, 8)
+    assert len(res) == 8
+    p0, r0, layout0, ne0, tot = res[0][1], res[0][2], res[0][3], res[0][4], res[0][5]
+    assert all(n % (8 * 64) == 0 for _, n in layout0)                          # every bucket padded to world * ALIGN elements
+    assert tot > sum(int(np.prod(v.shape)) for v in p0.values())               # ... i.e. real padding exists with these odd sizes
+    for r in res:
+        assert r[3] == layout0, "rank-dependent bucket layout"
+        assert r[4] == tot // 8, "optimizer state is not 1/8 per rank"
+        assert r[6] and r[7], f"rank {r[0]}: checkpoint round trip"
+        for k in p0:
+            assert np.array_equal(p0[k], r[1][k]), (r[0], k)                    # ranks agree bit for bit
+    for k in p0:
+        # (a bf16 sum over eight ranks and two micro-steps rounds differently from the fp32 mean of the reference: as in the
+        #  world-3 test the parameters agree to a few 1e-3 after the AdamW steps, not to the ulp)
+        assert np.allclose(p0[k], r0[k], atol=6e-3, rtol=2 ** -6), k

@@ -138,6 +138,10 @@ def test_gemm_every_tile_structure(K, M, N, K_, a_t, b_t, tile):
     caller-pinned entry point runs each of them on ragged, transposed and multi-K-tile problems against fp32 math.  The three
     also accumulate every output element in the same order (K tiles ascending, 16-deep MFMA steps ascending), so their results
     are bit-identical - which pins the W kernel's fragment / accumulator mapping to the two older structures'."""
+    if a_t and M % 8:
+        M = M // 8 * 8                                 # a reduction-major A needs a 16-byte aligned row start per k
+    if b_t and N % 8:
+        N = N // 8 * 8
     a, b = rnd(M, K_, seed=61), rnd(N, K_, seed=62)
     aa = a.t().contiguous() if a_t else a
     bb = b.t().contiguous() if b_t else b

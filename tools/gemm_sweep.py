@@ -6,10 +6,13 @@ the planner's cost model in gemm_bf16.hip is fitted on (profiles/r04_gemm_tile_f
 Shapes are the `roofline.by_shape` rows of the bench lines (M x N x K, aT / bT = reduction-major operands, Gx[..] = grouped launch);
 each (shape, structure) is timed in `rounds` interleaved rounds of `iters` back-to-back launches (HIP events), the minimum is kept.
 One JSON line per shape on stdout, a readable table on stderr."""
+import faulthandler
 import json
 import os
 import re
 import sys
+
+faulthandler.enable()
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
@@ -69,7 +72,10 @@ def main():
             us = {}
             for r in range(rounds):
                 for tname, tile in TILES:
+                    if r == 0:
+                        print(f"[run] {spec} tile={tname}", file=sys.stderr, flush=True)
                     run(tile)
+                    torch.cuda.synchronize()
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     torch.cuda.synchronize(); s.record()
                     for _ in range(iters):
