@@ -378,6 +378,85 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def parse_showtopo(text: str):
+    """`rocm-smi --showtopo` -> {"link_type": {(i, j): "XGMI" | "PCIE" | ...}, "hops": {...}, "weight": {...}} (what is present)."""
+    out = {}
+    sec = None
+    cols = []
+    for line in text.splitlines():
+        if line.startswith("="):
+            low = line.lower()
+            sec = ("link_type" if "link type between" in low else "hops" if "hops between" in low
+                   else "weight" if "weight between" in low else None)
+            cols = []
+            continue
+        if sec is None or not line.strip():
+            continue
+        tok = line.split()
+        if not cols:
+            if all(t.startswith("GPU") for t in tok):
+                cols = [int(t[3:]) for t in tok]
+            continue
+        if tok[0].startswith("GPU") and len(tok) == len(cols) + 1:
+            i = int(tok[0][3:])
+            for j, v in zip(cols, tok[1:]):
+                out.setdefault(sec, {})[(i, j)] = v
+    return out
+
+
+def preflight(world: int, backend: str, captured_init_output: str = ""):
+    """What the first real multi-GPU run needs to be diagnosable from its JSON line alone (rank 0): the collective library's
+    version, the version line it prints under NCCL_DEBUG=VERSION, and the node's link topology between the first and the last rank's
+    GPU (xGMI vs PCIe, hops).  Every probe is best effort and bounded in time; failures are recorded, never raised."""
+    import subprocess
+    pf = {"backend": backend, "visible_gpus": torch.cuda.device_count(),
+          "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    try:
+        v = torch.cuda.nccl.version()
+        pf["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:
+        pf["rccl_version"] = f"unavailable: {e!r}"[:120]
+    lines = [l.strip() for l in captured_init_output.splitlines() if "RCCL" in l or "NCCL version" in l or "HIP version" in l]
+    pf["nccl_debug_version_line"] = lines[:3] if lines else None
+    try:
+        r = subprocess.run(["rocm-smi", "--showtopo"], capture_output=True, text=True, timeout=30)
+        topo = parse_showtopo(r.stdout)
+        a, b = 0, max(world - 1, 0)
+        pf["topology"] = {k: topo.get(k, {}).get((a, b)) for k in ("link_type", "hops", "weight")}
+        pf["topology"]["pair"] = [a, b]
+        kinds = sorted(set(v for (i, j), v in topo.get("link_type", {}).items() if i != j and i < world and j < world))
+        pf["topology"]["link_types_among_ranks"] = kinds
+    except Exception as e:
+        pf["topology"] = f"rocm-smi --showtopo failed: {e!r}"[:160]
+    return pf
+
+
+class _CaptureFd1:
+    """Redirect the PROCESS's stdout (fd 1) into a temporary file for the duration of the block: RCCL prints its NCCL_DEBUG=VERSION
+    line with its own stdio, and stdout must stay the JSON line's alone."""
+
+    def __enter__(self):
+        import tempfile
+        sys.stdout.flush()
+        self.tmp = tempfile.TemporaryFile(mode="w+b")
+        self.saved = os.dup(1)
+        os.dup2(self.tmp.fileno(), 1)
+        self.text = ""
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            os.fsync(1)
+        except OSError:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode("utf-8", "replace")
+        self.tmp.close()
+        return False
+
+
 def step_check(w, named_params):
     """Correctness evidence of the step that was timed: its loss, the L2 norm of its gradients (libra_sumsq_bf16 over every
     trainable parameter's gradient: deterministic, so the number doubles as a checksum between runs / builds) and whether both
@@ -518,7 +597,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL over xGMI.  (LIBRA_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box.)
         backend = os.environ.get("LIBRA_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")       # one line per job (rank 0), captured below - not a perf knob
+        with _CaptureFd1() as cap:                           # the library's own stdout chatter stays out of the JSON stream
+            dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+            t = torch.ones(1, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t)                               # first collective: communicator creation prints the version line
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        init_output = cap.text
+        if float(t.item()) != float(world):
+            raise SystemExit(f"preflight all-reduce returned {float(t.item())}, expected {world}")
 
     def note(msg):
         if rank == 0:
@@ -539,6 +627,9 @@ def main():
     note(f"built {args.workload}; world={world} batch={args.batch} exchange={mode if world > 1 else None}")
 
     extra = {}
+    if world > 1 and rank == 0:
+        extra["preflight"] = preflight(world, backend, init_output)
+        note(f"preflight: {extra['preflight']}")
     if world > 1 and args.exchange == "auto" and not args.with_optimizer:
         # probe both exchange algorithms on this node (xGMI full mesh: direct reduce-scatter + all-gather vs whatever RCCL's
         # all-reduce picks) and keep the faster for the timed region; both numbers are reported

@@ -203,7 +203,8 @@ int libra_rope_bridge_pos(void* qkv, int64_t ld, const void* tb, int64_t ldt, co
 /* The same for a generation step (one new token per sequence, row n = sequence n), which also stores the token's four rows
  * K_same = rope(k), K_cross = rope(k + kb), V_same = v, V_cross = v + vb at slot *slot of the layer's caches [B, Lmax, H*128]
  * (row / batch strides in elements; the reference's cache update, modeling_libra.py:344-361) - libra_rope_bridge_pos followed by
- * libra_kv_cache_append in one launch.  `slot` is read on the device (capturable).                                              */
+ * libra_kv_cache_append in one launch.  `slot` is read on the device (capturable); a slot outside the sequence's own rows
+ * [0, batch_stride / row_stride) stores NOTHING in the caches (no out-of-bounds write when a replayed graph outruns the cache).      */
 int libra_rope_bridge_pos_append(void* qkv, int64_t ld, const void* tb, int64_t ldt, const void* bk_l, const void* bk_v,
                                  const void* bv_l, const void* bv_v, const uint8_t* flag, const void* cos, const void* sin,
                                  int64_t max_pos, void* k_cross, void* v_cross, int64_t ldc, int64_t B, const int* positions,
@@ -212,7 +213,8 @@ int libra_rope_bridge_pos_append(void* qkv, int64_t ld, const void* tb, int64_t 
 /* Append the new token of every sequence to a layer's four caches (the reference's `torch.cat` of past and present key / value
  * states, modeling_libra.py:344-361) in one launch: cache_x[b][*slot][0..W) = x[b][0..W) for x in (K_same, K_cross, V_same,
  * V_cross); x [B, W] with row strides ld_x, caches [B, Lmax, W] with row / batch strides in elements, slot = the position,
- * read on the device (one int64): the decode step stays capturable in a hipGraph. */
+ * read on the device (one int64): the decode step stays capturable in a hipGraph.  A slot outside [0, batch_stride / row_stride)
+ * stores nothing. */
 int libra_kv_cache_append(const void* k_same, int64_t ld_ks, const void* k_cross, int64_t ld_kc, const void* v_same, int64_t ld_vs,
                           const void* v_cross, int64_t ld_vc, void* cache_k_same, void* cache_k_cross, void* cache_v_same,
                           void* cache_v_cross, int64_t row_stride, int64_t batch_stride, const int64_t* slot, int64_t B, int64_t W,
@@ -368,7 +370,8 @@ int libra_rank_outer_wgrad(const void* x, int64_t ldx, const void* coef, int64_t
  * param = bf16(master).  master / m / v fp32, grad / param bf16; all pointers 16-byte aligned.  One HBM pass (28 B/element).
  * grad_norm_sq (device scalar or NULL) + max_grad_norm: global-norm gradient clipping as torch.nn.utils.clip_grad_norm_
  * (HF Trainer `max_grad_norm: 1.0`, libra_pretrain.yaml / deepspeed_configs/ZeRO-2.json "gradient_clipping": "auto"):
- * grad_scale is further multiplied by min(1, max_grad_norm / (sqrt(*grad_norm_sq) + 1e-6)), read on the device. */
+ * *grad_norm_sq = squared norm of the UNSCALED gradient range(s); the applied gradients are grad_scale * grad, so grad_scale is
+ * further multiplied by min(1, max_grad_norm / (|grad_scale| * sqrt(*grad_norm_sq) + 1e-6)), read on the device. */
 int libra_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
                      const float* grad_norm_sq, float max_grad_norm, void* stream);

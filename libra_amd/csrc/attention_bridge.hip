@@ -161,29 +161,42 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
         const int l31o = lane_o & 31, fko = lane_o >> 5;
         const int kswz = (l31o >> 1) & 7;
         const char* krow = kimg + l31o * 128;
+        // Fragment reads run FOUR k-steps (8 MFMAs, > one LDS round trip) ahead of their MFMAs: left to itself hipcc keeps one pair
+        // in flight and every MFMA waits out most of an LDS latency (s_waitcnt lgkmcnt(0) in front of each: the 16 MFMAs of a tile
+        // took ~1400 cycles for 512 of matrix pipe).  kf[h][j]: key half h, k-step j (mod 4).
+        bf16x8 kf[2][4];
+        auto rd = [&](int h, int ks) -> bf16x8 {
+            const int c = (2 * (ks & 3) + fko) ^ kswz;
+            return *(const bf16x8*)(krow + h * 8192 + (ks >> 2) * 4096 + (c << 4));
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kf[0][j] = rd(0, j); kf[1][j] = rd(1, j); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const int c = (2 * (ks & 3) + fko) ^ kswz;
-            const bf16x8 k0 = *(const bf16x8*)(krow + (ks >> 2) * 4096 + (c << 4));
-            const bf16x8 k1 = *(const bf16x8*)(krow + 8192 + (ks >> 2) * 4096 + (c << 4));
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks & 3], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks & 3], qf[ks], s1, 0, 0, 0);
+            if (ks < 4) { kf[0][ks] = rd(0, ks + 4); kf[1][ks] = rd(1, ks + 4); }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // O^T += V^T P^T for one 16-key step: `vstep` = V image + 4096 * step
+    // the 8 transpose reads of a 16-key step go out before its 4 MFMAs (one LDS latency per step instead of one per MFMA)
     auto pv_step = [&](const char* vstep, const bf16x8 pk) {
         const int pp = lane_o & 15, g16 = (lane_o >> 4) & 1;
         const char* vrow = vstep + (4 * (lane_o >> 5) + (pp >> 2)) * 256 + ((pp & 1) << 3);   // keys 4fk + (p>>2), 2nd read +8
         const int tlo = (2 * g16 + ((pp & 3) >> 1)) << 4;
+        union { bf16x8 v; s16x4 h2[2]; } va[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             // 32-line block dt of the 128-line (d) T-type tile
             const char* a = vrow + ((((dt ^ (pp >> 2)) & 3) << 6) | tlo);
-            union { bf16x8 v; s16x4 h2[2]; } va;
-            va.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
-            va.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pk, o[dt], 0, 0, 0);
+            va[dt].h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
+            va[dt].h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[dt].v, pk, o[dt], 0, 0, 0);
     };
     auto rescale = [&](float alpha) {
         l_run *= alpha;

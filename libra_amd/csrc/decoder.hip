@@ -171,11 +171,16 @@ __global__ __launch_bounds__(256) void rope_bridge_kernel(const RopeArgs p) {
             *(u32x2*)(p.k_cross + n * p.ldc + col) = pack4(kc[hf]);
             *(u32x2*)(p.v_cross + n * p.ldc + col) = pack4(vc[hf]);
             if (p.cache_ks) {
-                const long at = n * p.c_batch + (long)p.slot[0] * p.c_row + col;
-                *(u32x2*)(p.cache_ks + at) = pack4(ko[hf]);
-                *(u32x2*)(p.cache_kc + at) = pack4(kc[hf]);
-                *(u32x2*)(p.cache_vs + at) = pack4(v[hf]);
-                *(u32x2*)(p.cache_vc + at) = pack4(vc[hf]);
+                // (a slot outside the sequence's own [0, c_batch / c_row) rows stores nothing: the slot is a device value the host
+                //  cannot check when a captured graph is replayed - `index_copy_`, which this replaces, would have asserted)
+                const long slot = (long)p.slot[0];
+                if (slot >= 0 && (slot + 1) * p.c_row <= p.c_batch) {
+                    const long at = n * p.c_batch + slot * p.c_row + col;
+                    *(u32x2*)(p.cache_ks + at) = pack4(ko[hf]);
+                    *(u32x2*)(p.cache_kc + at) = pack4(kc[hf]);
+                    *(u32x2*)(p.cache_vs + at) = pack4(v[hf]);
+                    *(u32x2*)(p.cache_vc + at) = pack4(vc[hf]);
+                }
             }
         }
     }
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(256) void kv_cache_append_kernel(const KvAppendArgs
     if (which == 1) { src = p.src[1]; ld = p.ld[1]; dst = p.dst[1]; }
     else if (which == 2) { src = p.src[2]; ld = p.ld[2]; dst = p.dst[2]; }
     else if (which == 3) { src = p.src[3]; ld = p.ld[3]; dst = p.dst[3]; }
+    if (s < 0 || (s + 1) * p.row_stride > p.batch_stride) return;      // outside the sequence's rows: nothing is stored (see above)
     const bf16_t* sr = src + (long)b * ld;
     bf16_t* dr = dst + (long)b * p.batch_stride + s * p.row_stride;
     for (int c = threadIdx.x * 8; c < p.W; c += 256 * 8) *(u32x4*)(dr + c) = *(const u32x4*)(sr + c);

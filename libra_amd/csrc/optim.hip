@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     if (i8 >= n) return;
     if (a.gnorm_sq) {
         // torch.nn.utils.clip_grad_norm_ (HF Trainer `max_grad_norm`, DeepSpeed `gradient_clipping`): coef = max / (norm + 1e-6),
-        // applied only when < 1.  The norm is a device scalar: no host read between the backward and the update.
-        const float coef = a.max_norm / (sqrtf(*a.gnorm_sq) + 1e-6f);
+        // applied only when < 1.  The norm is a device scalar: no host read between the backward and the update.  *gnorm_sq is the
+        // squared norm of the UNSCALED bucket contents; the gradients actually applied are grad_scale * grad, so their norm is
+        // |grad_scale| * sqrt(*gnorm_sq) - what clip_grad_norm_ would see after the unscaling
+        const float coef = a.max_norm / (fabsf(a.gscale) * sqrtf(*a.gnorm_sq) + 1e-6f);
         a.gscale *= coef < 1.f ? coef : 1.f;
     }
     if (i8 + 8 <= n) {

@@ -412,9 +412,27 @@ class FlatAdamW:
                             for b, st in zip(self.buckets.buckets, self.state)]}
 
     @torch.no_grad()
-    def load_state_dict(self, sd: dict) -> None:
+    def load_state_dict(self, sd: dict, *, strict_hyper: bool = False) -> None:
         """Resume: restores step count, master weights and moments, and re-derives the bf16 parameters from the masters (so a
-        resumed run continues from the fp32 values, not from bf16-rounded weights with zero moments)."""
+        resumed run continues from the fp32 values, not from bf16-rounded weights with zero moments).  The shard must come from the
+        same world size / rank / sharding mode.  Hyper-parameters are the CONSTRUCTOR's (as torch.optim lets a resumed run change
+        lr or clipping), but a difference from the saved ones is never silent: a warning, or ValueError with strict_hyper."""
+        for k, mine in (("world", self.buckets.world), ("rank", self.buckets.rank), ("sharded", self.shard)):
+            if k in sd and sd[k] != mine:
+                raise ValueError(f"FlatAdamW.load_state_dict: saved {k} = {sd[k]!r}, this optimizer has {mine!r} (a ZeRO-1 shard "
+                                 "can only be resumed by the same rank of the same world size and mode)")
+        mine_h = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                  "max_grad_norm": self.max_grad_norm}
+        saved_h = sd.get("hyper") or {}
+        diff = {k: (tuple(saved_h[k]) if isinstance(saved_h[k], (list, tuple)) else saved_h[k], v) for k, v in mine_h.items()
+                if k in saved_h and (tuple(saved_h[k]) if isinstance(saved_h[k], (list, tuple)) else saved_h[k]) != v}
+        if diff:
+            msg = ("FlatAdamW.load_state_dict: hyper-parameters differ from the checkpoint's (saved, current): "
+                   + ", ".join(f"{k}={a!r}->{b!r}" for k, (a, b) in diff.items()))
+            if strict_hyper:
+                raise ValueError(msg)
+            import warnings
+            warnings.warn(msg + "; continuing with the current ones", RuntimeWarning, stacklevel=2)
         if len(sd["buckets"]) != len(self.state):
             raise ValueError("FlatAdamW.load_state_dict: bucket count differs (different parameter set or bucket size)")
         for b, st, pf, src in zip(self.buckets.buckets, self.state, self.pflat, sd["buckets"]):

@@ -364,6 +364,44 @@ def test_bench_self_launch_refuses_silently_measuring_one_gpu():
     assert r.returncode != 0 and "must agree" in r.stderr
 
 
+def test_bench_preflight_parses_topology_and_never_raises():
+    """Round-3 review item 7(ii): the first real 8-GPU run must be diagnosable from its JSON line alone - collective library
+    version, the NCCL_DEBUG=VERSION line, link type / hops between the first and the last rank's GPU."""
+    import bench
+    txt = """
+============================ ROCm System Management Interface ============================
+================================ Weight between two GPUs =================================
+       GPU0         GPU1         GPU7         
+GPU0   0            15           15           
+GPU1   15           0            15           
+GPU7   15           15           0            
+
+================================= Hops between two GPUs ==================================
+       GPU0         GPU1         GPU7         
+GPU0   0            1            1            
+GPU1   1            0            1            
+GPU7   1            1            0            
+
+=============================== Link Type between two GPUs ===============================
+       GPU0         GPU1         GPU7         
+GPU0   0            XGMI         XGMI         
+GPU1   XGMI         0            PCIE         
+GPU7   XGMI         PCIE         0            
+
+======================================= Numa Nodes =======================================
+GPU[0]		: (Topology) Numa Node: 0
+"""
+    t = bench.parse_showtopo(txt)
+    assert t["link_type"][(0, 7)] == "XGMI" and t["link_type"][(1, 7)] == "PCIE"
+    assert t["hops"][(0, 1)] == "1" and t["weight"][(1, 7)] == "15"
+    assert bench.parse_showtopo("garbage\nGPU0 x") == {}
+    pf = bench.preflight(8, "nccl", "noise\nRCCL version 2.26.6+hip7.0 HEAD:abc\nmore noise")      # no GPUs / maybe no rocm-smi here
+    assert pf["backend"] == "nccl" and pf["nccl_debug_version_line"] == ["RCCL version 2.26.6+hip7.0 HEAD:abc"]
+    assert "rccl_version" in pf and "topology" in pf
+    import json
+    json.dumps(pf)                                           # must go into the bench line as is
+
+
 def test_bench_physical_core_count_is_sane():
     import os
     import sys

@@ -3,7 +3,7 @@
 set -u
 mkdir -p gpurun_out
 out=gpurun_out/ab_step.txt; : > $out
-for rep in 1 2; do
+for rep in 1; do
   for v in r03 head; do
     if [ $v = r03 ]; then d=ab/r03; else d=.; fi
     ( cd $d && timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "

@@ -25,5 +25,11 @@ for s in (2, 3, 4):
           f"median gap {sorted(g[0] for g in gaps)[len(gaps)//2]/1e3:.1f} us")
     for g in gaps[:8]:
         print(f"    {g[0]/1e3:8.1f} us after {g[1]} before {g[2]}")
+    if s == 3:                       # context of the three largest gaps: the kernels around them
+        big = sorted(range(a, b - 1), key=lambda i: rows[i + 1][0] - rows[i][1], reverse=True)[:3]
+        for i in big:
+            print(f"  -- gap {(rows[i + 1][0] - rows[i][1]) / 1e3:.1f} us at kernel {i - a} of the window:")
+            for j in range(max(a, i - 6), min(b, i + 5)):
+                print(f"       {'>>' if j == i + 1 else '  '} +{(rows[j][0] - rows[a][0]) / 1e6:9.3f} ms  {(rows[j][1] - rows[j][0]) / 1e3:8.1f} us  {rows[j][2]}")
 PY
 rm -rf gpurun_out/trace_bridge
