@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 cd "$(dirname "$0")/.."
 out=gpurun_out/attn_ab.txt; : > $out
 keep=$(mktemp); cp libra_amd/lib/liblibra_hip.so $keep
-for rep in 1; do
+for rep in 1 2; do
   for v in "$@"; do
     cp ab/libs/$v.so libra_amd/lib/liblibra_hip.so
     echo -n "$v " >> $out; timeout 90 python tools/attn_bench.py ${ATTN_WHICH:-all} 2>&1 | tail -1 >> $out
