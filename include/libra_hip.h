@@ -100,6 +100,13 @@ size_t libra_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t splits);
 int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, int64_t splits, int flags, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The routed form of the same (row maps as libra_gemm_bf16_nt_routed; K-contiguous A; flags: LIBRA_GEMM_B_T, LIBRA_GEMM_RESIDUAL -
+ * the residual is read at the scattered row by the reduction stage): the decoder's text-stream projections of a step with few
+ * text rows (libra_pretrain.yaml:19 - 700-token sequences leave 976 text rows per 8-sequence step).                          */
+int libra_gemm_bf16_nt_splitk_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, int64_t splits, int flags, const void* resid, int64_t ldr,
+                                     const int32_t* a_rows, int64_t a_phys_rows, const int32_t* c_rows, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm over the last dim (nn.LayerNorm, eps 1e-5: modeling_clip.py:386-388,:866) ---------
  * x,y [rows,D] bf16 contiguous, gamma/beta [D] bf16, mean/rstd [rows] fp32 (saved for backward, may be

@@ -29,6 +29,8 @@ SIGNATURES = {
     "libra_gemm_splitk_plan": [_I64, _I64, _I64],
     "libra_gemm_splitk_workspace_bytes": [_I64, _I64, _I64],
     "libra_gemm_bf16_nt_splitk": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, C.c_size_t, _P],
+    "libra_gemm_bf16_nt_splitk_routed": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _I64, _P, _P,
+                                         C.c_size_t, _P],
     "libra_colsum_workspace_bytes": [_I64, _I64],
     "libra_colsum_bf16": [_P, _I64, _I64, _I64, _P, _P, C.c_size_t, _P],
     "libra_layernorm_bwd_workspace_bytes": [_I64, _I64],

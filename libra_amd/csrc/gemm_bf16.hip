@@ -326,7 +326,7 @@ static TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int64_t groups, int 
 extern "C" int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
     // (skinny outputs included: the rank-8 bridge weight gradients are [4096, 8] and [64, 4096] with K = 4.6k-11.8k tokens -
     //  as ordinary launches they occupy 16-32 workgroups; sliced over K they fill the chip and run at HBM speed)
-    if (M < 8 || N < 8 || K < 4096 || (M % 8) || (N % 8)) return 1;
+    if (M < 8 || N < 8 || K < 4096 || (N % 8)) return 1;          // (M % 8 only matters for a reduction-major A: the entry point checks it)
     const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles > 128) return 1;
     long s = 256 / tiles;
@@ -340,7 +340,9 @@ extern "C" int libra_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
     const double kt = (double)K / 64.0, tiles128 = (double)(((M + 127) / 128) * ((N + 127) / 128));
     if (tiles128 >= 192.0) {
         const double split_us = 8.6 + 1.48 * kt / (double)s + 5.3 + 2.0 * (double)s * (double)M * (double)N * 4.0 / 4.0e6;
-        if (cost128(tiles128, kt) < split_us) return 1;
+        if (cost128(tiles128, kt) < 0.8 * split_us) return 1;     // (0.8: the model is of the plain 128^2 launch; with row maps and a
+                                                                   //  residual in its epilogue it measured 157 us where the model says 109,
+                                                                   //  the sliced launch reads the residual in its reduction stage)
     }
     return (int)s;
 }
@@ -361,6 +363,29 @@ extern "C" int libra_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void*
     if (!workspace || workspace_bytes < libra_gemm_splitk_workspace_bytes(M, N, splits)) return LIBRA_ERR_ALIGN;
     return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 1.0f, 0, flags,
                                  (float*)workspace, (int)splits, nullptr, nullptr, stream, 1, nullptr, nullptr, nullptr);
+}
+
+// The routed form: row gather on A (K-contiguous A only), row scatter on C, optional residual read at the scattered row - what the
+// decoder's text-stream projections need when a step has FEW text rows (libra_pretrain.yaml:19: 700-token sequences, M = 976 text
+// rows per step: 64-172 tiles of 256^2 on 256 CUs unsplit).
+extern "C" int libra_gemm_bf16_nt_splitk_routed(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                                int64_t M, int64_t N, int64_t K, int64_t splits, int flags, const void* resid,
+                                                int64_t ldr, const int32_t* a_rows, int64_t a_phys_rows, const int32_t* c_rows,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0) return LIBRA_OK;
+    if (!A || !B || !C || K <= 0 || (K % BK) || splits < 2 || splits > K / BK) return LIBRA_ERR_SHAPE;
+    if (flags & ~(LIBRA_GEMM_B_T | LIBRA_GEMM_RESIDUAL)) return LIBRA_ERR_SHAPE;     // (a gathered A is K-contiguous)
+    const int bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
+    if ((lda % 8) || (ldb % 8) || (ldc % 8) || (N % 8) || ldc < N || lda < K) return LIBRA_ERR_SHAPE;
+    if (a_rows && a_phys_rows <= 0) return LIBRA_ERR_SHAPE;
+    const int64_t arows = a_rows ? a_phys_rows : M;
+    if (arows * lda >= (1LL << 31)) return LIBRA_ERR_SHAPE;
+    if (bt ? (ldb < N || K * ldb >= (1LL << 31)) : (ldb < K || N * ldb >= (1LL << 31))) return LIBRA_ERR_SHAPE;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) return LIBRA_ERR_ALIGN;
+    if ((flags & LIBRA_GEMM_RESIDUAL) && (!resid || (ldr % 8) || ((uintptr_t)resid & 15))) return LIBRA_ERR_ALIGN;
+    if (!workspace || workspace_bytes < libra_gemm_splitk_workspace_bytes(M, N, splits)) return LIBRA_ERR_ALIGN;
+    return libra_gemm256_launch_(A, lda, B, ldb, C, ldc, M, N, K, nullptr, resid, ldr, nullptr, 0, nullptr, 0, 1.0f, 0, flags,
+                                 (float*)workspace, (int)splits, a_rows, c_rows, stream, 1, nullptr, nullptr, nullptr);
 }
 
 extern "C" int libra_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

@@ -229,9 +229,11 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     else gemm_wave_epilogue<false>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
-// out[m][n] = bf16( sum_s slab[s][m][n] ), 8 elements per thread (deterministic split-K second stage)
+// out[row(m)][n] = bf16( sum_s slab[s][m][n] (+ resid[row(m)][n]) ), row(m) = c_rows ? c_rows[m] : m; 8 elements per thread
+// (deterministic split-K second stage; the routed form serves the decoder's text / vision GEMMs with few output rows)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int S, long MN, int N, bf16_t* __restrict__ C,
-                                                            long ldc) {
+                                                            long ldc, const int* __restrict__ c_rows, const bf16_t* __restrict__ resid,
+                                                            long ldr) {
     const long i8 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (i8 >= MN) return;
     float v[8];
@@ -243,8 +245,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
     }
-    const long m = i8 / N;
+    long m = i8 / N;
     const int n = (int)(i8 - m * N);
+    if (c_rows) m = c_rows[m];
+    if (resid) {
+        float r[8];
+        unpack8(*(const u32x4*)(resid + m * ldr + n), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
     *(u32x4*)(C + m * ldc + n) = pack8(v);
 }
 
@@ -288,7 +297,8 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     if (slab) {
         const long MN = (long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           slab, p.splitk, MN, (int)N, (bf16_t*)C, (long)ldc);
+                           slab, p.splitk, MN, (int)N, (bf16_t*)C, (long)ldc, c_rows, (flags & LIBRA_GEMM_RESIDUAL) ? (const bf16_t*)resid : nullptr,
+                           (long)ldr);
         if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     }
     return LIBRA_OK;

@@ -192,15 +192,26 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         raise ValueError(f"gemm_nt: out is {tuple(out.shape)}, expected {(M, N)}")
     plain = (bias is None and resid is None and not quick_gelu and qgelu_grad_of is None and preact_out is None
              and alpha_cols == 0 and a_rows is None and c_rows is None)
-    if plain and tile == 0 and M > 0 and N > 0:
+    # K-sliced launch + deterministic fp32 slab reduction where the unsplit problem would fill a fraction of the chip: plain
+    # problems (weight gradients), and routed ones with at most a residual (few-row text / vision projections)
+    routed_ok = (not plain and bias is None and not quick_gelu and qgelu_grad_of is None and preact_out is None and alpha_cols == 0
+                 and not a_t and (resid is None or (resid.dim() == 2 and resid.stride(1) == 1 and resid.dtype == BF16
+                                                    and resid.is_cuda and resid.shape == out.shape)))
+    if (plain or routed_ok) and tile == 0 and M > 0 and N > 0 and not (a_t and M % 8):
         splits = _lib.lib().libra_gemm_splitk_plan(M, N, K)
         if splits > 1:
             nbytes = _lib.lib().libra_gemm_splitk_workspace_bytes(M, N, splits)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
-            rc = _lib.lib().libra_gemm_bf16_nt_splitk(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                                      out.stride(0), M, N, K, splits,
-                                                      (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0), ws.data_ptr(),
-                                                      nbytes, _stream())
+            if plain:
+                rc = _lib.lib().libra_gemm_bf16_nt_splitk(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                                          out.stride(0), M, N, K, splits,
+                                                          (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0), ws.data_ptr(),
+                                                          nbytes, _stream())
+            else:
+                rc = _lib.lib().libra_gemm_bf16_nt_splitk_routed(
+                    a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K, splits,
+                    (GEMM_B_T if b_t else 0) | (GEMM_RESIDUAL if resid is not None else 0), _ptr(resid),
+                    resid.stride(0) if resid is not None else 0, _ptr(a_rows), a_phys, _ptr(c_rows), ws.data_ptr(), nbytes, _stream())
             _lib.check(rc, f"gemm_nt_splitk M={M} N={N} K={K} S={splits}")
             return out
     flags = (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0)

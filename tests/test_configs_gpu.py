@@ -171,3 +171,62 @@ def test_bench_self_launches_two_ranks_over_gloo_on_one_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["extra"]["dist_world_size"] == 2
     assert out["extra"]["backend"] == "gloo" and "exposed_comm_ms" in out["extra"] and out["step_check"]["finite"]
+
+
+def _cfg4_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    runs = []
+    for rep in range(2):                                       # the same step sequence twice from scratch: bit-identical or not
+        w = bench.make_bridge(dev, 2, 4096, world, "zero1", with_optimizer=True, recompute=True, full_finetune=True, layers=2)
+        losses = [float(w.step()) for _ in range(3)]
+        norm = float(w.opt.last_grad_norm_sq)
+        chk = 0.0
+        nparam = 0
+        for n, p in w.named:                                   # a checksum over every (all-gathered) bf16 parameter after the updates
+            chk += float(p.detach().double().abs().sum())
+            nparam += p.numel()
+        state = sum(s["master"].numel() for s in w.opt.state)
+        total = sum(b.flat.numel() for b in w.buckets.buckets)
+        trainable_text = sum(p.numel() for n, p in w.named if "vision" not in n)
+        runs.append((losses, norm, chk, nparam, state, total, trainable_text))
+        del w
+        torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    q.put((rank, runs))
+    dist.destroy_process_group()
+
+
+def test_configs4_full_width_two_layers_zero1_on_two_ranks():
+    """BASELINE configs[4] (libra_instruction.yaml:64-67,82; deepspeed_configs/ZeRO-2.json:15-21) at FULL width with 2 decoder
+    layers, as `bench.py --seq 4096 --batch 2 --full-finetune --with-optimizer --recompute --gpus 2` builds it: every parameter
+    trainable (the full-width TEXT weight-gradient GEMMs run: [22016 x 4096] x K 8192 reduction-major operands ...), gradient
+    checkpointing, ZeRO-1-style sharded AdamW with clipping over two ranks (sharing the box's one GPU over gloo).  Properties:
+    finite losses in the random-init band, the loss moves under the optimizer, each rank holds half of the optimizer state, both
+    ranks agree bit for bit, and a second run from scratch reproduces losses, gradient norm and parameter checksum exactly."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cfg4_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=1500) for _ in range(2)], key=lambda t: t[0])
+    [p.join(120) for p in ps]
+    (_, r0), (_, r1) = res
+    (l_a, n_a, c_a, nparam, state, total, text_elems), (l_b, n_b, c_b, *_rest) = r0
+    assert all(math.isfinite(x) for x in l_a) and 4.0 < l_a[0] < 14.0, l_a
+    assert l_a[1] != l_a[0] and l_a[2] < l_a[0], l_a                                  # the clipped AdamW steps move the loss down
+    assert math.isfinite(n_a) and n_a > 0
+    assert (l_a, n_a, c_a) == (l_b, n_b, c_b), "second run from scratch differs"      # deterministic step, exchange and update
+    assert r1[0][0] == l_a and r1[0][2] == c_a, "ranks disagree"                      # identical parameters after the all-gather
+    assert state == total // 2, (state, total)                                          # ZeRO-1: half of master / m / v per rank
+    assert text_elems > 0.5 * nparam                                                    # the text stream IS trainable here (full finetune)
+    parity_report(f"[configs[4] shape, full width x 2 layers, zero1 on 2 ranks] losses {l_a[0]:.4f} -> {l_a[1]:.4f} -> {l_a[2]:.4f}, "
+                  f"gradient norm {math.sqrt(n_a):.3f}; rerun from scratch and both ranks bit-identical; {nparam / 1e9:.2f} B parameters "
+                  f"all trainable, optimizer state {state / total:.2f} of the buckets per rank")

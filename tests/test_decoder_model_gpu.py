@@ -405,3 +405,56 @@ def test_libra_depth32_vs_reference_fixture_error_growth():
                   f"oracle): {' '.join(lines)}; loss {float(out.loss):.5f} vs {loss_ref:.5f}; worst of {n} reference gradients "
                   f"{gw:.2e} ({gname})")
     assert n > 400, n
+
+
+def test_libra_depth32_error_trend_over_weight_seeds():
+    """Round-3 review item 8: on the one 32-layer fixture ours crossed ABOVE the reference's bf16 arithmetic in layers 28-32 (2.7e-2
+    vs 2.3e-2).  Is that a rounding point of ours or the draw?  The same inputs, FIVE other weight draws (the fixture's CRC-seeded
+    generator with other seeds), each against the fp32 oracle (= the reference's fp32 run to 2e-5, test_oracle_libra_golden.py):
+    error of ours and of the oracle run op by op in bf16 at depths 24 / 28 / 31 / 32.  Gate: over the draws the mean ratio
+    ours / theirs at depth >= 28 stays <= 1.25 and no single draw exceeds 1.6; the table goes to the parity report."""
+    import os
+    import sys
+    from helpers import parity_report
+    from libra_amd.libra import LibraConfig, LibraForCausalLM
+    from oracle import libra_oracle as LO
+    from test_oracle_libra_golden import depth32_names_shapes
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from seeded_weights import seeded_state
+    t, meta = load_golden("libra_tiny_depth32.safetensors")
+    c = meta["cfg"]
+    kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
+              max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
+    ids, am, vi = t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"]
+    sig = t["in.signal"].to(BF)
+    valid = am.bool()
+    depths = (24, 28, 31, 32)
+    rows, ratios = [], []
+    for seed in (101, 202, 303, 404, 505):
+        sd = seeded_state(depth32_names_shapes(c), seed)
+        m = LibraForCausalLM(LibraConfig(**c))
+        m.load_state_dict(sd, strict=False)
+        m = m.to(BF).cuda()
+        with torch.no_grad():
+            out = m(input_ids=ids.cuda(), attention_mask=am.cuda(), vision_indices=vi.cuda(), contiguous_signal=sig.cuda(),
+                    output_hidden_states=True)
+            ours = [h.float().cpu() for h in out.hidden_states]
+            ref, hs32 = [], []
+            hid32, _ = LO.model_forward({k: v.float() for k, v in sd.items()}, ids, am, vi, sig.float(), hidden_states=hs32, **kw)
+            ref = hs32[:32] + [hid32]
+            hsb = []
+            hidb, _ = LO.model_forward({k: v.to(BF) for k, v in sd.items()}, ids, am, vi, sig, hidden_states=hsb, **kw)
+            theirs = [h.float() for h in hsb[:32] + [hidb]]
+        cell = []
+        for l in depths:
+            e_o, e_t = rel_err(ours[l][valid], ref[l][valid]), rel_err(theirs[l][valid], ref[l][valid])
+            cell.append(f"{l}:{e_o:.2e}/{e_t:.2e}")
+            if l >= 28:
+                ratios.append(e_o / e_t)
+        rows.append(f"seed {seed} " + " ".join(cell))
+        del m, out
+        torch.cuda.empty_cache()
+    mean = sum(ratios) / len(ratios)
+    parity_report("[a20 depth 32, five other weight draws] hidden-state rel err ours/theirs(bf16 oracle) vs the fp32 oracle: "
+                  + "; ".join(rows) + f"; ours/theirs at depth >= 28: mean {mean:.2f}, min {min(ratios):.2f}, max {max(ratios):.2f}")
+    assert mean <= 1.25 and max(ratios) <= 1.6, (mean, ratios)

@@ -425,6 +425,38 @@ def test_gemm_splitk_skinny(K, M, N, K_):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("M,N,K_,b_t", [(976, 1024, 8192, False), (976, 4096, 11008, True), (1156, 1024, 11008, False), (200, 520, 4096, True)])
+def test_gemm_splitk_routed_few_rows(K, M, N, K_, b_t):
+    """Few output rows, long reduction (the text-stream projections of a 700-token pretraining step: 976 text rows; the vision
+    projections of the instruction recipe: 1156 rows - M is not a multiple of 8): K-sliced launch + deterministic slab reduction with
+    the row gather, the row scatter and the residual of the routed GEMM, against fp32 math and the unsplit pinned structure."""
+    from libra_amd import _lib
+    assert _lib.lib().libra_gemm_splitk_plan(M, N, K_) > 1, "the planner does not slice this shape: the test would not reach the path"
+    g = torch.Generator().manual_seed(7)
+    phys = M + 211
+    rows = torch.randperm(phys, generator=g)[:M].to(torch.int32).cuda()
+    abig, rbig = rnd(phys, K_, seed=71, scale=0.5), rnd(phys, N, seed=72)
+    b = rnd(N, K_, seed=73, scale=0.1)
+    bb = b.t().contiguous() if b_t else b
+    ref = abig[rows.long()].float() @ b.float().t()
+    for resid in (None, rbig):
+        cbig = torch.zeros(phys, N, dtype=BF, device="cuda")
+        K.gemm_nt(abig, bb, out=cbig, b_t=b_t, a_rows=rows, c_rows=rows, resid=resid)
+        want = ref + (rbig[rows.long()].float() if resid is not None else 0.0)
+        close(cbig[rows.long()], want, rel=2e-3, what=f"routed split-K {M}x{N}x{K_} resid={resid is not None}")
+        untouched = torch.ones(phys, dtype=torch.bool, device="cuda"); untouched[rows.long()] = False
+        assert float(cbig[untouched].abs().max()) == 0.0
+        c2 = torch.zeros(phys, N, dtype=BF, device="cuda")
+        K.gemm_nt(abig, bb, out=c2, b_t=b_t, a_rows=rows, c_rows=rows, resid=resid)
+        assert torch.equal(cbig, c2)                                            # deterministic reduction
+        c3 = torch.zeros(phys, N, dtype=BF, device="cuda")                   # the unsplit 128^2 structure on the same problem
+        K.gemm_nt(abig, bb, out=c3, b_t=b_t, a_rows=rows, c_rows=rows, resid=resid, tile=1)
+        close(cbig[rows.long()], c3[rows.long()].float(), rel=5e-3, what="split vs unsplit")      # two bf16 roundings: one ulp apart at most
+    # plain problem whose M is not a multiple of 8 (was excluded from slicing by an over-strict plan)
+    a = rnd(M, K_, seed=74, scale=0.5)
+    close(K.gemm_nt(a, bb, b_t=b_t), a.float() @ b.float().t(), rel=2e-3, what="plain split-K, ragged M")
+
+
 @pytest.mark.parametrize("M,N,K_", [(1, 8, 64), (3, 200, 256), (8, 4096, 4096), (8, 1024, 11008), (16, 520, 3136), (13, 64, 512)])
 def test_gemm_skinny_rows(K, M, N, K_):
     """M <= 16 (the generation step) goes to the skinny HBM-bound kernel: plain, residual, row gather / scatter."""
