@@ -428,10 +428,11 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     return x_out
 
 
-def check_ids(input_ids, flag_bs, d: DecDims):
+def check_ids(input_ids, flag_bs, d: DecDims, also=()):
     """One fused device-side validation + ONE host read: vision_flag == (ids[0] >= V) (modeling_libra.py:707-710), text ids
     inside the text table and every codebook's vision id inside the vision table (nn.Embedding device-asserts upstream;
-    gather_rows itself does not bound-check)."""
+    gather_rows itself does not bound-check).  `also`: 0-d integer tensors that ride along on the same read -> their values
+    (the loss's target counts: reading them here keeps backward() free of a host synchronisation)."""
     if input_ids.dtype != torch.int64:
         raise TypeError(f"input_ids must be int64 (torch.long), got {input_ids.dtype}")
     V, Vv = d.vocab, d.vision_vocab
@@ -440,13 +441,15 @@ def check_ids(input_ids, flag_bs, d: DecDims):
     bad_text = ((ids0 < 0) & ~flag_bs).any()
     # (no boolean-mask gather: `input_ids[:, flag_bs]` is a hidden nonzero() + host sync)
     bad_vis = (flag_bs[None] & ((input_ids < V) | (input_ids >= V + Vv))).any()
-    code = int((bad_flag.to(torch.int32) + 2 * bad_text.to(torch.int32) + 4 * bad_vis.to(torch.int32)).item())
+    code = bad_flag.to(torch.int64) + 2 * bad_text.to(torch.int64) + 4 * bad_vis.to(torch.int64)
+    code, *rest = torch.stack([code, *[a.to(torch.int64) for a in also]]).tolist()
     if code & 1:
         raise AssertionError("Inconsistent input_ids and vision_flag")                 # modeling_libra.py:707-710
     if code & 2:
         raise IndexError("negative token id in input_ids")
     if code & 4:
         raise IndexError(f"a vision token id lies outside [{V}, {V + Vv}) in one of the codebooks")
+    return rest
 
 
 def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, unified: bool = False, feats=None, packed=None):
@@ -519,7 +522,9 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
             cell = (vl - 1).clamp(0, max(d.res * d.res - 1, 0))
             row = torch.where((vl >= 1) & (vl <= d.max_vision_len - 2), cell // d.res + 1, torch.zeros_like(vl))
             cache.run2d = pos2[:, -1, 0].long() - row
-    check_ids(input_ids, flag.view(B, S).bool(), d)
+    # the loss's per-codebook target counts (shifted labels >= 0) are known before the first layer: read with the id check
+    cnts = [(labels[q][:, 1:] >= 0).sum().clamp_min(1) for q in range(Q)] if labels is not None else []
+    counts = check_ids(input_ids, flag.view(B, S).bool(), d, also=cnts)
     cos, sin = rope_tables(d.hidden // d.heads, rope_rows(d, S), dev)
     saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
     x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None, vision_indices=vision_indices)
@@ -566,7 +571,7 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
             K.copy_rows(hidden_src, src2d[1], n_v, feats, d.hidden)
     z_lang, z_vis, z_all = heads_forward(sd, d, hidden, flag, lang_idx, vis_idx, Q, unified=unified, feats=feats, packed=packed)
     loss = None
-    tgts, counts = [], []
+    tgts = []
     if labels is not None:
         loss = torch.zeros((), dtype=torch.float32, device=dev)
         for q in range(Q):
@@ -584,9 +589,8 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
                     tot = tot + K.ce_rows(z_lang, tl, 0).sum()
                 if n_v:
                     tot = tot + K.ce_rows(z_vis[q], tv, d.vocab).sum()
-            cnt = (tgt >= 0).sum().clamp_min(1)
-            loss = loss + tot / cnt
-            tgts.append((tl, tv)); counts.append(cnt)
+            loss = loss + tot / counts[q]
+            tgts.append((tl, tv))
         loss = loss / Q
     if save:
         saved.update(x_last=x, rstd_f=rstd_f, hidden=hidden, tgts=tgts, counts=counts, cos=cos, sin=sin, lens=lens, B=B, S=S,
@@ -809,7 +813,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     # ---- loss -> logits -> final hidden
     hidden = sv["hidden"]
     dhid = torch.zeros((N, H), dtype=BF16, device=dev)
-    coef = [float(gscale / (sv["counts"][q].item() * Q)) for q in range(Q)]       # upstream gradient folded into dlogits
+    coef = [float(gscale / (sv["counts"][q] * Q)) for q in range(Q)]       # upstream gradient folded into dlogits
     def head_pad(name):
         """Head weight with its vocab (the dgrad reduction length) zero-padded to the GEMM's 64 granule."""
         W = sd[name]

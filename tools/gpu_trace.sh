@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_bridge -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/trace_bridge.log 2>&1 ); echo "trace rc=$?"
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_bridge -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra > $R/gpurun_out/trace_bridge.log 2>&1 ); echo "trace rc=$?"
 python - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace_bridge/**/*kernel_trace.csv", recursive=True)[0]
