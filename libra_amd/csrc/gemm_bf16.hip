@@ -29,6 +29,9 @@
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
 
+#ifndef TO128
+#define TO128 8, 8, 4, 2
+#endif
 namespace libra {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -62,16 +65,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- tile coordinates: XCD-contiguous, then grouped 8 M-tiles deep ----
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int u = xcd_remap(blockIdx.x, ntiles);
-    constexpr int GM = 8;
-    const int width = GM * p.tiles_n;
-    const int grp = u / width;
-    const int first_m = grp * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (u % width) % gsz;
-    const int tn = (u % width) / gsz;
+    // ---- tile coordinates: one compact patch per wave of workgroups, one sub-patch per XCD (hip_common.hpp: tile_order) ----
+    const TileRC trc = tile_order<TO128>(blockIdx.x, p.tiles_m, p.tiles_n);
+    const int tm = trc.tm, tn = trc.tn;
     const int m0 = tm * BM, n0 = tn * BN;
     const bf16_t* Ap = p.A; const bf16_t* Bp = p.B; bf16_t* Cp = p.C;          // grouped launch: blockIdx.z picks the group
     {   // (constant indices + selects: a dynamically indexed kernel-argument array would be copied to scratch)

@@ -31,6 +31,9 @@
 #include "gemm_tiles.hpp"
 #include "gemm_epilogue.hpp"
 
+#ifndef TO256
+#define TO256 4, 8, 4, 2
+#endif
 namespace libra {
 
 constexpr int HB = 16384;               // one 128x64 half-tile
@@ -47,15 +50,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, fk = lane >> 5;
 
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int u = xcd_remap(blockIdx.x, ntiles);
-    constexpr int GM = 4;
-    const int width = GM * p.tiles_n;
-    const int grp = u / width;
-    const int first_m = grp * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (u % width) % gsz;
-    const int tn = (u % width) / gsz;
+    const TileRC trc = tile_order<TO256>(blockIdx.x, p.tiles_m, p.tiles_n);
+    const int tm = trc.tm, tn = trc.tn;
     const int m0 = tm * 256, n0 = tn * 256;
     // grouped launch (same shapes / strides / row maps, different operands): blockIdx.z picks the group
     const bf16_t* Ap = p.A; const bf16_t* Bp = p.B; bf16_t* Cp = p.C;

@@ -30,6 +30,9 @@
 #include "gemm_tiles.hpp"
 #include "gemm_epilogue.hpp"
 
+#ifndef TOW
+#define TOW 4, 16, 4, 2
+#endif
 namespace libra {
 
 constexpr int WU = 16384;               // one unit: 128 lines x 64 k
@@ -45,15 +48,8 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int u = xcd_remap(blockIdx.x, ntiles);
-    constexpr int GM = 4;
-    const int width = GM * p.tiles_n;
-    const int grp = u / width;
-    const int first_m = grp * GM;
-    const int gsz = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (u % width) % gsz;
-    const int tn = (u % width) / gsz;
+    const TileRC trc = tile_order<TOW>(blockIdx.x, p.tiles_m, p.tiles_n);
+    const int tm = trc.tm, tn = trc.tn;
     const int m0 = tm * 256, n0 = tn * GW_BN;
     const bf16_t* Ap = p.A; const bf16_t* Bp = p.B; bf16_t* Cp = p.C;
     {   // grouped launch: blockIdx.z picks the group (constant indices + selects: no scratch copy of the argument arrays)

@@ -154,4 +154,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+
+// Tile (row, column) of workgroup `bid` of a tiles_m x tiles_n GEMM grid.  The hardware deals consecutive workgroup ids round-robin to
+// the 8 XCDs, so the WT = 8*XR*XC workgroups resident at one time ("a wave of workgroups") are given one compact patch of the output:
+// XCD x takes an XR x XC sub-patch (its private L2 sees XR + XC operand panels for XR*XC tiles) and the 8 sub-patches tile a
+// (XR*WR) x (XC*WC) patch, so the whole chip reads (XR*WR + XC*WC) panels per wave from the memory side and the 8 XCDs fetch the SAME
+// B panels at the same time (one HBM read + Infinity-Cache hits) instead of at 8 different moments of the launch.  Waves sweep the
+// columns of one XR*WR-row group before moving to the next group: the group's A panels stay cache-resident over the sweep.
+// Ragged edges shrink the group / block they touch; the map stays a bijection.  The last partial wave is dealt in XCD-contiguous chunks.
+struct TileRC { int tm, tn; };
+template <int XR, int XC, int WR, int WC>
+__device__ __forceinline__ TileRC tile_order(int bid, int tiles_m, int tiles_n) {
+    static_assert(WR * WC == 8, "8 XCDs");
+    constexpr int XT = XR * XC, WT = XT * 8, GR = XR * WR;
+    const int ntiles = tiles_m * tiles_n;
+    const int full = ntiles / WT * WT;
+    int u;
+    if (bid < full) u = (bid / WT) * WT + (bid & 7) * XT + ((bid % WT) >> 3);
+    else u = full + xcd_remap(bid - full, ntiles - full);
+    const int gw = GR * tiles_n;                    // level 1: groups of GR rows, each sweeping every column
+    const int g = u / gw;
+    int v = u - g * gw;
+    const int r0 = g * GR, gsz = min(GR, tiles_m - r0);
+    const int cb = v / (gsz * XC);                  // level 2: blocks of XC columns inside the group
+    v -= cb * gsz * XC;
+    const int c0 = cb * XC, csz = min(XC, tiles_n - c0);
+    const int rb = v / (XR * csz);                  // level 3: XR-row sub-blocks inside the column block (one XCD's patch)
+    v -= rb * XR * csz;
+    const int rr0 = rb * XR, rsz = min(XR, gsz - rr0);
+    TileRC t;
+    t.tm = r0 + rr0 + v % rsz;
+    t.tn = c0 + v / rsz;
+    return t;
+}
+
 }  // namespace libra
