@@ -28,6 +28,7 @@ __device__ __forceinline__ float qgelu_grad(float x) {
 }
 
 #define LIBRA_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LIBRA_VMCNT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define LIBRA_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // ---- epilogue of ONE wave: its 128 x 64 block (acc[i][j] = 32 x 32 MFMA accumulators, i = 32-row slab, j = 32-column half) goes
@@ -36,8 +37,10 @@ __device__ __forceinline__ float qgelu_grad(float x) {
 // m0w / n0w: first output row / column of the wave's block.  Two instantiations of the same code: INTERIOR (the whole
 // workgroup tile lies inside C and N is a multiple of 8 - every per-lane bound test and every scalar tail path folds away; > 98 %
 // of the tiles of the hot shapes) and the generic edge version.  The choice is wave-uniform (it comes from blockIdx).
-template <bool IN>
-__device__ __forceinline__ void gemm_wave_epilogue(const Gemm256Args& p, const f32x16 (&acc)[4][2], bf16_t* Cp, float* ct,
+// (NJ / J0: the accumulator array may be wider than the 64 columns handled here - gemm_bf16_x.hip's waves own 128 x 128 and call
+// this once per 64-column half, J0 = 0 / 2.)
+template <bool IN, int NJ = 2, int J0 = 0>
+__device__ __forceinline__ void gemm_wave_epilogue(const Gemm256Args& p, const f32x16 (&acc)[4][NJ], bf16_t* Cp, float* ct,
                                                    const int m0w, const int n0w, const int lane) {
     const int l31 = lane & 31, fk = lane >> 5;
     const int cg = lane & 7;                                   // 8-column group within the wave's 64 columns
@@ -131,12 +134,12 @@ __device__ __forceinline__ void gemm_wave_epilogue(const Gemm256Args& p, const f
     Extras e0, e1;
     fetch(0, e0);
     fetch(1, e1);
-    epi(acc[0][0], acc[0][1], 0, e0);
+    epi(acc[0][J0], acc[0][J0 + 1], 0, e0);
     fetch(2, e0);
-    epi(acc[1][0], acc[1][1], 1, e1);
+    epi(acc[1][J0], acc[1][J0 + 1], 1, e1);
     fetch(3, e1);
-    epi(acc[2][0], acc[2][1], 2, e0);
-    epi(acc[3][0], acc[3][1], 3, e1);
+    epi(acc[2][J0], acc[2][J0 + 1], 2, e0);
+    epi(acc[3][J0], acc[3][J0 + 1], 3, e1);
 }
 
 }  // namespace libra

@@ -80,6 +80,11 @@ __device__ __forceinline__ void glds16_off(const void* sbase, unsigned voff, voi
     const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(LIBRA_LDS char*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
+// the same with the LDS destination given as a byte address (wave-uniform)
+__device__ __forceinline__ void glds16_off_at(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
 // Make the compiler finish (wait for) whatever produces `v` HERE: values loaded in a prologue and first used inside a
 // tile loop would otherwise get their s_waitcnt vmcnt inside the loop, where it also drains the hidden LDS-DMA queue.
 template <typename T>
