@@ -106,7 +106,7 @@ def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recomp
     of the same width - the bench itself always runs the 32 layers of the configuration."""
     from libra_amd import decoder_engine as DE
     from libra_amd import dp
-    from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy, assemble_inputs, get_labels
+    from libra_amd.libra import LibraConfig, LibraForCausalLM, apply_freeze_policy, assemble_inputs, get_labels, plan_assembly
     clip, tok, pixel, _ = build_vit(device, batch)
     clip.requires_grad_(False)
     tok.model.encoder.allow_grad = False
@@ -148,10 +148,11 @@ def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recomp
             if w.buckets is None:
                 for p in params:
                     p.grad = None
+            plan = plan_assembly(text, img_ph_token_id=PH)          # (as LibraTokenizer.forward: placeholder positions before the encoder is queued)
             with torch.no_grad():
                 img = tok.encode(pixel)
             inp = assemble_inputs(text, am, img, img_ph_token_id=PH, img_gen_token_id=V - 2, boi_token_id=tok.boi_token_id,
-                                  num_codebook=2, max_vision_token_length=L)
+                                  num_codebook=2, max_vision_token_length=L, plan=plan)
             labels = get_labels(inp, spans, boi_token_id=tok.boi_token_id, bos_token_id=1)
             out = dec(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], vision_indices=inp["vision_indices"],
                       contiguous_signal=inp["coninous_signal"], labels=labels)

@@ -281,10 +281,12 @@ int libra_ce_rows(const void* logits, int64_t ldz, int64_t V, const int64_t* tar
                   float* loss_rows, int64_t rows, void* stream);
 
 /* ---- decoder backward row kernels ------------------------------------------------------------------*/
-/* dlogits[r,v] = sum_q [t_q[r]>=0] coef_q (softmax(z_r)[v] - [v == t_q[r]-target_sub]); target1 may be NULL.   */
+/* dlogits[r,v] = sum_q [t_q[r]>=0] coef_q (softmax(z_r)[v] - [v == t_q[r]-target_sub]); target1 may be NULL.
+ * scale_dev (device fp32 scalar, may be NULL): both coefficients are multiplied by *scale_dev in the kernel - the upstream
+ * gradient of the loss (autograd's incoming scalar, a loss scale) stays on the device, no host read at the start of backward. */
 int libra_ce_rows_bwd(const void* logits, int64_t ldz, int64_t V, const int64_t* target0, const int64_t* target1,
-                      int64_t target_sub, float coef0, float coef1, void* dlogits, int64_t lddz, int64_t rows,
-                      void* stream);
+                      int64_t target_sub, float coef0, float coef1, const float* scale_dev, void* dlogits, int64_t lddz,
+                      int64_t rows, void* stream);
 /* routed RMSNorm backward: dx = rstd (g - xh mean(g xh)) [+ dres], g = dy w_m, xh = x rstd (rstd from the forward) */
 int libra_rmsnorm_routed_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* w_lang,
                              const void* w_vis, const uint8_t* flag, const float* rstd, const void* dres, int64_t lddr,

@@ -61,7 +61,7 @@ SIGNATURES = {
     "libra_gather_rows": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _P],
     "libra_copy_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P],
     "libra_ce_rows": [_P, _I64, _I64, _P, _I64, _P, _I64, _P],
-    "libra_ce_rows_bwd": [_P, _I64, _I64, _P, _P, _I64, _F, _F, _P, _I64, _I64, _P],
+    "libra_ce_rows_bwd": [_P, _I64, _I64, _P, _P, _I64, _F, _F, _P, _P, _I64, _I64, _P],
     "libra_rmsnorm_routed_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
     "libra_rmsnorm_wgrad_workspace_bytes": [_I64, _I64],
     "libra_rmsnorm_routed_wgrad": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _I64, _I64, _P, _I64, _P],
@@ -84,7 +84,7 @@ SIGNATURES = {
     "libra_sumsq_bf16": [_P, _I64, _P, _I, _P, C.c_size_t, _P],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class LibraHipError(RuntimeError):

@@ -10,13 +10,14 @@ namespace libra {
 // averaged over the codebooks: coef_q = 1 / (count_q * Q)); one wave per row, three passes over the row.
 __global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const bf16_t* __restrict__ z, long ldz, int V,
                                                           const long long* __restrict__ t0, const long long* __restrict__ t1,
-                                                          long long sub, float c0, float c1, bf16_t* __restrict__ dz, long lddz,
-                                                          long rows) {
+                                                          long long sub, float c0, float c1, const float* __restrict__ scale_dev,
+                                                          bf16_t* __restrict__ dz, long lddz, long rows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const long long a0 = t0 ? t0[row] : -1, a1 = t1 ? t1[row] : -1;
-    const float w0 = a0 >= 0 ? c0 : 0.f, w1 = a1 >= 0 ? c1 : 0.f;
+    const float sc = scale_dev ? *scale_dev : 1.0f;
+    const float w0 = a0 >= 0 ? c0 * sc : 0.f, w1 = a1 >= 0 ? c1 * sc : 0.f;
     const float wsum = w0 + w1;
     const bf16_t* zr = z + row * ldz;
     bf16_t* dr = dz + row * lddz;
@@ -327,14 +328,14 @@ static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK
 using namespace libra;
 
 extern "C" int libra_ce_rows_bwd(const void* logits, int64_t ldz, int64_t V, const int64_t* target0, const int64_t* target1,
-                                 int64_t target_sub, float coef0, float coef1, void* dlogits, int64_t lddz, int64_t rows,
-                                 void* stream) {
+                                 int64_t target_sub, float coef0, float coef1, const float* scale_dev, void* dlogits,
+                                 int64_t lddz, int64_t rows, void* stream) {
     if (rows <= 0) return LIBRA_OK;
     if (V <= 0 || ldz < V || lddz < V) return LIBRA_ERR_SHAPE;
     if (!logits || !dlogits || (!target0 && !target1)) return LIBRA_ERR_ALIGN;
     hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)logits, (long)ldz, (int)V, (const long long*)target0, (const long long*)target1,
-                       (long long)target_sub, coef0, coef1, (bf16_t*)dlogits, (long)lddz, (long)rows);
+                       (long long)target_sub, coef0, coef1, scale_dev, (bf16_t*)dlogits, (long)lddz, (long)rows);
     return launched();
 }
 

@@ -797,8 +797,10 @@ def _norm_wgrad(dy, x, rstd, flag, lang_idx, vis_idx, want_l: bool, want_v: bool
     return out[:H], out[H:]
 
 
-def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
-    """Gradients of out["loss"] w.r.t. every parameter name in `want` (a set) -> {name: bf16 grad}."""
+def backward(sd, packed, d: DecDims, out, want, gscale=1.0):
+    """Gradients of out["loss"] w.r.t. every parameter name in `want` (a set) -> {name: bf16 grad}.
+    gscale: the upstream gradient of the loss - a float, or a one-element device tensor (autograd's incoming scalar), which is
+    applied inside the logits-gradient kernel and never read by the host."""
     sv = out["saved"]
     flag, lang_idx, vis_idx = out["flag"], out["lang_idx"], out["vis_idx"]
     B, S, Q = sv["B"], sv["S"], sv["Q"]
@@ -813,6 +815,9 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     # ---- loss -> logits -> final hidden
     hidden = sv["hidden"]
     dhid = torch.zeros((N, H), dtype=BF16, device=dev)
+    gdev = None
+    if isinstance(gscale, torch.Tensor):
+        gdev, gscale = gscale.detach().reshape(1).to(device=dev, dtype=torch.float32), 1.0
     coef = [float(gscale / (sv["counts"][q] * Q)) for q in range(Q)]       # upstream gradient folded into dlogits
     def head_pad(name):
         """Head weight with its vocab (the dgrad reduction length) zero-padded to the GEMM's 64 granule."""
@@ -828,7 +833,7 @@ def backward(sd, packed, d: DecDims, out, want, gscale: float = 1.0):
     def dlogits(z, t0, t1, sub, c0, c1, Vp):
         n, V = z.shape
         full = torch.zeros((K.round_up(n, 64), Vp), dtype=BF16, device=dev)      # zero pad rows AND pad columns
-        K.ce_rows_bwd(z, t0, t1, sub, c0, c1, full[:n, :V])
+        K.ce_rows_bwd(z, t0, t1, sub, c0, c1, full[:n, :V], scale=gdev)
         return full
 
     if Q > 2:

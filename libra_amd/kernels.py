@@ -194,7 +194,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
              and alpha_cols == 0 and a_rows is None and c_rows is None)
     # K-sliced launch + deterministic fp32 slab reduction where the unsplit problem would fill a fraction of the chip: plain
     # problems (weight gradients), and routed ones with at most a residual (few-row text / vision projections)
-    routed_ok = (not plain and bias is None and not quick_gelu and qgelu_grad_of is None and preact_out is None and alpha_cols == 0
+    # (M <= 16 routed rows are the generation step: the library's weight-streaming skinny kernel, not K slices)
+    routed_ok = (not plain and M > 16 and bias is None and not quick_gelu and qgelu_grad_of is None and preact_out is None and alpha_cols == 0
                  and not a_t and (resid is None or (resid.dim() == 2 and resid.stride(1) == 1 and resid.dtype == BF16
                                                     and resid.is_cuda and resid.shape == out.shape)))
     if (plain or routed_ok) and tile == 0 and M > 0 and N > 0 and not (a_t and M % 8):
@@ -836,11 +837,14 @@ def bridge_attn_bwd(q, k_same, k_cross, v_same, v_cross, out, dout, flag, kv_len
 
 
 # ---- routed decoder, backward rows -----------------------------------------------------------------------
-def ce_rows_bwd(logits, t0, t1, sub: int, c0: float, c1: float, out):
+def ce_rows_bwd(logits, t0, t1, sub: int, c0: float, c1: float, out, scale=None):
+    """scale (fp32 device scalar, optional): multiplies both coefficients inside the kernel (no host read of it)."""
     _chk2d(logits, "logits"); _chk2d(out, "out")
     rows, V = logits.shape
+    if scale is not None and (scale.dtype != torch.float32 or scale.numel() != 1 or scale.device != logits.device):
+        raise ValueError("ce_rows_bwd: scale must be a one-element fp32 tensor on the logits' device")
     rc = _lib.lib().libra_ce_rows_bwd(logits.data_ptr(), logits.stride(0), V, _ptr(t0), _ptr(t1), sub, float(c0), float(c1),
-                                      out.data_ptr(), out.stride(0), rows, _stream())
+                                      _ptr(scale), out.data_ptr(), out.stride(0), rows, _stream())
     _lib.check(rc, "ce_rows_bwd")
     return out
 

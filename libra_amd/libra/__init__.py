@@ -4,7 +4,7 @@ from .lookup_free_quantization import LFQ
 from .vqgan import VQModel
 from .configuration_libra import LibraConfig
 from .modeling_libra import LibraForCausalLM, LibraTrainWrapper, LlamaRMSNorm
-from .tokenization_libra import LibraTokenizer, apply_freeze_policy, assemble_inputs, get_labels
+from .tokenization_libra import LibraTokenizer, apply_freeze_policy, assemble_inputs, get_labels, plan_assembly
 
 __all__ = ["CLIPVisionTower", "ImageTokenizer", "LFQ", "VQModel", "LibraConfig", "LibraForCausalLM", "LibraTrainWrapper",
-           "LibraTokenizer", "LlamaRMSNorm", "apply_freeze_policy", "assemble_inputs", "get_labels"]
+           "LibraTokenizer", "LlamaRMSNorm", "apply_freeze_policy", "assemble_inputs", "get_labels", "plan_assembly"]

@@ -459,9 +459,9 @@ class _LibraFunction(torch.autograd.Function):
     def backward(ctx, gloss):
         if ctx.out.get("saved") is None:
             raise RuntimeError("backward through LibraForCausalLM requested but no activations were saved")
-        # the incoming scalar (1.0, or a loss scale / 1/accum factor) is folded into the logits gradient: one host read
-        # per step instead of one elementwise kernel per parameter
-        grads = DE.backward(ctx.sd, ctx.model._packed, ctx.model._dims, ctx.out, ctx.want, gscale=float(gloss))
+        # the incoming scalar (1.0, or a loss scale / 1/accum factor) is folded into the logits gradient ON THE DEVICE: no
+        # elementwise kernel per parameter and no host read (which would drain the whole forward before backward is queued)
+        grads = DE.backward(ctx.sd, ctx.model._packed, ctx.model._dims, ctx.out, ctx.want, gscale=gloss)
         res = []
         from .. import dp
         for n in ctx.names:

@@ -17,38 +17,48 @@ from transformers import BatchEncoding
 MAX_TOKEN_LENGTH = 2048                                                         # tokenization_libra.py:15
 
 
+def plan_assembly(text_ids: torch.Tensor, *, img_ph_token_id: int):
+    """Where the `<img_ph>` placeholders are: (mask [B,S], (batch index, position) of every placeholder in row-major order).
+    This is the ONE host-synchronising step of the tensor assembly (a nonzero) and it does not depend on the image encoder's
+    output - a training loop calls it BEFORE queueing the encoder and hands the result to assemble_inputs(plan=...), so the host
+    never waits for the encoder between the encoder and the decoder (the boolean-mask scatters upstream uses,
+    tokenization_libra.py:266,273,292, each hide such a wait: ~2 ms of idle GPU per step at the benchmark shape)."""
+    ph = text_ids == img_ph_token_id                                            # :250
+    return ph, ph.nonzero(as_tuple=True)
+
+
 def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_inputs: Optional[dict], *,
                     img_ph_token_id: int, img_gen_token_id: int, boi_token_id: int, num_codebook: int,
                     max_vision_token_length: int, contiguous_ignore_signs=None, has_image_flag=None,
-                    truncation: bool = False, max_length: Optional[int] = None) -> dict:
+                    truncation: bool = False, max_length: Optional[int] = None, plan=None) -> dict:
     """-> {"input_ids" [Q,B,S], "attention_mask", "vision_indices", "coninous_signal" [sic]} (same keys, incl. the
-    upstream spelling, that LibraTrainWrapper.forward consumes: modeling_libra.py:1425-1430)."""
+    upstream spelling, that LibraTrainWrapper.forward consumes: modeling_libra.py:1425-1430).
+    plan: plan_assembly(text_ids, ...) computed earlier (default: computed here)."""
     dev = text_ids.device
-    ph = text_ids == img_ph_token_id                                            # :250
-    ids = text_ids.clone()
-    gen = ids == img_gen_token_id
-    ids[gen] = boi_token_id                                                     # :253-254
+    ph, (pb, ps) = plan if plan is not None else plan_assembly(text_ids, img_ph_token_id=img_ph_token_id)
+    gen = text_ids == img_gen_token_id
+    ids = text_ids.masked_fill(gen, boi_token_id)                               # :253-254
     ids = ids[None, ...].repeat(num_codebook, 1, 1)                             # :256
     has_images = image_inputs is not None
     if has_images:
         img_ids, feat = image_inputs["input_ids"], image_inputs["encoder_feat"]
         if has_image_flag is not None:                                          # :262-264
             img_ids, feat = img_ids[:, has_image_flag], feat[has_image_flag]
-        ids[:, ph] = img_ids.flatten(1, 2)                                      # :266
+        ids[:, pb, ps] = img_ids.flatten(1, 2)                                  # :266 (a placeholder / image-token count mismatch raises here, as upstream)
     vi = torch.full(attention_mask.shape, max_vision_token_length, dtype=torch.long, device=dev)      # :270
     signal = None
     if has_images:
         L = img_ids.shape[2]
-        vi[ph] = torch.arange(L, device=dev).expand(img_ids.shape[1], -1).flatten(0, 1)                 # :273
+        vi[pb, ps] = torch.arange(L, device=dev).expand(img_ids.shape[1], -1).flatten(0, 1)             # :273
         z = torch.zeros([feat.shape[0], 1, feat.shape[2]], device=feat.device, dtype=feat.dtype)
         cont = torch.cat([z, feat, z], dim=1)                                   # :279-286
         if contiguous_ignore_signs is not None:
             sel = torch.as_tensor(contiguous_ignore_signs, device=cont.device, dtype=torch.bool)
             cont[sel] = 0                                                       # :288-289
         signal = torch.zeros([ids.shape[1], ids.shape[2], cont.shape[-1]], dtype=cont.dtype, device=cont.device)
-        signal[ph] = cont.flatten(0, 1).contiguous()                            # :291-292
+        signal[pb, ps] = cont.flatten(0, 1)                                     # :291-292
     else:
-        vi[gen] = 0                                                             # :275
+        vi.masked_fill_(gen, 0)                                                 # :275
     if truncation and max_length is not None:                                   # :296-301
         ids, attention_mask, vi = ids[:, :, :max_length], attention_mask[:, :max_length], vi[:, :max_length]
         if signal is not None:
@@ -59,10 +69,10 @@ def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_
 
 def get_labels(inputs: dict, label_mask_position_map: Sequence[Sequence], *, boi_token_id: int, bos_token_id: int):
     """LibraTrainWrapper.get_labels: ids with -100 at padding, BOI, BOS and the given (start, end) spans."""
-    labels = inputs["input_ids"].clone()
-    labels[:, inputs["attention_mask"] == 0] = -100
-    labels[labels == boi_token_id] = -100
-    labels[labels == bos_token_id] = -100
+    ids = inputs["input_ids"]
+    # (masked_fill, not boolean-mask assignment: `labels[:, mask] = v` is a hidden nonzero + host synchronisation)
+    drop = (inputs["attention_mask"] == 0)[None] | (ids == boi_token_id) | (ids == bos_token_id)
+    labels = ids.masked_fill(drop, -100)
     labels = labels.permute(1, 2, 0)
     for label, spans in zip(labels, label_mask_position_map):
         for start, end in spans:
@@ -204,6 +214,8 @@ class LibraTokenizer(torch.nn.Module):
         if (text_inputs["length"] > MAX_TOKEN_LENGTH).sum():
             logging.warning("The input token length ecceeds the max number that the model can hold. This may cause "
                             "performance degradation or OOM.")
+        # placeholder positions first (the assembly's one host read), THEN the image encoder: the host does not wait for the encoder
+        plan = plan_assembly(text_inputs["input_ids"], img_ph_token_id=self.text_tokenizer.img_ph_token_id)
         image_inputs = None
         if images is not None:
             image_inputs = self.image_tokenizer(images.to(self.dtype))                                          # :258-259
@@ -213,5 +225,5 @@ class LibraTokenizer(torch.nn.Module):
                               boi_token_id=self.image_tokenizer.boi_token_id, num_codebook=self.image_tokenizer.num_codebook,
                               max_vision_token_length=self.image_tokenizer.max_vision_token_length,
                               contiguous_ignore_signs=signs, has_image_flag=has_image_flag, truncation=truncation,
-                              max_length=max_length)
+                              max_length=max_length, plan=plan)
         return out if self.raw_output else BatchEncoding(out)

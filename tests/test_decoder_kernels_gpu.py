@@ -374,6 +374,15 @@ def test_swiglu_gather_ce(K):
     ref = F.cross_entropy(z[:, :V].float().cpu(), (tgt - 1000).clamp_min(0), reduction="none")
     ref[tgt < 0] = 0
     close(loss, ref, rel=1e-4, what="ce rows")
+    # backward: the upstream scalar as a device operand == the same scalar folded into the host coefficients (power of two: exact)
+    zt, tt = z[:, :V], tgt.cuda()
+    g_host = K.ce_rows_bwd(zt, tt, None, 1000, 0.25 * 4.0, 0.0, torch.empty(40, V, dtype=BF, device="cuda"))
+    g_dev = K.ce_rows_bwd(zt, tt, None, 1000, 0.25, 0.0, torch.empty(40, V, dtype=BF, device="cuda"),
+                          scale=torch.tensor([4.0], device="cuda"))
+    assert torch.equal(g_host, g_dev)
+    zl = z[:, :V].float().cpu().requires_grad_(True)
+    F.cross_entropy(zl, (tgt - 1000).clamp_min(0), reduction="none")[tgt >= 0].sum().backward()
+    close(g_dev, zl.grad, rel=4e-3, what="ce rows bwd")
 
 
 def test_rope_bridge_with_explicit_positions(K):
