@@ -148,6 +148,8 @@ class PackedOperands:
         with torch.no_grad():
             for k, (dst, name, tr) in enumerate(self._slices):
                 p = sd[name]
+                if p.data_ptr() == dst.data_ptr() and tr is False:
+                    continue                                  # adopted (see adopt()): the parameter IS this slice
                 key = (p.data_ptr(), p._version)
                 if force or (volatile and p.requires_grad) or self._keys.get(k) != key:
                     src = p.detach()
@@ -157,6 +159,30 @@ class PackedOperands:
             if dsts:
                 torch._foreach_copy_(dsts, srcs)          # a handful of multi-tensor launches instead of ~500 small copies / step
         return len(dsts)
+
+    def adopt(self, sd: Dict[str, torch.Tensor]) -> int:
+        """Make every parameter that fills exactly one whole-row slice of a fused operand a VIEW of that slice (`p.data = slice`, values
+        preserved): q / k / v, the low-rank A's, the bridge A's, gate / up, the unified heads.  From then on an optimizer step writes
+        the fused operand directly and refresh() has nothing to copy for them - at Libra-11B the per-forward refresh of the trainable
+        vision A stacks was ~500 small copies = 2.2 GB read + written (2.6 ms of GPU time and as much host time per step), and
+        the frozen text q|k|v / gate|up weights stop existing twice (13.5 GB).  Anything that re-points `.data` later (`.to()`, a
+        flat-buffer optimizer such as dp.FlatAdamW) simply falls back to the copying path: refresh() compares data_ptr.
+        Called by the owning model (LibraForCausalLM._refresh_packed) - a PackedOperands built on somebody else's tensors copies.
+        -> number of parameters adopted."""
+        count: Dict[str, int] = {}
+        for _, name, _ in self._slices:
+            count[name] = count.get(name, 0) + 1
+        n = 0
+        with torch.no_grad():
+            for dst, name, tr in self._slices:
+                p = sd[name]
+                if (tr is not False or count[name] != 1 or not isinstance(p, torch.nn.Parameter) or tuple(dst.shape) != tuple(p.shape)
+                        or not dst.is_contiguous() or p.dtype != dst.dtype or p.device != dst.device or p.data_ptr() == dst.data_ptr()):
+                    continue
+                dst.copy_(p.detach())
+                p.data = dst
+                n += 1
+        return n
 
     def __getitem__(self, i: int) -> dict:
         return self.layers[i]

@@ -224,6 +224,7 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         dev = sd["model.embed_tokens.weight"].device
         if self._packed is None or self._packed.device != dev:
             self._packed = DE.PackedOperands(sd, self._dims)
+            self._packed.adopt(sd)       # this model's own parameters become views of the fused operands: nothing to re-copy per step
         else:
             self._packed.refresh(sd, volatile=volatile)
         return self._packed

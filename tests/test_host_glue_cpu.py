@@ -288,6 +288,34 @@ def test_packed_operands_refresh_policy():
     assert po.refresh(sd, force=True) == n_slices
 
 
+def test_packed_operands_adopt_makes_parameters_views_of_the_fused_operands():
+    """PackedOperands.adopt (called by the owning model): every parameter that fills one whole-row slice becomes a view of it -
+    values unchanged, `.data` writes land in the fused operand without a refresh copy, and a parameter re-pointed later
+    (`.to()`, a flat-buffer optimizer) falls back to the copying refresh."""
+    from libra_amd import decoder_engine as DE
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    sd = {k[2:]: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in t.items() if k.startswith("w.")}
+    d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
+                   heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
+                   codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
+                   signal=c["contiguous_signal_size"], rank=c["bridge_rank"], down_ratio=c["vision_down_ratio"])
+    before = {k: v.detach().clone() for k, v in sd.items()}
+    po = DE.PackedOperands(sd, d)
+    n_slices = len(po._slices)
+    adopted = po.adopt(sd)
+    assert 0 < adopted < n_slices and po.adopt(sd) == 0                  # (bridge B's feed two layouts: they stay copies)
+    assert all(torch.equal(before[k], sd[k].detach()) for k in sd)
+    q, H = "model.layers.0.self_attn.q_proj.weight", c["hidden_size"]
+    assert sd[q].data_ptr() == po[0]["wqkv_ab"].data_ptr()
+    sd[q].data.add_(1.0)                                                 # an optimizer step through .data ...
+    assert torch.equal(po[0]["wqkv_ab"][:H, :H], sd[q].detach())         # ... is already in the fused operand
+    assert po.refresh(sd) == n_slices - adopted                          # only the non-adopted trainable slices are re-copied
+    sd[q].data = sd[q].data.clone()                                      # re-pointed storage: the copying path takes over
+    sd[q].data.add_(1.0)
+    assert po.refresh(sd) == n_slices - adopted + 1 and torch.equal(po[0]["wqkv_ab"][:H, :H], sd[q].detach())
+
+
 def test_row_arena_lease_follows_the_lifetime_of_the_saved_forward():
     """the arena's ownership flag was cleared only by backward(); a grad-enabled forward whose graph was
     dropped (an evaluation without no_grad, `float(model(**kw).loss)`, an exception before backward) left it set for good and
