@@ -21,7 +21,7 @@ __device__ __forceinline__ void stage_tile64(const bf16_t* __restrict__ base, lo
         int gr = row_lo + r;
         gr = gr < row_hi_excl ? gr : row_hi_excl - 1;
         const int c = (lane & 7) ^ g64(r);
-        glds16(base + (long)gr * ld + c * 8, lds_tile + (wave * 16 + j * 8) * 128);
+        glds16_off(base, (unsigned)(((long)gr * ld + c * 8) * 2), lds_tile + (wave * 16 + j * 8) * 128);   // (tile base in SGPRs + 32-bit lane offset)
     }
 }
 // byte offset of (row, 16-byte chunk)

@@ -98,10 +98,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_nt_kernel(const Gem
         char* da = smem + buf * 2 * TILE_BYTES + wave * 4096;
         const bf16_t* ga = Ap + kt * kstepA;
         const bf16_t* gb = Bp + kt * kstepB;
+        // (wave-uniform K-tile base + per-lane 32-bit byte offset: no 64-bit VALU address per piece)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(ga + srcA[j], da + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_off(ga, 2u * srcA[j], da + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(gb + srcB[j], da + TILE_BYTES + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_off(gb, 2u * srcB[j], da + TILE_BYTES + j * 1024);
     };
     stage(0, 0);
     const FragAddr fa = make_frag_addr(lane);

@@ -87,8 +87,14 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
         glds16(base + srcB[h][1], dst + 1024);
     };
     const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;       // (one address-space cast, not one per piece)
-    auto pieceA = [&](int h, int kt, int j) { glds16_at(Ap + kt * kstepA + srcA[h][j], lds0 + (unsigned)((kt & 1) * KTB + h * HB + ldst + j * 1024)); };
-    auto pieceB = [&](int h, int kt, int j) { glds16_at(Bp + kt * kstepB + srcB[h][j], lds0 + (unsigned)((kt & 1) * KTB + (2 + h) * HB + ldst + j * 1024)); };
+    // wave-uniform K-tile base in an SGPR pair + the loop-invariant per-lane byte offset: no per-piece 64-bit VALU address
+    unsigned boA[2][2], boB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { boA[h][j] = 2u * srcA[h][j]; boB[h][j] = 2u * srcB[h][j]; }
+    auto pieceA = [&](int h, int kt, int j) { glds16_off_at(Ap + kt * kstepA, boA[h][j], lds0 + (unsigned)((kt & 1) * KTB + h * HB + ldst + j * 1024)); };
+    auto pieceB = [&](int h, int kt, int j) { glds16_off_at(Bp + kt * kstepB, boB[h][j], lds0 + (unsigned)((kt & 1) * KTB + (2 + h) * HB + ldst + j * 1024)); };
 
     const FragAddr fa = make_frag_addr(lane);
     const int aoff = wr * HB;                                  // A half of this wave group

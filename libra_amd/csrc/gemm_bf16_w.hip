@@ -71,8 +71,12 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
     const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;       // (one address-space cast, not one per piece)
     const unsigned ldst = lds0 + (unsigned)(wave * 4096);                        // this wave's 4 pieces inside any unit
     // unit map: A1st / A2nd (h = 0 / 1) of K tile kt at ((kt & 1) * 2 + h) * WU, B at 4 * WU
-    auto pieceA = [&](int h, int kt, int j) { glds16_at(Ap + kt * kstepA + srcA[h][j], ldst + (unsigned)(((kt & 1) * 2 + h) * WU + j * 1024)); };
-    auto pieceB = [&](int kt, int j) { glds16_at(Bp + kt * kstepB + srcB[j], ldst + (unsigned)(4 * WU + j * 1024)); };
+    // (wave-uniform K-tile base in an SGPR pair + the loop-invariant per-lane byte offset: no per-piece 64-bit VALU address)
+    unsigned boA[2][4], boB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { boA[0][j] = 2u * srcA[0][j]; boA[1][j] = 2u * srcA[1][j]; boB[j] = 2u * srcB[j]; }
+    auto pieceA = [&](int h, int kt, int j) { glds16_off_at(Ap + kt * kstepA, boA[h][j], ldst + (unsigned)(((kt & 1) * 2 + h) * WU + j * 1024)); };
+    auto pieceB = [&](int kt, int j) { glds16_off_at(Bp + kt * kstepB, boB[j], ldst + (unsigned)(4 * WU + j * 1024)); };
 
     const FragAddr fa = make_frag_addr(lane);
     const int toA[2] = {frag_toff<AT>(lane, wr * 2), frag_toff<AT>(lane, wr * 2 + 1)};      // this wave's 64 lines inside either A unit
