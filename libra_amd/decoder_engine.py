@@ -517,13 +517,25 @@ def heads_forward(sd, d: DecDims, hidden, flag, lang_idx, vis_idx, Q: int, *, un
 
 def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, signal, labels=None, *,
             want_hidden_states: bool = False, save: bool = False, cache: Optional[KVCache] = None,
-            recompute: bool = False):
+            recompute: bool = False, inputs_embeds: Optional[torch.Tensor] = None):
     """-> dict(hidden [B,S,H], flag, lang_idx, vis_idx, z_lang [n_l,V], z_vis list of [n_v,Vv], loss or None, saved).
+    `inputs_embeds` [B,S,H] with input_ids None (LibraModel.forward, modeling_libra.py:703-716, :748-754): the decoder runs on the
+    given embeddings - no table lookup, no signal processing (upstream applies both only when it computes the embeddings itself);
+    backward() then leaves the gradient w.r.t. them in out["d_inputs_embeds"].
     `cache` (empty KVCache): prefill - every layer's K/V rows of the prompt are stored for decode_step.
     `recompute` (with save): gradient checkpointing per decoder layer (modeling_libra.py:787-797) - only each layer's
     INPUT is kept; backward() re-runs layer_forward before layer_backward (4.3 GB instead of 61 GB at B=8, S=2048)."""
-    Q, B, S = input_ids.shape
-    dev = input_ids.device
+    if (input_ids is None) == (inputs_embeds is None):
+        raise ValueError("exactly one of input_ids and inputs_embeds")
+    if input_ids is not None:
+        Q, B, S = input_ids.shape
+        dev = input_ids.device
+    else:
+        if inputs_embeds.dim() != 3 or inputs_embeds.shape[2] != d.hidden or tuple(inputs_embeds.shape[:2]) != tuple(vision_indices.shape):
+            raise ValueError(f"inputs_embeds must be [B, S, {d.hidden}] matching vision_indices {tuple(vision_indices.shape)}")
+        if cache is not None:
+            raise NotImplementedError("inputs_embeds with a KV cache (generation feeds token ids)")
+        Q, (B, S), dev = d.codebooks, inputs_embeds.shape[:2], inputs_embeds.device
     if labels is not None and labels.dtype != torch.int64:
         raise TypeError(f"labels must be int64 (torch.long), got {labels.dtype}")
     if save:
@@ -550,10 +562,16 @@ def forward(sd, packed, d: DecDims, input_ids, attention_mask, vision_indices, s
             cache.run2d = pos2[:, -1, 0].long() - row
     # the loss's per-codebook target counts (shifted labels >= 0) are known before the first layer: read with the id check
     cnts = [(labels[q][:, 1:] >= 0).sum().clamp_min(1) for q in range(Q)] if labels is not None else []
-    counts = check_ids(input_ids, flag.view(B, S).bool(), d, also=cnts)
+    if input_ids is not None:
+        counts = check_ids(input_ids, flag.view(B, S).bool(), d, also=cnts)
+    else:
+        counts = torch.stack(cnts).tolist() if cnts else []                        # (no ids to validate: the read carries the counts only)
     cos, sin = rope_tables(d.hidden // d.heads, rope_rows(d, S), dev)
     saved = dict(layers=[], emb={}, recompute=bool(recompute)) if save else None
-    x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None, vision_indices=vision_indices)
+    if input_ids is not None:
+        x = embed(sd, d, input_ids, flag, lang_idx, vis_idx, signal, saved["emb"] if save else None, vision_indices=vision_indices)
+    else:
+        x = inputs_embeds.detach().reshape(B * S, d.hidden).to(BF16).contiguous()
     hs = [x] if want_hidden_states else None
     # per-layer saved row buffers come from the model's arena unless an earlier saved forward still waits for its backward
     global _ARENA, _ARENA_PREFIX
@@ -953,6 +971,11 @@ def backward(sd, packed, d: DecDims, out, want, gscale=1.0):
         K.errors.poll_async(dev)               # sticky device error word of the bounded in-kernel waits: read back without a stall
 
     # ---- embeddings (modeling_libra.py:625-661)
+    if sv["input_ids"] is None:                # the forward ran on caller-provided embeddings: their gradient is the result
+        out["d_inputs_embeds"] = dx.view(B, S, H)
+        _zero_fill(g, groups[-1], sd)
+        dp.emit_new(g, emitted)
+        return g
     e = sv["emb"]
     proc = "model.vision_contiguous_signal_processor.weight"
     if not d.concat and "sig_all" in e and w(proc):         # x += processor(signal) on every row: dW = dx^T signal

@@ -268,15 +268,21 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                 use_cache: Optional[bool] = None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 contiguous_signal: Optional[torch.Tensor] = None, vision_indices: Optional[torch.LongTensor] = None,
                 past_hidden_states=None, past_vision_flag=None, max_cache_len: Optional[int] = None):
-        if input_ids is None or vision_indices is None:
-            raise ValueError("You have to specify input_ids [Q,B,S] and vision_indices [B,S]")
-        if inputs_embeds is not None:
-            raise NotImplementedError("inputs_embeds: the embedding gather is part of the fused path")
+        if input_ids is not None and inputs_embeds is not None:                        # modeling_libra.py:703-704
+            raise ValueError("You cannot specify both decoder_input_ids and decoder_inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is None:                                # :715-716
+            raise ValueError("You have to specify either decoder_input_ids or decoder_inputs_embeds")
+        if vision_indices is None:
+            raise ValueError("You have to specify vision_indices [B,S] (the modality of every position, :1116)")
         if output_attentions:
             raise NotImplementedError("attention maps are not produced by the fused kernels")
-        if not input_ids.is_cuda:
+        lead = input_ids if input_ids is not None else inputs_embeds
+        if not lead.is_cuda:
             raise RuntimeError("libra_amd LibraForCausalLM runs on MI355X only; got CPU tensors (no CPU fallback)")
-        assert len(input_ids) == self.config.vision_codebook_num                      # :705
+        if input_ids is not None:
+            assert len(input_ids) == self.config.vision_codebook_num                  # :705
+        elif past_key_values is not None or use_cache:
+            raise NotImplementedError("inputs_embeds with use_cache / past_key_values (generation feeds token ids)")
         if past_key_values is not None or use_cache:
             if labels is not None:
                 raise ValueError("labels with use_cache / past_key_values: the cached path is inference only (:1142)")
@@ -284,15 +290,15 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
                                         max_cache_len)
         if position_ids is not None:
             raise NotImplementedError("custom position_ids on the training path (positions are arange(S), :736-739)")
-        Q, B, S = input_ids.shape
+        B, S = lead.shape[1:3] if input_ids is not None else lead.shape[:2]
         if attention_mask is None:
-            attention_mask = torch.ones((B, S), dtype=torch.bool, device=input_ids.device)
+            attention_mask = torch.ones((B, S), dtype=torch.bool, device=lead.device)
         names, params = self._named_params()
         holder = {}
         # (grad mode is always off inside Function.forward and needs_input_grad ignores no_grad(): read it here)
         holder["grad_on"] = torch.is_grad_enabled()
         loss = _LibraFunction.apply(self, holder, names, input_ids, attention_mask, vision_indices, contiguous_signal, labels,
-                                    bool(output_hidden_states), *params)
+                                    bool(output_hidden_states), inputs_embeds, *params)
         out = holder["out"]
         if labels is None:
             loss = None
@@ -443,18 +449,19 @@ class _LibraFunction(torch.autograd.Function):
     freeze policy, modeling_libra.py:1342-1369, is expressed through requires_grad exactly as upstream)."""
 
     @staticmethod
-    def forward(ctx, model, holder, names, input_ids, attention_mask, vision_indices, signal, labels, want_hs, *params):
+    def forward(ctx, model, holder, names, input_ids, attention_mask, vision_indices, signal, labels, want_hs, inputs_embeds, *params):
         sd = dict(zip(names, params))
         packed = model._refresh_packed(sd)
-        need = labels is not None and holder.get("grad_on", True) and any(ctx.needs_input_grad[9:])
+        need = labels is not None and holder.get("grad_on", True) and any(ctx.needs_input_grad[9:])     # ([9] = inputs_embeds)
         out = DE.forward(sd, packed, model._dims, input_ids, attention_mask, vision_indices, signal, labels,
                          want_hidden_states=want_hs, save=need,
-                         recompute=need and model.model.gradient_checkpointing and model.training)
+                         recompute=need and model.model.gradient_checkpointing and model.training, inputs_embeds=inputs_embeds)
         holder["out"] = out
         ctx.model, ctx.sd, ctx.out, ctx.names = model, sd, out, names
-        ctx.want = {n for n, ng in zip(names, ctx.needs_input_grad[9:]) if ng}
+        ctx.want = {n for n, ng in zip(names, ctx.needs_input_grad[10:]) if ng}
+        ctx.embeds_dtype = inputs_embeds.dtype if inputs_embeds is not None and ctx.needs_input_grad[9] else None
         loss = out["loss"]
-        return loss if loss is not None else torch.zeros((), device=input_ids.device)
+        return loss if loss is not None else torch.zeros((), device=vision_indices.device)
 
     @staticmethod
     def backward(ctx, gloss):
@@ -471,7 +478,9 @@ class _LibraFunction(torch.autograd.Function):
                 gr = gr.reshape(ctx.sd[n].shape)
             res.append(gr)
         ctx.out["saved"] = None
-        return (None,) * 9 + tuple(res)
+        d_emb = ctx.out.pop("d_inputs_embeds", None)
+        d_emb = d_emb.to(ctx.embeds_dtype) if (d_emb is not None and ctx.embeds_dtype is not None) else None
+        return (None,) * 9 + (d_emb,) + tuple(res)
 
 
 def _cfg_get(cfg, key, default=None):

@@ -48,6 +48,47 @@ def test_gradient_checkpointing_recompute_is_bit_identical():
         assert m(**kw)._engine_out["saved"] is None
 
 
+def test_inputs_embeds_runs_the_decoder_on_given_embeddings():
+    """LibraModel.forward's `inputs_embeds` branch (modeling_libra.py:703-716, :748-754): no table lookup and no signal processing -
+    the decoder runs on the given [B, S, H].  Fed with the embeddings the token path itself computes (hidden_states[0]), loss,
+    logits and every decoder gradient are the token path's bit for bit; the gradient w.r.t. the embeddings, scattered by token id,
+    IS the text embedding table's gradient of the token path; both / neither input raise as upstream."""
+    m, kw, t, _ = _tiny()
+    out = m(**kw, output_hidden_states=True)
+    out.loss.backward()
+    plain = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    logits = out.logits
+    m.zero_grad(set_to_none=True)
+    E = out.hidden_states[0].detach().clone().requires_grad_(True)
+    kw2 = {k: v for k, v in kw.items() if k not in ("input_ids", "contiguous_signal")}
+    out2 = m(inputs_embeds=E, **kw2)
+    assert torch.equal(out2.loss, out.loss) and torch.equal(out2.logits, logits)
+    out2.loss.backward()
+    emb_stage = ("embed_tokens", "vision_embed_tokens", "vision_contiguous_signal_processor", "vision_signal_norm", "vision_position_embedding")
+    checked = 0
+    for n, p in m.named_parameters():
+        if n in plain and not any(k in n for k in emb_stage):
+            assert torch.equal(p.grad, plain[n]), n
+            checked += 1
+    assert checked > 20
+    assert E.grad is not None and E.grad.shape == E.shape and bool(torch.isfinite(E.grad.float()).all())
+    ids0 = kw["input_ids"][0].reshape(-1)
+    lang = (kw["vision_indices"].reshape(-1) >= m.config.max_vision_token_length)
+    acc = torch.zeros(m.model.embed_tokens.weight.shape, dtype=torch.float32, device="cuda")
+    acc.index_add_(0, ids0[lang], E.grad.reshape(-1, E.shape[-1])[lang].float())
+    assert torch.equal(acc.to(BF), plain["model.embed_tokens.weight"])
+    m.eval()
+    with torch.no_grad():
+        ev = m(inputs_embeds=E.detach(), **{k: v for k, v in kw2.items() if k != "labels"})
+    assert ev.loss is None and torch.equal(ev.logits, logits)
+    with pytest.raises(ValueError, match="both"):
+        m(inputs_embeds=E.detach(), **kw)
+    with pytest.raises(ValueError, match="either"):
+        m(**kw2)
+    with pytest.raises(NotImplementedError):
+        m(inputs_embeds=E.detach(), use_cache=True, **{k: v for k, v in kw2.items() if k != "labels"})
+
+
 def test_logits_lazy_in_training_and_eager_in_eval():
     """`.logits` [Q,B,S,V+514] (modeling_libra.py:1180-1188): eager without autograd (Trainer.prediction_step reads it from
     items()), built on first access in a training step; same values either way and equal to the reference fixture's pattern."""
