@@ -535,3 +535,37 @@ def test_save_pretrained_from_pretrained_round_trip_keeps_the_reference_key_set(
     import json
     with open(os.path.join(tmp_path, "config.json")) as f:
         assert json.load(f)["model_type"] == m.config.model_type
+
+
+def test_gemm_tile_order_model_is_a_bijection_with_compact_xcd_patches():
+    """hip_common.hpp `tile_order<XR,XC,WR,WC>` restated in Python (the device function is exercised by every GEMM parity test on
+    ragged grids; this pins the INTENT): workgroup id -> output tile is a bijection for any grid, and in a full wave of workgroups
+    XCD x (= id % 8) owns one XR x XC sub-patch of one (XR*WR) x (XC*WC) patch."""
+    def xcd_remap(bid, nblk):
+        q, r = nblk >> 3, nblk & 7
+        xcd, j = bid & 7, bid >> 3
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + j
+
+    def order(bid, tm, tn, XR, XC, WR, WC):
+        XT = XR * XC; WT = XT * 8; GR = XR * WR
+        nt = tm * tn; full = nt // WT * WT
+        u = (bid // WT) * WT + (bid & 7) * XT + ((bid % WT) >> 3) if bid < full else full + xcd_remap(bid - full, nt - full)
+        gw = GR * tn; g = u // gw; v = u - g * gw
+        r0 = g * GR; gsz = min(GR, tm - r0)
+        cb = v // (gsz * XC); v -= cb * gsz * XC
+        c0 = cb * XC; csz = min(XC, tn - c0)
+        rb = v // (XR * csz); v -= rb * XR * csz
+        rr0 = rb * XR; rsz = min(XR, gsz - rr0)
+        return r0 + rr0 + v % rsz, c0 + v // rsz
+
+    for cfg in ((4, 8, 4, 2), (4, 16, 4, 2), (8, 8, 4, 2)):          # the 256^2, 256x128 and 128^2 kernels' instantiations
+        for tm in (1, 2, 3, 5, 16, 19, 37, 46):
+            for tn in (1, 3, 4, 8, 16, 17, 43, 86, 172):
+                seen = {order(b, tm, tn, *cfg) for b in range(tm * tn)}
+                assert len(seen) == tm * tn and all(0 <= a < tm and 0 <= c < tn for a, c in seen), (cfg, tm, tn)
+    rows = {}
+    for b in range(256):                                               # first wave of the 11760 x 22016 text GEMM (46 x 86 tiles)
+        rows.setdefault(b & 7, []).append(order(b, 46, 86, 4, 8, 4, 2))
+    for x, tiles in rows.items():
+        ms, ns = sorted({t[0] for t in tiles}), sorted({t[1] for t in tiles})
+        assert len(tiles) == 32 and ms == list(range(4 * (x % 4), 4 * (x % 4) + 4)) and ns == list(range(8 * (x // 4), 8 * (x // 4) + 8))
