@@ -166,7 +166,9 @@ class PackedOperands:
         the fused operand directly and refresh() has nothing to copy for them - at Libra-11B the per-forward refresh of the trainable
         vision A stacks was ~500 small copies = 2.2 GB read + written (2.6 ms of GPU time and as much host time per step), and
         the frozen text q|k|v / gate|up weights stop existing twice (13.5 GB).  Anything that re-points `.data` later (`.to()`, a
-        flat-buffer optimizer such as dp.FlatAdamW) simply falls back to the copying path: refresh() compares data_ptr.
+        flat-buffer optimizer such as dp.FlatAdamW) simply falls back to the copying path: refresh() compares data_ptr.  A parameter
+        that ALREADY is a view of a larger storage when adopt() runs (the optimizer was built before the model's first forward)
+        is left alone for the same reason: its owner's buffer is the truth.
         Called by the owning model (LibraForCausalLM._refresh_packed) - a PackedOperands built on somebody else's tensors copies.
         -> number of parameters adopted."""
         count: Dict[str, int] = {}
@@ -178,6 +180,12 @@ class PackedOperands:
                 p = sd[name]
                 if (tr is not False or count[name] != 1 or not isinstance(p, torch.nn.Parameter) or tuple(dst.shape) != tuple(p.shape)
                         or not dst.is_contiguous() or p.dtype != dst.dtype or p.device != dst.device or p.data_ptr() == dst.data_ptr()):
+                    continue
+                # A parameter that already views a LARGER storage belongs to somebody's flat buffer (dp.FlatAdamW binds `p.data`
+                # to its `pf` buckets, ZeRO / FSDP style wrappers do the same): its owner keeps writing that buffer, so re-pointing
+                # the parameter here would silently detach it from the optimizer.  It stays a copy refreshed per forward.
+                # (dp.FlatAdamW also marks what it owns - a bucket of ONE parameter is exactly that parameter's size)
+                if getattr(p, "_libra_flat_owner", None) is not None or p.untyped_storage().nbytes() != p.numel() * p.element_size():
                     continue
                 dst.copy_(p.detach())
                 p.data = dst

@@ -351,6 +351,7 @@ class FlatAdamW:
                     p = params[n]
                     pf[off:off + k].copy_(p.detach().reshape(-1))
                     p.data = pf[off:off + k].view(shape)     # (packed operand copies are refreshed every forward: safe)
+                    p._libra_flat_owner = id(self)           # PackedOperands.adopt() must not re-point it to a fused operand
                 lo, hi = b.shard if self.shard else (0, b.flat.numel())
                 master = pf[lo:hi].float()
                 segs = []                                    # (start, end, weight decay) inside [lo, hi), param-aligned
@@ -374,6 +375,12 @@ class FlatAdamW:
     def step(self, lr: Optional[float] = None):
         """Update from the buckets' current (exchanged) gradients.  Call after `buckets.finish()`; with mode zero1 the
         per-bucket all-gathers of the new parameters overlap the next bucket's update."""
+        dev = self.buckets.device
+        if torch.device(dev).type == "cuda":
+            # a bounded in-kernel wait of the attention backward that ran out leaves the gradients undefined and sets a device
+            # error word the backward polled asynchronously: never apply such gradients (one host wait, only if a poll is queued)
+            from . import kernels as K
+            K.errors.check(dev, wait=True, pending_only=True)
         self.t += 1
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
@@ -414,13 +421,19 @@ class FlatAdamW:
     @torch.no_grad()
     def load_state_dict(self, sd: dict, *, strict_hyper: bool = False) -> None:
         """Resume: restores step count, master weights and moments, and re-derives the bf16 parameters from the masters (so a
-        resumed run continues from the fp32 values, not from bf16-rounded weights with zero moments).  The shard must come from the
-        same world size / rank / sharding mode.  Hyper-parameters are the CONSTRUCTOR's (as torch.optim lets a resumed run change
+        resumed run continues from the fp32 values, not from bf16-rounded weights with zero moments).  A ZeRO-1 shard must come from the
+        same world size / rank; un-sharded state loads on any rank of any world size.  Hyper-parameters are the CONSTRUCTOR's (as torch.optim lets a resumed run change
         lr or clipping), but a difference from the saved ones is never silent: a warning, or ValueError with strict_hyper."""
-        for k, mine in (("world", self.buckets.world), ("rank", self.buckets.rank), ("sharded", self.shard)):
-            if k in sd and sd[k] != mine:
-                raise ValueError(f"FlatAdamW.load_state_dict: saved {k} = {sd[k]!r}, this optimizer has {mine!r} (a ZeRO-1 shard "
-                                 "can only be resumed by the same rank of the same world size and mode)")
+        # the sharding MODE must match; world size and rank only matter when the state is a shard (un-sharded state is the same on
+        # every rank: rank 0 saves, every rank loads, and a resume on another world size is legitimate)
+        sharded = bool(sd.get("sharded", self.shard))
+        if sharded != self.shard:
+            raise ValueError(f"FlatAdamW.load_state_dict: saved sharded = {sharded!r}, this optimizer has {self.shard!r}")
+        if sharded:
+            for k, mine in (("world", self.buckets.world), ("rank", self.buckets.rank)):
+                if k in sd and sd[k] != mine:
+                    raise ValueError(f"FlatAdamW.load_state_dict: saved {k} = {sd[k]!r}, this optimizer has {mine!r} (a ZeRO-1 "
+                                     "shard can only be resumed by the same rank of the same world size)")
         mine_h = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
                   "max_grad_norm": self.max_grad_norm}
         saved_h = sd.get("hyper") or {}

@@ -141,10 +141,16 @@ class DeviceErrors:
         st["event"].record()
         st["pending"] = True
 
-    def check(self, device, wait: bool = False) -> None:
+    def check(self, device, wait: bool = False, pending_only: bool = False) -> None:
+        """wait=False: raise only if an earlier poll has already landed.  wait=True: poll now and wait for it (a host
+        synchronisation).  pending_only: wait only when a backward has queued a poll since the last check - what an optimizer
+        calls before it applies that backward's gradients (dp.FlatAdamW.step)."""
         st = self._state(device)
+        if wait and pending_only and not st["pending"]:
+            return
         if wait:
-            self.poll_async(device)
+            if not (pending_only and st["pending"]):
+                self.poll_async(device)
             st["event"].synchronize()
         elif not st["pending"] or not st["event"].query():
             return

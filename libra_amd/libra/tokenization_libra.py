@@ -234,7 +234,8 @@ class LibraTokenizer(torch.nn.Module):
             logging.warning("The input token length ecceeds the max number that the model can hold. This may cause "
                             "performance degradation or OOM.")
         # placeholder positions first (the assembly's one host read), THEN the image encoder: the host does not wait for the encoder
-        plan = plan_assembly(text_inputs["input_ids"], img_ph_token_id=self.text_tokenizer.img_ph_token_id)
+        # (text-only batch: no plan, no host read - assemble_inputs has nothing to place)
+        plan = None if images is None else plan_assembly(text_inputs["input_ids"], img_ph_token_id=self.text_tokenizer.img_ph_token_id)
         image_inputs = None
         if images is not None:
             image_inputs = self.image_tokenizer(images.to(self.dtype))                                          # :258-259

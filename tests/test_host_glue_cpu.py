@@ -316,6 +316,68 @@ def test_packed_operands_adopt_makes_parameters_views_of_the_fused_operands():
     assert po.refresh(sd) == n_slices - adopted + 1 and torch.equal(po[0]["wqkv_ab"][:H, :H], sd[q].detach())
 
 
+def test_adopt_leaves_parameters_of_a_flat_buffer_optimizer_alone():
+    """dp.FlatAdamW binds every trainable `p.data` to a view of its flat `pf` buckets when it is BUILT - before the
+    model's first forward, where PackedOperands.adopt() runs.  adopt() used to re-point those parameters to the fused operands:
+    opt.step() kept writing `pf`, which nothing read any more, and the adopted trainable slices never trained.  A parameter
+    that already views a larger storage now stays where it is (refresh() copies it per forward), the frozen ones are still adopted,
+    and an optimizer step reaches the fused operand through the next refresh."""
+    from libra_amd import decoder_engine as DE
+    from libra_amd import dp
+    from helpers import torch_adamw_update, torch_sumsq
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    sd = {k[2:]: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in t.items() if k.startswith("w.")}
+    for k, p in sd.items():
+        p.requires_grad_("vision" in k)                                  # the pretrain freeze policy
+    d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
+                   heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
+                   codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
+                   signal=c["contiguous_signal_size"], rank=c["bridge_rank"], down_ratio=c["vision_down_ratio"])
+    named = [(n, p) for n, p in sd.items() if p.requires_grad and n != "vision_hidden_placeholder"]
+    st = dp.GradBuckets(named, bucket_bytes=1 << 16)
+    opt = dp.FlatAdamW(st, named, lr=1e-2, update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+
+    def inside_pf(p):
+        return any(pf.data_ptr() <= p.data_ptr() < pf.data_ptr() + pf.numel() * pf.element_size() for pf in opt.pflat)
+    assert all(inside_pf(p) for _, p in named)
+    po = DE.PackedOperands(sd, d)                                        # the model's first forward: pack + adopt
+    adopted = po.adopt(sd)
+    assert adopted > 0                                                   # the frozen text q / k / v / gate / up still become views
+    assert all(inside_pf(p) for _, p in named), "adopt() detached a trainable parameter from the optimizer's flat buffers"
+    a = "model.layers.0.self_attn.vision_q_proj.weight_A"
+    r = sd[a].shape[0]
+    before = {n: p.detach().clone() for n, p in named}
+    for n, _ in named:                                                   # a gradient of ones in every bucket slot
+        st.view(n).fill_(1.0)
+    opt.step()
+    assert all(not torch.equal(before[n], p.detach()) for n, p in named), "a trainable parameter did not move"
+    assert not torch.equal(po[0]["aqkv_ab"][:r], sd[a].detach())         # the fused operand is a copy: stale until ...
+    assert po.refresh(sd) > 0 and torch.equal(po[0]["aqkv_ab"][:r], sd[a].detach())     # ... the per-forward refresh
+
+
+def test_flat_adamw_unsharded_state_loads_on_any_rank_sharded_state_does_not():
+    """un-sharded optimizer state is identical on every rank (rank 0 saves, every rank loads, a resume on another
+    world size is fine); only a ZeRO-1 SHARD is tied to (world, rank).  The sharding mode itself must always match."""
+    from libra_amd import dp
+    from helpers import torch_adamw_update, torch_sumsq
+    ps = [("a.weight", torch.nn.Parameter(torch.randn(8, 16).to(torch.bfloat16))), ("b.weight", torch.nn.Parameter(torch.randn(16).to(torch.bfloat16)))]
+    st = dp.GradBuckets(ps, bucket_bytes=1 << 12)
+    opt = dp.FlatAdamW(st, ps, lr=1e-2, update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    for n, _ in ps:
+        st.view(n).fill_(0.5)
+    opt.step()
+    sd = opt.state_dict()
+    assert sd["sharded"] is False
+    sd_other = dict(sd, world=8, rank=3)                                 # saved by rank 3 of 8 in allreduce mode
+    ps2 = [(n, torch.nn.Parameter(torch.zeros_like(p))) for n, p in ps]
+    opt2 = dp.FlatAdamW(dp.GradBuckets(ps2, bucket_bytes=1 << 12), ps2, lr=1e-2, update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    opt2.load_state_dict(sd_other)
+    assert opt2.t == 1 and all(torch.equal(p.detach(), q.detach()) for (_, p), (_, q) in zip(ps, ps2))
+    with pytest.raises(ValueError, match="sharded"):
+        opt2.load_state_dict(dict(sd, sharded=True))
+
+
 def test_row_arena_lease_follows_the_lifetime_of_the_saved_forward():
     """the arena's ownership flag was cleared only by backward(); a grad-enabled forward whose graph was
     dropped (an evaluation without no_grad, `float(model(**kw).loss)`, an exception before backward) left it set for good and
