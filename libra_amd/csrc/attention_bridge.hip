@@ -6,59 +6,64 @@
 // where m is the per-token modality flag.  The reference evaluates this with TWO full QK^T and TWO full PV
 // products and ~6 materialised [B,H,S,S] tensors (its own "TODO: make it more efficient", :288).  Here the
 // caller provides the four operands K_same = rope(k), K_cross = rope(k + kb), V_same = v, V_cross = v + vb
-// (libra_rope_bridge) and this kernel streams 32-key tiles; a tile pair whose queries and keys are all of one
-// modality combination (the overwhelmingly common case: one contiguous 578-token image span per sequence)
-// loads and multiplies only ONE variant; only modality-boundary tiles pay for both, selected per element.
+// (libra_rope_bridge) and a workgroup of 8 waves x 32 query rows streams 64-key tiles through LDS.
 //
-// Structure = the ViT kernel's transposed scheme (S^T = K Q^T, O^T = V^T P^T with P^T fed straight from the
-// accumulator registers), plus: V tiles are staged row-major as they lie in HBM and read with the LDS
-// transpose load (ds_read_b64_tr_b16) — no V^T copy exists; keys beyond the causal diagonal or the
-// sequence's valid length are masked; work-groups are ordered heaviest-first (causal imbalance).
+// Round-5 structure ("two wave groups half a tile apart").  Rounds 2-4 ran the 8 waves in lock step (one barrier per tile):
+// on every SIMD both resident waves multiplied at the same time and both did their softmax at the same time, so the matrix
+// pipe idled through every softmax (23.7 % busy, 10.3 VALU + 6 SALU per MFMA by PMC) whatever the staging primitive,
+// occupancy shape or fragment schedule was (six structures within +-5 %).  Now:
+//   * the work list of a workgroup is a list of UNITS = (key tile, operand variant pass).  A wave whose 32 rows meet keys of
+//     one modality combination only - the overwhelmingly common case - has ONE unit per tile; only waves that really
+//     straddle a modality boundary visit a tile twice (same-variant pass, cross-variant pass: disjoint (row, key) sets are
+//     two valid online-softmax steps).  A unit is skipped, PLAIN (no per-element test of any kind: interior tile, one
+//     variant) or MASKED (causal diagonal / padding / modality selected by a per-lane 64-bit key mask) - decided once per
+//     (wave, unit) in the prologue, lane-parallel, and kept in two registers (v_readlane per unit: no loads, no mask code
+//     and ~0 SALU in the steady state);
+//   * a unit is two phases: SM (online softmax of S_u: VALU only) and M = [O += V_u^T P_u ; S_{u+1} = K_{u+1} Q^T]
+//     (32 MFMAs + their LDS fragment reads, software-pipelined one step ahead, fragment addresses = lane constant + immediate);
+//   * waves 0-3 and waves 4-7 (one of each per SIMD) run this sequence ONE PHASE APART (the second group passes one extra
+//     s_barrier at the start): on every SIMD one wave owns the matrix pipe while its partner does its softmax on the VALU;
+//   * K/V tiles arrive by direct-to-LDS loads into a 2-slot K ring and a 2-slot V ring (slot = both variants): stage
+//     (V_{t+1}, K_{t+2}) is requested in the phase after the last read of the slots it overwrites and waited for (vmcnt(0) by
+//     every wave, then the phase barrier) one phase before its first read - two phases in flight, nothing else ever waits.
 #include <atomic>
+#include <type_traits>
 #include "hip_common.hpp"
-#include "gemm_tiles.hpp"
 #include "attention_bridge_args.hpp"
 #include "../../include/libra_hip.h"
+
+#ifndef LIBRA_ATTN_PRIO
+#define LIBRA_ATTN_PRIO 1
+#endif
 
 namespace libra {
 
 constexpr int BD = 128;            // head dim
 constexpr int BQ = 256;            // query rows per workgroup (8 waves x 32)
 constexpr int BKV = 64;            // keys per tile (two 32-key halves)
-constexpr int VAR_BYTES = 2 * BKV * BD * 2;     // one variant: K tile (16 KiB) + V tile (16 KiB)
-constexpr int STAGE_BYTES = 2 * VAR_BYTES;      // same + cross
-constexpr int BR_LDS = 2 * STAGE_BYTES + 1024;  // double buffered + key-modality masks
+constexpr int TILE_B = BKV * BD * 2;          // one operand tile, 16 KiB
+constexpr int SLOT_B = 2 * TILE_B;            // ring slot: same variant | cross variant
+constexpr int KRING = 0;                      // 2 slots
+constexpr int VRING = 2 * SLOT_B;             // 2 slots
+constexpr int MASK_OFF = 4 * SLOT_B;          // key-modality words of the sequence (<= 130 words; 1 KiB reserved)
+constexpr int BLK_OFF = MASK_OFF + 1024;      // block-level tile sets (6 words)
+constexpr int TAB_OFF = BLK_OFF + 64;         // per-wave unit tables: 8 x 128 x 2 B
+constexpr int BR_LDS = TAB_OFF + 8 * 256;
 
 // K tile image: four N-type [32 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 4 KiB each, ordered
 //               (key half, d half).  V tile image: T-type [64 keys][128 d] (256-byte rows, chunk ^ ((row&3)<<2)), 16 KiB.
-__device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ kp, unsigned ldk_b, const bf16_t* __restrict__ vp,
-                                         unsigned ldv_b, int key0, int S, char* dst, int wave, int lane) {
-    // (kp, vp: wave-uniform sequence/head bases; ld*_b: row strides in bytes; per-lane part is a 32-bit byte offset)
-    // K: 16 pieces of 1 KiB (8 rows x 128 B); piece pc -> sub-tile pc>>2, rows 8*(pc&3)..; wave w takes pieces 2w, 2w+1
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pc = wave * 2 + j;
-        const int st = pc >> 2, r = (pc & 3) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int key = key0 + (st >> 1) * 32 + r; key = key < S ? key : S - 1;
-        glds16_off(kp, (unsigned)key * ldk_b + (unsigned)((st & 1) * 128 + c * 16), dst + pc * 1024);
-    }
-    // V: 16 pieces of 1 KiB (4 rows x 256 B); wave w takes pieces 2w, 2w+1
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pc = wave * 2 + j;
-        const int r = pc * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ ((r & 3) << 2);
-        int key = key0 + r; key = key < S ? key : S - 1;
-        glds16_off(vp, (unsigned)key * ldv_b + (unsigned)(c * 16), dst + 16384 + pc * 1024);
-    }
-}
+// Unit table entry: bits 0-1 mode (0 skip, 1 plain, 2 masked), bit 2 operand variant (1 = cross), bit 3 last unit of its tile,
+//                   bits 4.. key tile.
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 bits_below(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
 
-__global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArgs p) {
+__global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* kmask = (unsigned*)(smem + 2 * STAGE_BYTES);        // per 32 keys: bit j = key j is a vision token
+    unsigned* kmask = (unsigned*)(smem + MASK_OFF);               // per 32 keys: bit j = key j is a vision token
+    unsigned* blk = (unsigned*)(smem + BLK_OFF);                  // [0,1] tiles with a second pass, [2,3] same needed, [4,5] cross needed
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD: one of each group
     const int fk = lane >> 5, l31 = lane & 31;
 
     const int nblk = p.B * p.H * p.n_qt;
@@ -74,48 +79,133 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
     const bool active = q0w < S;
     int q = q0w + l31;
     q = q < S ? q : S - 1;
-
-    // ---- every per-lane global operand of the prologue is REQUESTED before the first wait: the query's modality byte and its Q
-    // fragments (lane (q = l31, half fk) holds Q[q][16*ks + 8*fk .. +8], ks = 0..7) ride the same memory round trip as the flag
-    // bytes of the mask pass (one workgroup per CU: nothing else covers a prologue's serial round trips - there were three)
-    // (the first K / V tile goes out first of all, BOTH variants: which of them the tile needs is only known after the mask pass
-    //  and two barriers - one more 32 KiB per workgroup buys the loop's first wait a head start of a full round trip)
-    {
-        const bf16_t* ks0 = p.k_same + tok0 * p.ldk + h * BD;
-        const bf16_t* kc0 = p.k_cross + tok0 * p.ldkc + h * BD;
-        const bf16_t* vs0 = p.v_same + tok0 * p.ldv + h * BD;
-        const bf16_t* vc0 = p.v_cross + tok0 * p.ldvc + h * BD;
-        stage_kv(ks0, (unsigned)p.ldk * 2u, vs0, (unsigned)p.ldv * 2u, 0, S, smem, wave, lane);
-        stage_kv(kc0, (unsigned)p.ldkc * 2u, vc0, (unsigned)p.ldvc * 2u, 0, S, smem + VAR_BYTES, wave, lane);
-    }
-    const int q_vis_raw = p.flag[tok0 + q];
-    bf16x8 qf[8];
-    {
-        const bf16_t* qp = p.q + (tok0 + q) * p.ldq + h * BD + fk * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
-    // ---- key-modality masks of this sequence into LDS (ballot over 32 flags) ----
-    modality_masks(p.flag + tok0, S, kmask, tid, 512);
-    const bool q_vis = q_vis_raw != 0;
-    // block-level query modality presence (for staging decisions all waves must agree on)
-    int* qpres = (int*)(kmask + 192);        // all LDS lives in the one dynamic array (a second __shared__ object
-    if (tid < 2) qpres[tid] = 0;             // would make hipcc drain the direct-to-LDS queue before every ds_read)
-    __syncthreads();
-    {
-        const bool valid = (q0w + l31) < S && fk == 0;
-        if (__ballot(valid && q_vis)) if (lane == 0) atomicOr(&qpres[1], 1);
-        if (__ballot(valid && !q_vis)) if (lane == 0) atomicOr(&qpres[0], 1);
-    }
-    __syncthreads();
-    const bool blkL = __builtin_amdgcn_readfirstlane(qpres[0]) != 0, blkV = __builtin_amdgcn_readfirstlane(qpres[1]) != 0;
-    const bool wV = __ballot(q_vis && (q0w + l31) < S) != 0;        // this wave's query modalities
-    const bool wL = __ballot(!q_vis && (q0w + l31) < S) != 0;
+    // causal: keys 0 .. min(S, (qt+1)*BQ) - 1
+    int kend = (qt + 1) * BQ; kend = kend < S ? kend : S;
+    const int nkt = (kend + BKV - 1) / BKV;                        // <= 64 (S <= 4096)
 
     const bf16_t* ks_base = p.k_same + tok0 * p.ldk + h * BD;
     const bf16_t* kc_base = p.k_cross + tok0 * p.ldkc + h * BD;
     const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * BD;
     const bf16_t* vc_base = p.v_cross + tok0 * p.ldvc + h * BD;
+    const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;
+
+    // ---- direct-to-LDS pieces.  A 16-KiB tile is 16 pieces of 1 KiB; wave w moves pieces 2w, 2w+1 of every tile.
+    // K piece pc -> sub-tile pc>>2, rows 8*(pc&3)..+7 (8 rows x 128 B); V piece pc -> rows 4*pc..+3 (4 rows x 256 B)
+    const int stK = (wave * 2) >> 2;
+    const int rK = ((wave * 2) & 3) * 8 + (lane >> 3);             // row inside the sub-tile (piece 1: + 8)
+    const int rowK = (stK >> 1) * 32 + rK;                         // key row inside the tile
+    const unsigned colK0 = (unsigned)((stK & 1) * 128 + (((lane & 7) ^ ((rK >> 1) & 7)) << 4));
+    const unsigned colK1 = colK0 ^ 64u;                            // row + 8 flips bit 2 of the chunk swizzle
+    const int rV = wave * 8 + (lane >> 4);                         // (piece 1: + 4, same chunk)
+    const unsigned colV = (unsigned)(((lane & 15) ^ ((rV & 3) << 2)) << 4);
+    // piece (operand, variant, j) of key tile t: rows past the end of the sequence are clamped (masked later)
+    auto piece_t = [&](const bool isK, const int var, const int j, const int t) {
+        const int lim = S - 1 - t * BKV;
+        int row = isK ? rowK + 8 * j : rV + 4 * j;
+        row = row < lim ? row : lim;
+        const long ld = isK ? (var ? p.ldkc : p.ldk) : (var ? p.ldvc : p.ldv);
+        const bf16_t* base = (isK ? (var ? kc_base : ks_base) : (var ? vc_base : vs_base)) + (long)t * BKV * ld;
+        const unsigned voff = (unsigned)row * (unsigned)(ld * 2) + (isK ? (j ? colK1 : colK0) : colV);
+        glds16_off_at(base, voff, lds0 + (unsigned)((isK ? KRING : VRING) + (t & 1) * SLOT_B + var * TILE_B + (wave * 2 + j) * 1024));
+    };
+    // in-loop pieces of the stage issued at the last unit of key tile kt: slot i = 4*variant + 2*isK + j; V of tile kt+1, K of kt+2
+    auto piece = [&](const int i, const int kt) { piece_t((i >> 1) & 1, i >> 2, i & 1, kt + 1 + ((i >> 1) & 1)); };
+
+    // ---- prologue: everything the first phases need is REQUESTED before the first wait (one workgroup per CU: nothing else
+    // covers a prologue's serial round trips).  K_0, V_0 and K_1 go out in both variants: which of them the tiles need is only
+    // known after the mask pass and two barriers.
+#pragma unroll
+    for (int var = 0; var < 2; ++var)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { piece_t(true, var, j, 0); piece_t(false, var, j, 0); }
+    if (nkt > 1) {
+#pragma unroll
+        for (int var = 0; var < 2; ++var)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) piece_t(true, var, j, 1);
+    }
+    const int q_vis_raw = p.flag[tok0 + q];
+    bf16x8 qf[8];                                                   // lane (q = l31, half fk) holds Q[q][16*ks + 8*fk .. +8]
+    {
+        const bf16_t* qp = p.q + (tok0 + q) * p.ldq + h * BD + fk * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+    modality_masks(p.flag + tok0, S, kmask, tid, 512);
+    if (tid < 8) blk[tid] = 0;
+    const bool q_vis = q_vis_raw != 0;
+    __syncthreads();
+
+    // ---- per-wave classification of every key tile, lane = tile
+    const bool wV = __ballot(q_vis && (q0w + l31) < S) != 0;        // this wave's query modalities
+    const bool wL = __ballot(!q_vis && (q0w + l31) < S) != 0;
+    unsigned e0 = 0, e1 = 0;                                        // this lane's tile: entries of pass 0 / pass 1
+    {
+        const int kv0 = lane * BKV;
+        const u64 mm = (u64)kmask[2 * lane] | ((u64)kmask[2 * lane + 1] << 32);
+        const u64 rng = bits_below(len - kv0) & ~bits_below(start - kv0);       // valid keys of the tile
+        const bool kV = (mm & rng) != 0, kL = (~mm & rng) != 0;
+        const bool wsame = (wL && kL) || (wV && kV), wcross = (wL && kV) || (wV && kL);
+        const bool in = active && lane < nkt && kv0 <= q0w + 31 && (wsame || wcross);
+        const bool both = in && wsame && wcross;
+        const bool full = kv0 + BKV - 1 <= q0w && kv0 >= start && kv0 + BKV <= len;
+        const u64 b_sec = __ballot(both), b_same = __ballot(in && wsame), b_cross = __ballot(in && wcross);
+        if (lane == 0) {
+            if ((unsigned)b_sec) atomicOr(&blk[0], (unsigned)b_sec);
+            if ((unsigned)(b_sec >> 32)) atomicOr(&blk[1], (unsigned)(b_sec >> 32));
+            if ((unsigned)b_same) atomicOr(&blk[2], (unsigned)b_same);
+            if ((unsigned)(b_same >> 32)) atomicOr(&blk[3], (unsigned)(b_same >> 32));
+            if ((unsigned)b_cross) atomicOr(&blk[4], (unsigned)b_cross);
+            if ((unsigned)(b_cross >> 32)) atomicOr(&blk[5], (unsigned)(b_cross >> 32));
+        }
+        e0 = (unsigned)((!in ? 0 : ((full && !both) ? 1 : 2)) | ((in && !wsame) ? 4 : 0) | (lane << 4));
+        e1 = (unsigned)((both ? 2 : 0) | 4 | 8 | (lane << 4));
+    }
+    __syncthreads();
+    const u64 sec_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[0]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[1]) << 32);
+    const u64 same_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[2]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[3]) << 32);
+    const u64 cross_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[4]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[5]) << 32);
+    const int U = nkt + __popcll(sec_blk);                          // units of this workgroup (<= 128)
+    unsigned tab0, tab1;                                            // lane i: entry of unit i / unit 64 + i (0 past the end)
+    {
+        unsigned short* tab = (unsigned short*)(smem + TAB_OFF) + wave * 128;
+        if (lane < nkt) {
+            const int u0 = lane + __popcll(sec_blk & bits_below(lane));
+            const bool sec = (sec_blk >> lane) & 1ull;
+            tab[u0] = (unsigned short)(e0 | (sec ? 0u : 8u));
+            if (sec) tab[u0 + 1] = (unsigned short)e1;
+        }
+        tab0 = lane < U ? tab[lane] : 0u;                           // (same wave, in-order LDS queue: no barrier)
+        tab1 = lane + 64 < U ? tab[lane + 64] : 0u;
+    }
+    auto entry = [&](const int u) -> unsigned {                     // u wave-uniform
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)tab0, u & 63), c = (unsigned)__builtin_amdgcn_readlane((int)tab1, u & 63);
+        return u < 64 ? a : c;
+    };
+    // stage requested at the last unit of tile kt: bit i = piece slot i wanted (V of tile kt + 1, K of tile kt + 2)
+    auto dma_mask = [&](const int kt) -> unsigned {
+        unsigned dm = 0;
+        if (kt + 1 < nkt) dm |= (((same_blk >> (kt + 1)) & 1ull) ? 0x03u : 0u) | (((cross_blk >> (kt + 1)) & 1ull) ? 0x30u : 0u);
+        if (kt + 2 < nkt) dm |= (((same_blk >> (kt + 2)) & 1ull) ? 0x0cu : 0u) | (((cross_blk >> (kt + 2)) & 1ull) ? 0xc0u : 0u);
+        return dm;
+    };
+    auto issue_all = [&](const unsigned dm, const int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (dm & (1u << i)) piece(i, kt);
+    };
+
+    // ---- fragment addressing: lane constants; tile base, k-step and key half are uniform / immediate
+    int kb[4], vb[4];
+    {
+        const int kswz = (l31 >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kb[j] = l31 * 128 + (((2 * j + fk) ^ kswz) << 4);
+        const int pp = lane & 15, g16 = (lane >> 4) & 1;
+        const int vrow = (4 * fk + (pp >> 2)) * 256 + ((pp & 1) << 3);       // keys 4fk + (p>>2), 2nd read +8
+        const int tlo = (2 * g16 + ((pp & 3) >> 1)) << 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vb[dt] = vrow + ((((dt ^ (pp >> 2)) & 3) << 6) | tlo);   // 32-line block dt of the 128-line (d) tile
+    }
 
     f32x16 o[4];
 #pragma unroll
@@ -123,144 +213,81 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sA, sB;                                                  // S^T of the unit in flight: key halves 0 / 1
+    union PK { bf16x8 v; unsigned u[4]; };
+    PK pk[4];                                                       // P^T of the unit in flight as the four 16-key B operands
+    const int qabs = q0w + l31;
 
-    // causal: keys 0 .. min(S, (qt+1)*BQ) - 1
-    int kend = (qt + 1) * BQ; kend = kend < S ? kend : S;
-    const int nkt = (kend + BKV - 1) / BKV;
-
-    // modality content of `n` keys starting at 32-key word w0 (n = 32 or 64), valid keys only
-    auto key_mods = [&](int w0, int n, bool& kV, bool& kL) {
-        // (readfirstlane: LDS data is wave-uniform here, and MFMAs under a branch the compiler believes divergent cost a
-        //  full copy of every accumulator they touch)
-        unsigned long long m = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0]);
-        if (n == 64) m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0 + 1]) << 32;
-        int nvalid = S - w0 * 32; nvalid = nvalid > n ? n : nvalid;
-        const unsigned long long full = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-        kV = (m & full) != 0; kL = ((~m) & full) != 0;
-    };
-    auto stage = [&](int buf, int t) {
-        bool kV, kL;
-        key_mods(2 * t, 64, kV, kL);
-        char* dst = smem + buf * STAGE_BYTES;
-        if ((blkL && kL) || (blkV && kV))
-            stage_kv(ks_base, (unsigned)p.ldk * 2u, vs_base, (unsigned)p.ldv * 2u, t * BKV, S, dst, wave, lane);
-        if ((blkL && kV) || (blkV && kL))
-            stage_kv(kc_base, (unsigned)p.ldkc * 2u, vc_base, (unsigned)p.ldvc * 2u, t * BKV, S, dst + VAR_BYTES, wave, lane);
-    };
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) pin(qf[ks]);                     // Q has landed before the loop's LDS-DMA traffic starts
 
-    // fragment addressing.  The lane-derived LDS offsets are recomputed per tile from an opaque copy of the lane id:
-    // hoisted to kernel entry they are ten long-lived registers that hipcc spills around the tile loop, and a scratch
-    // reload inside the loop is a vmcnt(0) drain of the LDS-DMA queue.
-    int lane_o = lane;
-    // S^T (2 x 32 keys x 32 queries) of both key halves of the K image at `kimg`.  The two accumulators alternate: eight
-    // back-to-back MFMAs on ONE accumulator are a dependent chain that runs at half rate (round-1 cycle stamps: 1400 cycles
-    // for the 16 QK MFMAs of a tile).
-    auto qk_pair = [&](const char* kimg, f32x16& s0, f32x16& s1) {
-        const int l31o = lane_o & 31, fko = lane_o >> 5;
-        const int kswz = (l31o >> 1) & 7;
-        const char* krow = kimg + l31o * 128;
-        // Fragment reads run FOUR k-steps (8 MFMAs, > one LDS round trip) ahead of their MFMAs: left to itself hipcc keeps one pair
-        // in flight and every MFMA waits out most of an LDS latency (s_waitcnt lgkmcnt(0) in front of each: the 16 MFMAs of a tile
-        // took ~1400 cycles for 512 of matrix pipe).  kf[h][j]: key half h, k-step j (mod 4).
-        bf16x8 kf[2][4];
-        auto rd = [&](int h, int ks) -> bf16x8 {
-            const int c = (2 * (ks & 3) + fko) ^ kswz;
-            return *(const bf16x8*)(krow + h * 8192 + (ks >> 2) * 4096 + (c << 4));
+    union VA { bf16x8 v; s16x4 h2[2]; };
+    // M phase: [O^T += V^T P^T of this unit: MFMAs 0-15 = (k-step st, 32-line d block dt)] [S^T = K Q^T of the next unit: MFMAs
+    // 16-31 = (k-step ks, key half)].  ONE ring of NF operand fragments serves both products: the fragment of MFMA n + NF is
+    // requested right after MFMA n has issued (its registers are free then), i.e. every LDS read runs NF - 1 MFMAs (~160 cycles)
+    // ahead of its consumer and the phase holds 24 fragment registers instead of 64.  k-step st of P.V consumes accumulator
+    // regs 8(st&1)..+7 of half st>>1 = local keys 32(st>>1) + 16(st&1) + 4fk + {0..3, 8..11}.  The two S accumulators alternate:
+    // eight back-to-back MFMAs on ONE accumulator are a dependent chain that runs at half rate.
+    constexpr int NF = 6;
+    auto m_phase = [&](auto pv_c, auto qk_c, const char* vimg, const char* kimg, const unsigned dmA, const int kt) {
+        constexpr bool PV = decltype(pv_c)::value, QK = decltype(qk_c)::value;
+        constexpr int N = (PV ? 16 : 0) + (QK ? 16 : 0), I0 = PV ? 0 : 16;
+        bf16x8 F[NF];
+        auto fread = [&](const int i) -> bf16x8 {
+            if (i < 16) {
+                const char* a = vimg + (i >> 2) * 4096 + vb[i & 3];
+                VA t;
+                t.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
+                t.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
+                return t.v;
+            }
+            const int ks = (i - 16) >> 1, hh = (i - 16) & 1;
+            return *(const bf16x8*)(kimg + kb[ks & 3] + hh * 8192 + (ks >> 2) * 4096);
         };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { kf[0][j] = rd(0, j); kf[1][j] = rd(1, j); }
+        for (int n = 0; n < NF; ++n) F[n] = fread(I0 + n);
+        if constexpr (QK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks & 3], qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks & 3], qf[ks], s1, 0, 0, 0);
-            if (ks < 4) { kf[0][ks] = rd(0, ks + 4); kf[1][ks] = rd(1, ks + 4); }
+        for (int n = 0; n < N; ++n) {
+            const int i = I0 + n;
+            if (i < 16) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], pk[i >> 2].v, o[i & 3], 0, 0, 0);
+            else if (i & 1) sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], qf[(i - 16) >> 1], sB, 0, 0, 0);
+            else sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], qf[(i - 16) >> 1], sA, 0, 0, 0);
+            if (n + NF < N) F[n % NF] = fread(i + NF);
+            if (PV && i < 16 && (i & 1)) {                          // group 0's staging pieces ride between the P.V MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                if (dmA & (1u << (i >> 1))) piece(i >> 1, kt);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // O^T += V^T P^T for one 16-key step: `vstep` = V image + 4096 * step
-    // the 8 transpose reads of a 16-key step go out before its 4 MFMAs (one LDS latency per step instead of one per MFMA)
-    auto pv_step = [&](const char* vstep, const bf16x8 pk) {
-        const int pp = lane_o & 15, g16 = (lane_o >> 4) & 1;
-        const char* vrow = vstep + (4 * (lane_o >> 5) + (pp >> 2)) * 256 + ((pp & 1) << 3);   // keys 4fk + (p>>2), 2nd read +8
-        const int tlo = (2 * g16 + ((pp & 3) >> 1)) << 4;
-        union { bf16x8 v; s16x4 h2[2]; } va[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            // 32-line block dt of the 128-line (d) T-type tile
-            const char* a = vrow + ((((dt ^ (pp >> 2)) & 3) << 6) | tlo);
-            va[dt].h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a));
-            va[dt].h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + 2048));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[dt].v, pk, o[dt], 0, 0, 0);
-    };
-    auto rescale = [&](float alpha) {
-        l_run *= alpha;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    };
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-        if (!active) continue;
+    // per-element key mask of a MASKED unit: key <= query (causal), start <= key < len (padding), and the pair's modality
+    // relation == the unit's variant.  One 64-bit word per lane, tested with compile-time bit positions.
+    auto apply_mask = [&](const int kt, const int var) {
         const int kv0 = kt * BKV;
-        if (kv0 > q0w + 31) continue;                               // tile entirely above this wave's diagonal
-        asm volatile("" : "+v"(lane_o));
-        const char* sks = smem + cur * STAGE_BYTES;                 // same variant: K (4 x 4 KiB), V at +16384
-        const char* skc = sks + VAR_BYTES;
-        bool kV, kL;
-        key_mods(2 * kt, 64, kV, kL);
-        const bool wsame = (wL && kL) || (wV && kV);
-        const bool wcross = (wL && kV) || (wV && kL);
-
-        const bool mixed = wsame && wcross;                         // both variants present: select per element
-        const char* img1 = wsame ? sks : skc;                       // primary variant (same unless only cross is needed)
-
-        // ---- S^T = K Q^T, 64 keys x 32 queries ----
-        f32x16 sA, sB;
+        const unsigned km0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt]);
+        const unsigned km1 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + 1]);
+        // cross pair <=> key bit != query bit; wanted <=> cross == var  =>  valid = ~(km ^ QV ^ VAR)
+        const unsigned flip = ~((q_vis ? ~0u : 0u) ^ (var ? ~0u : 0u));
+        // left padding: keys before `start` are masked for real queries; a padding QUERY row keeps them (its output is never used)
+        const int lo = qabs < start ? 0 : start;
+        int hi = qabs < len - 1 ? qabs : len - 1;                   // last valid key of this row
+        const u64 rng = bits_below(hi - kv0 + 1) & ~bits_below(lo - kv0);
+        const unsigned v0 = ((km0 ^ flip) & (unsigned)rng) >> (4 * fk);
+        const unsigned v1 = ((km1 ^ flip) & (unsigned)(rng >> 32)) >> (4 * fk);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; }
-        qk_pair(img1, sA, sB);
-        unsigned crA = 0, crB = 0;                                  // bit r: element r takes the cross variant (mixed tiles)
-        if (mixed) {
-            f32x16 tA, tB;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { tA[r] = 0.f; tB[r] = 0.f; }
-            qk_pair(skc, tA, tB);
-            const unsigned km0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt]);
-            const unsigned km1 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + 1]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = (r & 3) + 8 * (r >> 2) + 4 * fk;     // local key of accumulator row r
-                const bool ca = (((km0 >> kl) & 1u) != 0) != q_vis, cb = (((km1 >> kl) & 1u) != 0) != q_vis;
-                sA[r] = ca ? tA[r] : sA[r];
-                sB[r] = cb ? tB[r] : sB[r];
-                crA |= (ca ? 1u : 0u) << r;
-                crB |= (cb ? 1u : 0u) << r;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int bpos = (r & 3) + 8 * (r >> 2);                // local key of accumulator row r (minus 4 fk)
+            sA[r] = ((v0 >> bpos) & 1u) ? sA[r] : -INFINITY;
+            sB[r] = ((v1 >> bpos) & 1u) ? sB[r] : -INFINITY;
         }
-        if (kv0 + BKV - 1 > q0w || kv0 + BKV > len || kv0 < start) {   // causal diagonal / padded keys inside this tile
-            const int qabs = q0w + l31;
-            // left padding: keys before `start` are masked for real queries; a padding QUERY row keeps them (its output is
-            // never used, but an all-masked row would be NaN and 0 x NaN would leak through P.V of later rows' tiles)
-            const int lo = qabs < start ? 0 : start;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                sA[r] = (key <= qabs && key < len && key >= lo) ? sA[r] : -INFINITY;
-                sB[r] = (key + 32 <= qabs && key + 32 < len && key + 32 >= lo) ? sB[r] : -INFINITY;
-            }
-        }
-        // ---- online softmax; the running max only advances when a tile exceeds it by 2^DEFER_THR ----
+    };
+    // online softmax of (sA, sB) -> pk; the running max only advances when a tile exceeds it by 2^DEFER_THR
+    auto softmax = [&]() {
         float tmax = max3f(sA[0], sA[1], sB[0]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) tmax = max3f(tmax, sA[r], sA[r + 1]);
@@ -269,44 +296,117 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_fwd_kernel(const BridgeArg
         tmax = fmaxf(tmax, sB[15]);
         tmax = half_swap_max(tmax * p.sl2);
         const float m_new = fmaxf(m_run, tmax);
-        if (__any(m_new > m_run + DEFER_THR)) {                     // wave-uniform; the first tile always lands here
-            // a row that has seen no key yet (left padding: a whole tile masked for the real rows while the pad rows of the
-            // same wave keep theirs) has m_run = m_new = -inf: exp2(-inf - -inf) = NaN would poison o and l for good
-            rescale(m_new == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new));
+        if (__any(m_new > m_run + DEFER_THR)) {                     // wave-uniform; the first unit always lands here
+            // a row that has seen no key yet has m_run = m_new = -inf: exp2(-inf - -inf) = NaN would poison o and l for good
+            const float alpha = m_new == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             m_run = m_new;
         }
         const float nm = m_run == -INFINITY ? 0.f : -m_run;         // (a row with no visible key yet stays at exactly 0)
-        float psum = 0.f;
+        float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             sA[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sA[r], p.sl2, nm));
             sB[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sB[r], p.sl2, nm));
-            psum += sA[r] + sB[r];
+            ps0 += sA[r];
+            ps1 += sB[r];
         }
-        l_run += psum;
-        // ---- O^T += V^T P^T; k-step st consumes accumulator regs 8(st&1)..+7 of half st>>1 = local keys
-        //      32(st>>1) + 16(st&1) + 4fk + {0..3, 8..11}
+        l_run += ps0 + ps1;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            union { bf16x8 v; unsigned u[4]; } pk, pk2;
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r0 = 8 * (st & 1) + 2 * j;
-                pk.u[j] = st < 2 ? pack2bf(sA[r0], sA[r0 + 1]) : pack2bf(sB[r0], sB[r0 + 1]);
+                pk[st].u[j] = st < 2 ? pack2bf(sA[r0], sA[r0 + 1]) : pack2bf(sB[r0], sB[r0 + 1]);
             }
-            if (mixed) {                                            // split P by variant (bf16 pair masks)
-                const unsigned cr = (st < 2 ? crA : crB) >> (8 * (st & 1));
+    };
+    // ---- main loop.  Global phase g: group 0 does SM_u at g = 2u and M_u at g = 2u + 1, group 1 one phase later.
+    // A wave computes units [0, Uw) - Uw = one past its last non-skipped unit - with ONE code path (a skipped unit inside that
+    // range, i.e. another wave's second pass, multiplies P = 0 into an operand tile the workgroup did load); the remaining units
+    // [Uw, U) (tiles above this wave's diagonal) only keep the staging and barrier protocol going.
+    const u64 act0 = __ballot((tab0 & 3u) != 0), act1 = __ballot((tab1 & 3u) != 0);
+    const int Uw = act1 ? 128 - (int)__builtin_clzll(act1) : (act0 ? 64 - (int)__builtin_clzll(act0) : 0);
+    // operand images of a unit: its own variant, or - skipped unit - whichever variant of the tile the workgroup loads
+    auto var_of = [&](const unsigned e) -> int {
+        const int kt = (int)(e >> 4);
+        return (e & 3u) ? (int)((e >> 2) & 1u) : (((same_blk >> kt) & 1ull) ? 0 : 1);
+    };
+    auto kimg_of = [&](const unsigned e) -> const char* { return smem + KRING + ((e >> 4) & 1) * SLOT_B + var_of(e) * TILE_B; };
+    auto vimg_of = [&](const unsigned e) -> const char* { return smem + VRING + ((e >> 4) & 1) * SLOT_B + var_of(e) * TILE_B; };
+    auto sm_phase = [&](const unsigned e, const unsigned dm) {
+        const int kt = (int)(e >> 4);
+        if (grp == 1 && dm) issue_all(dm, kt);                      // (group 0 issues the same stage between its MFMAs)
+        if (e & 3u) {
+            if ((e & 3u) == 2u) apply_mask(kt, (int)((e >> 2) & 1u));
+            softmax();
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned keep2 = (((cr >> (2 * j)) & 1u) ? 0xffffu : 0u) | (((cr >> (2 * j + 1)) & 1u) ? 0xffff0000u : 0u);
-                    pk2.u[j] = pk.u[j] & keep2;
-                    pk.u[j] &= ~keep2;
-                }
-            }
-            pv_step(img1 + 16384 + st * 4096, pk.v);
-            if (mixed) pv_step(skc + 16384 + st * 4096, pk2.v);
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[st].u[j] = 0u;
         }
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage this group requested one phase ago
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto m_end = [&]() {
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage this group requested in its SM phase
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                // K_0, V_0, K_1 landed
+    unsigned e_cur = entry(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    if (Uw > 0) m_phase(std::false_type{}, std::true_type{}, nullptr, kimg_of(e_cur), 0u, 0);
+    __builtin_amdgcn_s_barrier();
+    int u = 0;
+    for (; u + 1 < Uw; ++u) {
+        const unsigned e_nxt = entry(u + 1);
+        const int kt = (int)(e_cur >> 4);
+        const unsigned dm = (e_cur & 8u) ? dma_mask(kt) : 0u;
+        sm_phase(e_cur, dm);
+#if LIBRA_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        m_phase(std::true_type{}, std::true_type{}, vimg_of(e_cur), kimg_of(e_nxt), grp == 0 ? dm : 0u, kt);
+#if LIBRA_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        m_end();
+        e_cur = e_nxt;
     }
+    if (u < Uw) {                                                   // this wave's last unit: no next S
+        const int kt = (int)(e_cur >> 4);
+        const unsigned dm = (e_cur & 8u) ? dma_mask(kt) : 0u;
+        sm_phase(e_cur, dm);
+#if LIBRA_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        m_phase(std::true_type{}, std::false_type{}, vimg_of(e_cur), nullptr, grp == 0 ? dm : 0u, kt);
+#if LIBRA_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        m_end();
+        ++u;
+    }
+    for (; u < U; ++u) {                                            // units above this wave's diagonal: staging duty only
+        const unsigned e = entry(u);
+        const int kt = (int)(e >> 4);
+        const unsigned dm = (e & 8u) ? dma_mask(kt) : 0u;
+        if (grp == 1 && dm) issue_all(dm, kt);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 0 && dm) issue_all(dm, kt);
+        m_end();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                     // re-align the two groups
 
     // ---- finish ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

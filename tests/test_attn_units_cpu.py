@@ -1,0 +1,127 @@
+"""The bridge-attention forward's work list (libra_amd/csrc/attention_bridge.hip, round 5) restated in numpy: per wave of 32 query
+rows, every key tile becomes zero, one or two UNITS (operand variant passes), each skipped / plain / masked.  The test pins what the
+kernel relies on: over all units of a wave, every (query, key) pair the reference attends to (causal, inside [start, len), real
+query) is covered EXACTLY once and with the operand variant the closed form asks for (cross iff the two tokens' modalities differ:
+modeling_libra.py:364-370 / :282-293), a plain unit has no pair to mask, and the staging protocol's tile sets cover every
+variant some wave reads."""
+import numpy as np
+import pytest
+
+BQ, BKV = 256, 64
+
+
+def bits_below(n):
+    return (1 << 64) - 1 if n >= 64 else (0 if n <= 0 else (1 << n) - 1)
+
+
+def plan_block(flag, S, length, start, qt):
+    """-> per wave: list of units (kt, var, mode, last) in the workgroup's unit order, and the block-level tile sets."""
+    n32 = (S + 31) // 32
+    kmask = [0] * (2 * 64 + 2)
+    for t in range(n32):
+        for i in range(32):
+            tok = t * 32 + i
+            if tok < S and flag[tok]:
+                kmask[t] |= 1 << i
+    kend = min((qt + 1) * BQ, S)
+    nkt = (kend + BKV - 1) // BKV
+    per_wave = []
+    sec_blk = same_blk = cross_blk = 0
+    for wave in range(8):
+        q0w = qt * BQ + wave * 32
+        active = q0w < S
+        rows = [r for r in range(q0w, q0w + 32) if r < S]
+        wV = any(flag[r] for r in rows)
+        wL = any(not flag[r] for r in rows)
+        tiles = []
+        for kt in range(64):
+            kv0 = kt * BKV
+            mm = kmask[2 * kt] | (kmask[2 * kt + 1] << 32)
+            rng = bits_below(length - kv0) & ~bits_below(start - kv0)
+            kV, kL = (mm & rng) != 0, (~mm & rng & ((1 << 64) - 1)) != 0
+            wsame, wcross = (wL and kL) or (wV and kV), (wL and kV) or (wV and kL)
+            inn = active and kt < nkt and kv0 <= q0w + 31 and (wsame or wcross)
+            both = inn and wsame and wcross
+            full = kv0 + BKV - 1 <= q0w and kv0 >= start and kv0 + BKV <= length
+            e0 = (0 if not inn else (1 if (full and not both) else 2), 1 if (inn and not wsame) else 0)
+            e1 = (2 if both else 0, 1)
+            tiles.append((e0, e1))
+            if both: sec_blk |= 1 << kt
+            if inn and wsame: same_blk |= 1 << kt
+            if inn and wcross: cross_blk |= 1 << kt
+        per_wave.append(tiles)
+    units = []
+    for wave in range(8):
+        lst = []
+        for kt in range(nkt):
+            (m0, v0), (m1, v1) = per_wave[wave][kt]
+            sec = (sec_blk >> kt) & 1
+            lst.append((kt, v0, m0, not sec))
+            if sec:
+                lst.append((kt, v1, m1, True))
+        units.append(lst)
+    return units, nkt, sec_blk, same_blk, cross_blk, kmask
+
+
+def element_valid(kmask, flag, q, key, kt, var, length, start):
+    """apply_mask's predicate for one (query row, key) of a MASKED unit."""
+    kv0 = kt * BKV
+    lo = 0 if q < start else start
+    hi = min(q, length - 1)
+    rng = bits_below(hi - kv0 + 1) & ~bits_below(lo - kv0)
+    j = key - kv0
+    kbit = (kmask[2 * kt + (j >> 5)] >> (j & 31)) & 1
+    cross = kbit != (1 if flag[q] else 0)
+    return bool((rng >> j) & 1) and (cross == bool(var))
+
+
+@pytest.mark.parametrize("case", ["bench", "two_spans", "random", "left_pad", "right_pad", "ragged", "text_only"])
+def test_units_cover_every_attended_pair_once_with_the_right_variant(case):
+    rs = np.random.RandomState(hash(case) % 1000)
+    S, length, start = 2048, 2048, 0
+    flag = np.zeros(S, dtype=bool)
+    if case == "bench":
+        flag[1:579] = True
+    elif case == "two_spans":
+        flag[5:583] = True; flag[900:1478] = True
+    elif case == "random":
+        S = length = 700; flag = rs.rand(S) < 0.4
+    elif case == "left_pad":
+        S = length = 1024; start = 133; flag = np.zeros(S, dtype=bool); flag[start + 1:start + 579] = True
+    elif case == "right_pad":
+        S = 1024; length = 801; flag = np.zeros(S, dtype=bool); flag[1:579] = True
+    elif case == "ragged":
+        S = length = 1000; flag = np.zeros(S, dtype=bool); flag[300:878] = True
+    n_qt = (S + BQ - 1) // BQ
+    for qt in range(n_qt):
+        units, nkt, sec_blk, same_blk, cross_blk, kmask = plan_block(flag, S, length, start, qt)
+        assert all(len(u) == len(units[0]) for u in units)                 # one barrier schedule for the workgroup
+        assert len(units[0]) == nkt + bin(sec_blk).count("1")
+        for wave in range(8):
+            q0w = qt * BQ + wave * 32
+            cover = {}
+            for (kt, var, mode, last) in units[wave]:
+                if mode == 0:
+                    continue
+                assert (cross_blk if var else same_blk) >> kt & 1, "a wave reads an operand variant the workgroup does not stage"
+                for q in range(q0w, min(q0w + 32, S)):
+                    for key in range(kt * BKV, min(kt * BKV + BKV, S)):
+                        if mode == 1:
+                            ok = True                                           # plain: no test of any kind in the kernel
+                        else:
+                            ok = element_valid(kmask, flag, q, key, kt, var, length, start)
+                        if ok:
+                            assert (q, key) not in cover, ("pair covered twice", q, key)
+                            cover[(q, key)] = var
+            for q in range(q0w, min(q0w + 32, S)):
+                if not (start <= q < length):
+                    continue                                                    # padding query rows: output unused
+                for key in range(0, S):
+                    want = key <= q and start <= key < length
+                    if want:
+                        assert cover.get((q, key)) == int(flag[q] != flag[key]), ("missing / wrong variant", q, key)
+                    else:
+                        assert (q, key) not in cover, ("pair should be masked", q, key)
+            # the last flag marks exactly the final unit of every tile
+            lasts = [kt for (kt, _, _, last) in units[wave] if last]
+            assert lasts == list(range(nkt))
