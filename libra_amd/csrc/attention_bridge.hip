@@ -35,6 +35,15 @@
 #ifndef LIBRA_ATTN_PRIO
 #define LIBRA_ATTN_PRIO 1
 #endif
+#ifndef LIBRA_ATTN_DBG          // timing-only anatomy builds (results wrong): 1 no in-loop staging, 2 no softmax arithmetic,
+#define LIBRA_ATTN_DBG 0        // 4 no P.V product, 8 no Q.K product, 16 no main loop, 32 every unit plain, 64 no barriers in the loop
+#endif
+
+#if LIBRA_ATTN_DBG & 64
+#define LOOP_BARRIER() ((void)0)
+#else
+#define LOOP_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 
 namespace libra {
 
@@ -48,7 +57,14 @@ constexpr int VRING = 2 * SLOT_B;             // 2 slots
 constexpr int MASK_OFF = 4 * SLOT_B;          // key-modality words of the sequence (<= 130 words; 1 KiB reserved)
 constexpr int BLK_OFF = MASK_OFF + 1024;      // block-level tile sets (6 words)
 constexpr int TAB_OFF = BLK_OFF + 64;         // per-wave unit tables: 8 x 128 x 2 B
+#if LIBRA_ATTN_DBG & 128          // + cycle stamps of workgroup 0 (heaviest block of sequence 0 / head 0), dumped over the start of out_lo
+constexpr int STAMP_OFF = TAB_OFF + 8 * 256;
+constexpr int BR_LDS = STAMP_OFF + 8 * 1024;
+#define STAMP() do { if (dbg_blk) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); if (lane == 0 && n_stamp < 256) ((unsigned*)(smem + STAMP_OFF))[wave * 256 + n_stamp] = t_; ++n_stamp; } } while (0)
+#else
 constexpr int BR_LDS = TAB_OFF + 8 * 256;
+#define STAMP() ((void)0)
+#endif
 
 // K tile image: four N-type [32 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 4 KiB each, ordered
 //               (key half, d half).  V tile image: T-type [64 keys][128 d] (256-byte rows, chunk ^ ((row&3)<<2)), 16 KiB.
@@ -88,6 +104,10 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * BD;
     const bf16_t* vc_base = p.v_cross + tok0 * p.ldvc + h * BD;
     const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;
+#if LIBRA_ATTN_DBG & 128
+    const bool dbg_blk = blockIdx.x == 0;
+    int n_stamp = 0;
+#endif
 
     // ---- direct-to-LDS pieces.  A 16-KiB tile is 16 pieces of 1 KiB; wave w moves pieces 2w, 2w+1 of every tile.
     // K piece pc -> sub-tile pc>>2, rows 8*(pc&3)..+7 (8 rows x 128 B); V piece pc -> rows 4*pc..+3 (4 rows x 256 B)
@@ -165,7 +185,11 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     const u64 sec_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[0]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[1]) << 32);
     const u64 same_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[2]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[3]) << 32);
     const u64 cross_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[4]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[5]) << 32);
+#if LIBRA_ATTN_DBG & 16
+    const int U = 0;
+#else
     const int U = nkt + __popcll(sec_blk);                          // units of this workgroup (<= 128)
+#endif
     unsigned tab0, tab1;                                            // lane i: entry of unit i / unit 64 + i (0 past the end)
     {
         unsigned short* tab = (unsigned short*)(smem + TAB_OFF) + wave * 128;
@@ -183,10 +207,16 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
         return u < 64 ? a : c;
     };
     // stage requested at the last unit of tile kt: bit i = piece slot i wanted (V of tile kt + 1, K of tile kt + 2)
+    // (a tile NO wave needs - keys before a left-padded sequence's start - is still staged in its same variant: a wave multiplies
+    //  P = 0 into it, and 0 x whatever-was-in-LDS could be NaN)
+    const u64 same_st = same_blk | ~cross_blk;
     auto dma_mask = [&](const int kt) -> unsigned {
         unsigned dm = 0;
-        if (kt + 1 < nkt) dm |= (((same_blk >> (kt + 1)) & 1ull) ? 0x03u : 0u) | (((cross_blk >> (kt + 1)) & 1ull) ? 0x30u : 0u);
-        if (kt + 2 < nkt) dm |= (((same_blk >> (kt + 2)) & 1ull) ? 0x0cu : 0u) | (((cross_blk >> (kt + 2)) & 1ull) ? 0xc0u : 0u);
+        if (kt + 1 < nkt) dm |= (((same_st >> (kt + 1)) & 1ull) ? 0x03u : 0u) | (((cross_blk >> (kt + 1)) & 1ull) ? 0x30u : 0u);
+        if (kt + 2 < nkt) dm |= (((same_st >> (kt + 2)) & 1ull) ? 0x0cu : 0u) | (((cross_blk >> (kt + 2)) & 1ull) ? 0xc0u : 0u);
+#if LIBRA_ATTN_DBG & 1
+        dm = 0;
+#endif
         return dm;
     };
     auto issue_all = [&](const unsigned dm, const int kt) {
@@ -230,7 +260,9 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     // eight back-to-back MFMAs on ONE accumulator are a dependent chain that runs at half rate.
     constexpr int NF = 6;
     auto m_phase = [&](auto pv_c, auto qk_c, const char* vimg, const char* kimg, const unsigned dmA, const int kt) {
-        constexpr bool PV = decltype(pv_c)::value, QK = decltype(qk_c)::value;
+        constexpr bool PV = decltype(pv_c)::value && !(LIBRA_ATTN_DBG & 4), QK = decltype(qk_c)::value && !(LIBRA_ATTN_DBG & 8);
+        if constexpr (!PV && decltype(pv_c)::value) { if (dmA) issue_all(dmA, kt); }
+        if constexpr (!QK && decltype(qk_c)::value) { asm volatile("" : "+v"(sA), "+v"(sB)); }
         constexpr int N = (PV ? 16 : 0) + (QK ? 16 : 0), I0 = PV ? 0 : 16;
         bf16x8 F[NF];
         auto fread = [&](const int i) -> bf16x8 {
@@ -258,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
             else if (i & 1) sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], qf[(i - 16) >> 1], sB, 0, 0, 0);
             else sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], qf[(i - 16) >> 1], sA, 0, 0, 0);
             if (n + NF < N) F[n % NF] = fread(i + NF);
-            if (PV && i < 16 && (i & 1)) {                          // group 0's staging pieces ride between the P.V MFMAs
+            if (decltype(pv_c)::value && PV && i < 16 && (i & 1)) {                          // group 0's staging pieces ride between the P.V MFMAs
                 __builtin_amdgcn_sched_barrier(0);
                 if (dmA & (1u << (i >> 1))) piece(i >> 1, kt);
             }
@@ -288,6 +320,16 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     };
     // online softmax of (sA, sB) -> pk; the running max only advances when a tile exceeds it by 2^DEFER_THR
     auto softmax = [&]() {
+#if LIBRA_ATTN_DBG & 2
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r0 = 8 * (st & 1) + 2 * j;
+                pk[st].u[j] = st < 2 ? pack2bf(sA[r0], sA[r0 + 1]) : pack2bf(sB[r0], sB[r0 + 1]);
+            }
+        return;
+#endif
         float tmax = max3f(sA[0], sA[1], sB[0]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) tmax = max3f(tmax, sA[r], sA[r + 1]);
@@ -333,15 +375,18 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     // operand images of a unit: its own variant, or - skipped unit - whichever variant of the tile the workgroup loads
     auto var_of = [&](const unsigned e) -> int {
         const int kt = (int)(e >> 4);
-        return (e & 3u) ? (int)((e >> 2) & 1u) : (((same_blk >> kt) & 1ull) ? 0 : 1);
+        return (e & 3u) ? (int)((e >> 2) & 1u) : (((same_st >> kt) & 1ull) ? 0 : 1);
     };
     auto kimg_of = [&](const unsigned e) -> const char* { return smem + KRING + ((e >> 4) & 1) * SLOT_B + var_of(e) * TILE_B; };
     auto vimg_of = [&](const unsigned e) -> const char* { return smem + VRING + ((e >> 4) & 1) * SLOT_B + var_of(e) * TILE_B; };
     auto sm_phase = [&](const unsigned e, const unsigned dm) {
         const int kt = (int)(e >> 4);
+        STAMP();                                                    // [0] SM start
         if (grp == 1 && dm) issue_all(dm, kt);                      // (group 0 issues the same stage between its MFMAs)
         if (e & 3u) {
+#if !(LIBRA_ATTN_DBG & 32)
             if ((e & 3u) == 2u) apply_mask(kt, (int)((e >> 2) & 1u));
+#endif
             softmax();
         } else {
 #pragma unroll
@@ -349,15 +394,20 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pk[st].u[j] = 0u;
         }
+        STAMP();                                                    // [1] softmax done
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage this group requested one phase ago
+        STAMP();                                                    // [2] staging wait done
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        LOOP_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
+        STAMP();                                                    // [3] barrier passed = M start
     };
     auto m_end = [&]() {
+        STAMP();                                                    // [4] MFMAs issued
         if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage this group requested in its SM phase
+        STAMP();                                                    // [5] staging wait done
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        LOOP_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -402,12 +452,18 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
         const unsigned dm = (e & 8u) ? dma_mask(kt) : 0u;
         if (grp == 1 && dm) issue_all(dm, kt);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        LOOP_BARRIER();
         if (grp == 0 && dm) issue_all(dm, kt);
         m_end();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();                     // re-align the two groups
 
+#if LIBRA_ATTN_DBG & 128
+    __syncthreads();
+    if (dbg_blk && p.out_lo) for (int i = tid; i < 2048; i += 512) ((unsigned*)p.out_lo)[i] = ((unsigned*)(smem + STAMP_OFF))[i];
+    if (dbg_blk && p.out_lo && tid == 0) { ((unsigned*)p.out_lo)[2048] = (unsigned)U; }
+    if (dbg_blk && p.out_lo && lane == 0) ((unsigned*)p.out_lo)[2049 + wave] = (unsigned)Uw;
+#endif
     // ---- finish ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -416,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     char* so = smem + wave * (32 * OROW);
     // two passes through the per-wave staging rows: the bf16 output, then (when asked for) its rounding residual
 #pragma unroll 1
-    for (int part = 0; part < (p.out_lo ? 2 : 1); ++part) {
+    for (int part = 0; part < ((p.out_lo && !(LIBRA_ATTN_DBG & 128)) ? 2 : 1); ++part) {
         if (part) __syncthreads();
         if (active) {
 #pragma unroll
