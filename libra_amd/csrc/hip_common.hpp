@@ -91,11 +91,29 @@ template <typename T>
 __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
 
 // Modality bit masks of one sequence into LDS: word t, bit i = token 32 t + i is a vision token, words [0, ceil(S/32)] (the
-// spare last word is zero so a ragged 64-token tile reads zeros).  One thread per word, its 32 flag bytes as 32 independent
-// loads: ONE memory round trip for the whole workgroup.  [The per-wave ballot loop this replaces made one dependent global
-// load per 256 tokens - 9 serial round trips per workgroup at S = 2048, ~10 us of every attention workgroup's prologue.]
+// spare last word is zero so a ragged 64-token tile reads zeros).  Fast path (flags 4-byte aligned, S a multiple of 4): every
+// thread loads ONE dword = 4 flags, coalesced, and 8 lanes OR their nibbles into a word (3 cross-lane steps): one memory round
+// trip and ~40 VALU.  [Round 5 cycle stamps: the previous form - one thread per word, 32 byte loads each, 65 threads busy - was
+// 8.4k of the attention forward's 10.5k prologue cycles.]  Generic path: one thread per word, its 32 flag bytes as 32
+// independent loads (still ONE round trip; the per-wave ballot loop before that made 9 dependent ones at S = 2048).
 __device__ __forceinline__ void modality_masks(const unsigned char* __restrict__ flag_seq, int S, unsigned* masks, int tid, int nthreads) {
     const int n32 = (S + 31) / 32;
+    if ((((unsigned long)flag_seq | (unsigned long)S) & 3ul) == 0) {
+        const int n_dw = S >> 2;
+        for (int i0 = 0; i0 < n32 * 8; i0 += nthreads) {            // (n32 * 8 dwords cover whole words; lanes past n_dw hold 0)
+            const int i = i0 + tid;
+            unsigned d = 0;
+            if (i < n_dw) d = ((const unsigned*)flag_seq)[i];
+            unsigned nib = ((d & 0xffu) ? 1u : 0u) | ((d & 0xff00u) ? 2u : 0u) | ((d & 0xff0000u) ? 4u : 0u) | ((d & 0xff000000u) ? 8u : 0u);
+            unsigned v = nib << (4 * (tid & 7));
+            v |= (unsigned)__shfl_xor((int)v, 1, 64);
+            v |= (unsigned)__shfl_xor((int)v, 2, 64);
+            v |= (unsigned)__shfl_xor((int)v, 4, 64);
+            if ((tid & 7) == 0 && (i >> 3) < n32) masks[i >> 3] = v;
+        }
+        if (tid == 0) masks[n32] = 0;
+        return;
+    }
     for (int t = tid; t < n32 + 1; t += nthreads) {
         unsigned char f[32];
 #pragma unroll
