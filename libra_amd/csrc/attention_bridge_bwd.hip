@@ -77,10 +77,15 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fk = lane >> 5, l31 = lane & 31;
-    const int nblk = p.B * p.H * p.n_t;
-    const int L = xcd_remap(blockIdx.x, nblk);
-    const int qt = p.n_t - 1 - (L % p.n_t);
-    const int bh = L / p.n_t;
+    // persistent workgroups with the forward kernel's static rotation schedule (bridge_attn_fwd_kernel): item i = w + k P is
+    // (sequence, head) i / n_t, query block (i + k) mod n_t
+    const int nitems = p.B * p.H * p.n_t;
+    const int P = (int)gridDim.x;
+    const int w_id = xcd_remap(blockIdx.x, P);
+#pragma unroll 1
+    for (int step = 0, item = w_id; item < nitems; ++step, item += P) {
+    const int qt = p.n_t - 1 - ((item % p.n_t + step) % p.n_t);
+    const int bh = item / p.n_t;
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
     const long tok0 = (long)b * S;
@@ -313,6 +318,8 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
             }
         }
     }
+    __syncthreads();                                                // the next item's staging overwrites the output rows' LDS
+    }   // persistent item loop
 }
 
 // ================================================================================================
@@ -357,10 +364,21 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     const int kw = wave & 1, qh = (wave >> 1) & 1;
     const bool role_dk = (wave >> 2) != 0;                       // waves 0-3: dV; waves 4-7: dK
     const int fk = lane >> 5, l31 = lane & 31;
-    const int nblk = p.B * p.H * p.n_t;
-    const int L = xcd_remap(blockIdx.x, nblk);
-    const int ktile = L % p.n_t;                                 // low key tiles see the most queries: they come first
-    const int bh = L / p.n_t;
+    // Persistent workgroups, static schedule (as in bridge_attn_fwd_kernel): the launcher starts P workgroups (one per CU, P a
+    // multiple of n_t); workgroup w handles the items i = w + k P, k = 0, 1, ...: (sequence, head) i / n_t and key tile
+    // (i + k) mod n_t.  A key tile's weight is the number of query tiles at or below it (1 .. n_t): the rotation by k hands every
+    // workgroup every weight once per n_t steps, so the CUs finish together without a queue, and a CU no longer waits ~7 us for
+    // the dispatch of each of its (8192 / 256 =) 32 one-per-CU workgroups.  An XCD's 32 workgroups stream the Q / dO tiles of the
+    // same few (sequence, head) pairs at a time through that XCD's L2.
+    const int nitems = p.B * p.H * p.n_t;
+    const int P = (int)gridDim.x;
+    const int w_id = xcd_remap(blockIdx.x, P);
+    int npass = 0;
+    if (tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;   // the pairs' sequence words count on across items
+#pragma unroll 1
+    for (int step = 0, item = w_id; item < nitems; ++step, item += P) {
+    const int ktile = (item % p.n_t + step) % p.n_t;
+    const int bh = item / p.n_t;
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
     const long tok0 = (long)b * S;
@@ -400,8 +418,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     // (an LDS-space pointer: through a generic `volatile int*` the poll compiled to `flat_load_dword .. sc0 sc1` + `s_waitcnt vmcnt(0)`,
     //  which also drained the next tile's direct-to-LDS queue in every iteration of the dK waves)
     volatile LIBRA_LDS int* xseq = (volatile LIBRA_LDS int*)(LIBRA_LDS char*)(smem + DKV_XP + 4 * 4096) + (qh * 2 + kw);
-    int npass = 0;
-    if (tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;
     f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -586,7 +602,6 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
             }
         __syncthreads();
     }
-    if (kbase_w >= S) return;
     // ---- store: each wave's two [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
     constexpr int OROW = 264;
     char* so = smem + wave * (32 * OROW);
@@ -616,13 +631,31 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
             }
         }
     };
-    if (qh == 0) { if (role_dk) store(acc_s, p.scale, p.dk_same); else store(acc_s, 1.0f, p.dv_same); }
-    else { if (role_dk) store(acc_c, p.scale, p.dk_cross); else store(acc_c, 1.0f, p.dv_cross); }
+    if (kbase_w < S) {
+        if (qh == 0) { if (role_dk) store(acc_s, p.scale, p.dk_same); else store(acc_s, 1.0f, p.dv_same); }
+        else { if (role_dk) store(acc_c, p.scale, p.dk_cross); else store(acc_c, 1.0f, p.dv_cross); }
+    }
+    __syncthreads();                                             // the next item's staging overwrites the store rows' LDS
+    }   // persistent item loop
 }
 
 }  // namespace libra
 
 using namespace libra;
+
+// persistent grid: one workgroup per CU, rounded down to a multiple of the rotation period (the kernels' static schedules need
+// it), at least one period, at most one workgroup per item
+static long persistent_grid(long nitems, int period) {
+    static std::atomic<int> n_cu{0};              // (benign race: every thread stores the same value)
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n_cu = cus;
+    }
+    long nblk = (long)n_cu / period * period;
+    if (nblk < period) nblk = period;
+    return nblk > nitems ? nitems : nblk;
+}
 
 extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                                      int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
@@ -663,11 +696,12 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     long nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
     // (other dK/dV structures that were built and measured in round 2: profiles/r02_attn_bwd_anatomy.md)
-    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)nblk), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)persistent_grid(nblk, a.n_t)), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
+    nblk = persistent_grid(nblk, a.n_t);
     hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
