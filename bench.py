@@ -34,6 +34,8 @@ VIT_L = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num
 GFLOP_FWD_PER_IMG = 381.9
 GFLOP_LAYER = 15.884               # one encoder layer forward
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0            # HBM3E peak (MI355X_MICROARCH.md)
+ACHIEVABLE_HBM_GBPS = 6300.0      # what a streaming kernel reaches on this chip (same guide; the row kernels run 4.7-6.0 TB/s)
 METRIC = "images/sec/GPU fwd+bwd (ViT+bridge, 336px, seq2048) at 1/2/4/8 MI355X"
 
 
@@ -502,7 +504,7 @@ def timed(w, steps, warmup, world, device):
     return dt
 
 
-def roofline(w, workload, ips_per_gpu, gflop_step_img):
+def roofline(w, workload, ips_per_gpu, gflop_step_img, ms_step=None):
     """One instrumented step: HIP events around every GEMM launch on the launch stream (the whole step runs on one stream,
     so a bracket contains exactly its own launch)."""
     from libra_amd import kernels as K
@@ -522,6 +524,32 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img):
     by_shape = [{"shape": n, "launches": c, "ms": round(ms, 2), "tflops": round(fl / 1e9 / ms, 1) if ms > 0 else 0.0}
                 for n, (c, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:48]]
     traffic, src, prov = hbm_traffic("libra" if workload == "bridge" else "vit")
+    # the rest of the step from the same instrumented pass: attention against the MFMA peak (causal-minimal FLOPs), the row kernels
+    # against HBM (algorithmic bytes: each operand / result row once; 8 TB/s peak, ~6.3 TB/s achievable per MI355X_MICROARCH.md),
+    # and what no bracket covers (torch glue, copies, small kernels, launch gaps) = whole step - bracketed time
+    by_kernel = {"gemm": {"launches": len(gem), "ms": round(gms, 2), "tflops": round(achieved, 1), "frac_mfma": round(achieved / PEAK_BF16_TFLOPS, 4)}}
+    for kind in ("attn_fwd", "attn_bwd"):
+        rs = [(wk, t) for k, wk, t in recs if k == kind]
+        if rs:
+            tms, fl = sum(t for _, t in rs), sum(wk[0] for wk, _ in rs)
+            by_kernel["bridge_" + kind] = {"launches": len(rs), "ms": round(tms, 2), "us_per_launch": round(tms / len(rs) * 1e3, 1),
+                                           "tflops": round(fl / 1e9 / tms, 1), "frac_mfma": round(fl / 1e9 / tms / PEAK_BF16_TFLOPS, 4)}
+    rows = {}
+    for k, wk, t in recs:
+        if k == "row":
+            e = rows.setdefault(wk[2], [0, 0.0, 0.0])
+            e[0] += 1; e[1] += t; e[2] += wk[1]
+    if rows:
+        rms, rby = sum(e[1] for e in rows.values()), sum(e[2] for e in rows.values())
+        by_kernel["row_kernels"] = {"launches": sum(e[0] for e in rows.values()), "ms": round(rms, 2), "GBps": round(rby / rms / 1e6, 1),
+                                    "frac_hbm_peak": round(rby / rms / 1e6 / PEAK_HBM_GBPS, 4),
+                                    "frac_hbm_achievable": round(rby / rms / 1e6 / ACHIEVABLE_HBM_GBPS, 4),
+                                    "each": {n: {"launches": c, "ms": round(ms_, 2), "GBps": round(by / ms_ / 1e6, 1)}
+                                             for n, (c, ms_, by) in sorted(rows.items(), key=lambda kv: -kv[1][1])}}
+    bracketed = sum(t for _, _, t in recs)
+    by_kernel["launches_bracketed"] = len(recs)
+    if ms_step is not None:
+        by_kernel["unbracketed_ms"] = round(ms_step - bracketed, 2)      # (bracket times come from one extra step; ms_step from the timed region)
     return {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (256x256x64 tiles; + gemm_bf16_nt_w_kernel 256x128 two per CU / "
                                        "gemm_bf16_nt_kernel 128x128 for tail rows and small problems, split-K wgrad slabs): every "
                                        "launch made through libra_gemm_bf16_nt*",
@@ -531,7 +559,7 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img):
             "algorithmic_bytes_per_launch": round(gbytes),
             "timing": "HIP events on the launch stream around every GEMM launch of one extra step",
             "launches": len(gem), "avg_launch_us": round(gms / max(len(gem), 1) * 1e3, 1), "gemm_ms_per_step": round(gms, 2),
-            "gemm_gflop_per_step": round(gflop, 1), "by_shape": by_shape,
+            "gemm_gflop_per_step": round(gflop, 1), "by_shape": by_shape, "by_kernel": by_kernel,
             "whole_step_frac": round(ips_per_gpu * gflop_step_img / 1e3 / PEAK_BF16_TFLOPS, 4)}
 
 
@@ -677,7 +705,7 @@ def main():
             check = {"error": repr(e)[:200]}
     gpi = gflop_per_image(args.workload, args.seq, args.full_finetune)
     try:
-        roof = roofline(w, args.workload, ips / world, gpi)
+        roof = roofline(w, args.workload, ips / world, gpi, ms)
     except Exception as e:                           # (instrumented extra step; the timed result stands without it)
         roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
                 "error": repr(e)[:200]}

@@ -21,6 +21,10 @@
 #include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
 
+#ifndef LIBRA_DKV_PERSIST       // 1: persistent dK/dV workgroups with the rotation schedule (measured SLOWER in round 5: see DESIGN)
+#define LIBRA_DKV_PERSIST 0
+#endif
+
 namespace libra {
 
 constexpr int D128 = 128;
@@ -63,19 +67,33 @@ __device__ __forceinline__ void stage_t64(const bf16_t* __restrict__ base, unsig
 }
 
 // ================================================================================================
-// dQ pass: 8 waves x 32 queries per workgroup, 64-key tiles (two 32-key halves per barrier), per variant one K image
-// (row reads for S^T = K Q^T, transposed reads for dQ^T += K^T dS^T) and one V image (row reads for dP^T = V dO^T).
-constexpr int DQ_VAR = 32768;                 // K tile 16 KiB + V tile 16 KiB (64 keys)
-constexpr int DQ_STAGE_B = 2 * DQ_VAR;        // same + cross
-constexpr int DQ_LDS_B = 2 * DQ_STAGE_B + 1024;
+// dQ pass, round-5 structure = the forward kernel's (attention_bridge.hip): 8 waves x 32 queries per workgroup, the work list is
+// a list of UNITS = (64-key tile, operand variant) with a per-wave mode (skip / plain / masked) decided once in the prologue,
+// a unit is a DS phase (VALU only: P = exp2(S sl2 - L), mask, dS = P (dP - D), pack) and an M phase
+//     [dQ^T += K_u^T dS_u^T : 16 MFMAs, transposed reads]  [S_{u+1}^T = K_{u+1} Q^T, dP_{u+1}^T = V_{u+1} dO^T : 32 MFMAs, row reads]
+// waves 0-3 and 4-7 (one of each per SIMD) run the sequence one phase apart, so a SIMD's matrix pipe works for one wave while the
+// other does its dS arithmetic; a unit's K | V tile (32 KiB, one variant) travels through a ring of 4 stages, requested two units
+// ahead from the DS phases only; persistent workgroups with the static rotation schedule.  The K tile is staged once in the
+// reduction-major image and read BOTH ways (16-byte row reads for S, LDS transpose reads for dQ), V in the same image (row reads).
 constexpr int DQ_BQ = 256;
+constexpr int DQ_TILE = 16384;                // one [64 keys][128 d] operand tile
+constexpr int DQ_STAGE_B = 2 * DQ_TILE;       // ring stage: K tile | V tile of one unit
+constexpr int DQ_NSTAGE = 4;
+constexpr int DQ_MASK_OFF = DQ_NSTAGE * DQ_STAGE_B;   // key-modality words (<= 130; 1 KiB)
+constexpr int DQ_BLK_OFF = DQ_MASK_OFF + 1024;        // block-level unit sets (4 words)
+constexpr int DQ_TAB_OFF = DQ_BLK_OFF + 64;           // per-wave unit tables: 8 x 128 x 2 B
+constexpr int DQ_LDS_B = DQ_TAB_OFF + 8 * 256;
 
-__global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const BridgeBwdArgs p) {
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 bits_below64(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
+
+__global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dq_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* kmask = (unsigned*)(smem + 2 * DQ_STAGE_B);
-    int* qpres = (int*)(kmask + 192);
+    unsigned* kmask = (unsigned*)(smem + DQ_MASK_OFF);
+    unsigned* blk = (unsigned*)(smem + DQ_BLK_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
     const int fk = lane >> 5, l31 = lane & 31;
     // persistent workgroups with the forward kernel's static rotation schedule (bridge_attn_fwd_kernel): item i = w + k P is
     // (sequence, head) i / n_t, query block (i + k) mod n_t
@@ -89,37 +107,77 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
     const long tok0 = (long)b * S;
-    const int len = p.kv_len ? p.kv_len[b] : S;
+    int len = p.kv_len ? p.kv_len[b] : S;
+    len = len < S ? len : S;
     const int q0w = qt * DQ_BQ + wave * 32;
     const bool active = q0w < S;
     int q = q0w + l31;
     const bool qin = q < S;
     q = qin ? q : S - 1;
+    int kend = (qt + 1) * DQ_BQ; kend = kend < S ? kend : S;
+    const int nkt = (kend + 63) / 64;                               // <= 64 (S <= 4096)
 
-    // every per-lane global operand of the prologue is requested before the first wait (one round trip instead of three: with one
-    // workgroup per CU nothing else covers them): modality byte, Q and dO fragments, L and D of this lane's query
-    // (the first K / V tile goes out first of all, both variants - see bridge_attn_fwd_kernel)
-    {
-        stage_t64(p.k_same + tok0 * p.ldk + h * D128, (unsigned)p.ldk * 2u, 0, S, smem, wave, lane);
-        stage_t64(p.v_same + tok0 * p.ldv + h * D128, (unsigned)p.ldv * 2u, 0, S, smem + 16384, wave, lane);
-        stage_t64(p.k_cross + tok0 * p.ldkc + h * D128, (unsigned)p.ldkc * 2u, 0, S, smem + DQ_VAR, wave, lane);
-        stage_t64(p.v_cross + tok0 * p.ldvc + h * D128, (unsigned)p.ldvc * 2u, 0, S, smem + DQ_VAR + 16384, wave, lane);
-    }
+    const bf16_t* ks_base = p.k_same + tok0 * p.ldk + h * D128;
+    const bf16_t* kc_base = p.k_cross + tok0 * p.ldkc + h * D128;
+    const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * D128;
+    const bf16_t* vc_base = p.v_cross + tok0 * p.ldvc + h * D128;
+    const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;
+
+    // ---- direct-to-LDS pieces: a 16-KiB tile is 16 pieces of 1 KiB (4 rows x 256 B); wave w moves pieces 2w, 2w + 1 of the K and
+    // of the V tile of a unit: rows 8w + (lane >> 4) and + 4, 16-byte chunk (lane & 15) ^ tswz(row).  tswz(row + 4) = tswz(row) ^ 1
+    // here (row >> 2 is even), so the second piece's per-lane offset is the first one's +- 16 bytes and its row step goes into the
+    // wave-uniform base: 4 offset registers + 1 for the four operands.
+    const int r0 = wave * 8 + (lane >> 4);
+    const int c0 = (lane & 15) ^ tswz(r0);
+    const int d16 = (c0 & 1) ? -16 : 16;
+    const unsigned ldkb_s = (unsigned)(p.ldk * 2), ldkb_c = (unsigned)(p.ldkc * 2), ldvb_s = (unsigned)(p.ldv * 2), ldvb_c = (unsigned)(p.ldvc * 2);
+    const unsigned oKs = (unsigned)(lane >> 4) * ldkb_s + (unsigned)(c0 << 4), oKc = (unsigned)(lane >> 4) * ldkb_c + (unsigned)(c0 << 4);
+    const unsigned oVs = (unsigned)(lane >> 4) * ldvb_s + (unsigned)(c0 << 4), oVc = (unsigned)(lane >> 4) * ldvb_c + (unsigned)(c0 << 4);
+    auto stage_unit = [&](const int t, const int var, const int st) {
+        const unsigned dst = lds0 + (unsigned)(st * DQ_STAGE_B + wave * 2048);
+        const long ldk_ = var ? p.ldkc : p.ldk, ldv_ = var ? p.ldvc : p.ldv;
+        const bf16_t* kbase = (var ? kc_base : ks_base) + ((long)t * 64 + wave * 8) * ldk_;
+        const bf16_t* vbase = (var ? vc_base : vs_base) + ((long)t * 64 + wave * 8) * ldv_;
+        if (t * 64 + 64 <= S) {
+            const unsigned ok = var ? oKc : oKs, ov = var ? oVc : oVs;
+            glds16_off_at(kbase, ok, dst); glds16_off_at(kbase + 4 * ldk_, ok + (unsigned)d16, dst + 1024);
+            glds16_off_at(vbase, ov, dst + DQ_TILE); glds16_off_at(vbase + 4 * ldv_, ov + (unsigned)d16, dst + DQ_TILE + 1024);
+            return;
+        }
+        // the sequence's last, ragged tile: rows clamped to the last token (their keys are masked); offsets from the tile's first row
+        const int lim = S - 1 - t * 64;                             // >= 0: the tile holds at least one token
+        const unsigned ldkb = var ? ldkb_c : ldkb_s, ldvb = var ? ldvb_c : ldvb_s;
+        const bf16_t* kt_ = kbase - (long)(wave * 8) * ldk_;
+        const bf16_t* vt_ = vbase - (long)(wave * 8) * ldv_;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int row = r0 + 4 * j;
+            row = row < lim ? row : lim;
+            const unsigned cc = (unsigned)((c0 ^ j) << 4);
+            glds16_off_at(kt_, (unsigned)row * ldkb + cc, dst + j * 1024);
+            glds16_off_at(vt_, (unsigned)row * ldvb + cc, dst + DQ_TILE + j * 1024);
+        }
+    };
+
+    // ---- prologue: every per-lane global operand is requested before the first wait (one round trip; with one workgroup per CU
+    // nothing else covers them); the first two stages are requested on the forward kernel's guess (tile 0, same), (tile 0, cross)
+    stage_unit(0, 0, 0);
+    stage_unit(0, 1, 1);
     const int q_vis_raw = p.flag[tok0 + q];
     bf16x8 qf[8], dof[8];
     {
         const bf16_t* qp = p.q + (tok0 + q) * p.ldq + h * D128 + fk * 8;
-        const bf16_t* dp = p.dout + (tok0 + q) * p.ldo + h * D128 + fk * 8;
+        const bf16_t* dp_ = p.dout + (tok0 + q) * p.ldo + h * D128 + fk * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 16); dof[ks] = *(const bf16x8*)(dp + ks * 16); }
+        for (int ks = 0; ks < 8; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 16); dof[ks] = *(const bf16x8*)(dp_ + ks * 16); }
     }
     const long sidx = ((long)b * p.H + h) * S + q;
     float nLq2 = -p.lse[sidx] * LOG2E;
     // D = sum_d dO . O of this lane's query (the softmax-backward row term) from the dO fragments already in flight + the O row:
-    // this lane's 64 channels here, the other half one permlane swap away - the separate delta pass over dO, O and O_lo is gone;
-    // the dK / dV pass reads what the fk = 0 lanes store below
-    bf16x8 of[8], ol[8];
+    // this lane's 64 channels here, the other half one permlane swap away; the dK / dV pass reads what the fk = 0 lanes store
+    float Dq = 0.f;
     {
+        bf16x8 of[8], ol[8];
         const bf16_t* op = p.out + (tok0 + q) * p.ldout + h * D128 + fk * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) of[ks] = *(const bf16x8*)(op + ks * 16);
@@ -128,165 +186,237 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dq_kernel(const Bridge
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) ol[ks] = *(const bf16x8*)(lp + ks * 16);
         }
+        modality_masks(p.flag + tok0, S, kmask, tid, 512);
+        if (tid < 8) blk[tid] = 0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = bf2f((bf16_t)of[ks][e]);
+                if (p.out_lo) o += bf2f((bf16_t)ol[ks][e]);
+                Dq = __builtin_fmaf(o, bf2f((bf16_t)dof[ks][e]), Dq);
+            }
     }
-    modality_masks(p.flag + tok0, S, kmask, tid, 512);
-    float Dq = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float o = bf2f((bf16_t)of[ks][e]);
-            if (p.out_lo) o += bf2f((bf16_t)ol[ks][e]);
-            Dq = __builtin_fmaf(o, bf2f((bf16_t)dof[ks][e]), Dq);
-        }
     Dq = half_swap_sum(Dq);
     if (fk == 0 && qin) p.delta[sidx] = Dq;
     const bool q_vis = q_vis_raw != 0;
-    if (tid < 2) qpres[tid] = 0;
     __syncthreads();
-    if (__ballot(qin && fk == 0 && q_vis)) if (lane == 0) atomicOr(&qpres[1], 1);
-    if (__ballot(qin && fk == 0 && !q_vis)) if (lane == 0) atomicOr(&qpres[0], 1);
-    __syncthreads();
-    const bool blkL = __builtin_amdgcn_readfirstlane(qpres[0]) != 0, blkV = __builtin_amdgcn_readfirstlane(qpres[1]) != 0;
-    const bool wV = __ballot(q_vis && qin) != 0, wL = __ballot(!q_vis && qin) != 0;
 
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { pin(qf[ks]); pin(dof[ks]); }   // prologue loads have landed before any LDS-DMA is in flight
-    pin(nLq2); pin(Dq);
-    const bf16_t* ks_base = p.k_same + tok0 * p.ldk + h * D128;
-    const bf16_t* kc_base = p.k_cross + tok0 * p.ldkc + h * D128;
-    const bf16_t* vs_base = p.v_same + tok0 * p.ldv + h * D128;
-    const bf16_t* vc_base = p.v_cross + tok0 * p.ldvc + h * D128;
+    // ---- per-wave classification of every key tile, lane = tile (as the forward kernel; no left padding in the backward)
+    const bool wV = __ballot(q_vis && qin) != 0, wL = __ballot(!q_vis && qin) != 0;
+    unsigned m_same = 0, m_cross = 0;
+    {
+        const int kv0 = lane * 64;
+        const u64 mm = (u64)kmask[2 * lane] | ((u64)kmask[2 * lane + 1] << 32);
+        const u64 rng = bits_below64(len - kv0);
+        const bool kV = (mm & rng) != 0, kL = (~mm & rng) != 0;
+        const bool in = active && lane < nkt && kv0 <= q0w + 31;
+        const bool wsame = in && ((wL && kL) || (wV && kV)), wcross = in && ((wL && kV) || (wV && kL));
+        const bool full = kv0 + 63 <= q0w && kv0 + 64 <= len;
+        const bool plain = full && !(wsame && wcross);
+        m_same = wsame ? (plain ? 1u : 2u) : 0u;
+        m_cross = wcross ? (plain ? 1u : 2u) : 0u;
+        const u64 b_same = __ballot(wsame), b_cross = __ballot(wcross);
+        if (lane == 0) {
+            if ((unsigned)b_same) atomicOr(&blk[0], (unsigned)b_same);
+            if ((unsigned)(b_same >> 32)) atomicOr(&blk[1], (unsigned)(b_same >> 32));
+            if ((unsigned)b_cross) atomicOr(&blk[2], (unsigned)b_cross);
+            if ((unsigned)(b_cross >> 32)) atomicOr(&blk[3], (unsigned)(b_cross >> 32));
+        }
+    }
+    __syncthreads();
+    const u64 same_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[0]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[1]) << 32);
+    const u64 cross_blk = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[2]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[3]) << 32);
+    const int U = __popcll(same_blk) + __popcll(cross_blk);         // units of this workgroup (<= 128)
+    unsigned tab0, tab1;                                            // lane i: entry of unit i / unit 64 + i (0 past the end)
+    {
+        unsigned short* tab = (unsigned short*)(smem + DQ_TAB_OFF) + wave * 128;
+        if (lane < nkt) {
+            const u64 below = bits_below64(lane);
+            const int u0 = __popcll(same_blk & below) + __popcll(cross_blk & below);
+            const bool hs = (same_blk >> lane) & 1ull, hc = (cross_blk >> lane) & 1ull;
+            if (hs) tab[u0] = (unsigned short)(m_same | (unsigned)(lane << 3));
+            if (hc) tab[u0 + (hs ? 1 : 0)] = (unsigned short)(m_cross | 4u | (unsigned)(lane << 3));
+        }
+        tab0 = lane < U ? tab[lane] : 0u;                           // (same wave, in-order LDS queue: no barrier)
+        tab1 = lane + 64 < U ? tab[lane + 64] : 0u;
+    }
+    auto entry = [&](const int u) -> unsigned {                     // u wave-uniform; 0 past the end
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)tab0, u & 63), c = (unsigned)__builtin_amdgcn_readlane((int)tab1, u & 63);
+        return u < 64 ? a : (u < 128 ? c : 0u);
+    };
+    {
+        const unsigned e0 = entry(0), e1 = entry(1);
+        const bool ok0 = U < 1 || (e0 >> 2) == 0u, ok1 = U < 2 || (e1 >> 2) == 1u;       // (tile 0, same) / (tile 0, cross)
+        if (!ok0 || !ok1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!ok0) stage_unit((int)(e0 >> 3), (int)((e0 >> 2) & 1u), 0);
+            if (!ok1) stage_unit((int)(e1 >> 3), (int)((e1 >> 2) & 1u), 1);
+        }
+    }
+
+    // ---- fragment addressing: per-lane constants XOR a compile-time constant
+    int xr, xt0, xt1;
+    {
+        const int pp = lane & 15, g16 = (lane >> 4) & 1;
+        const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
+        xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
+        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
+        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4) + 2048;
+    }
 
     f32x16 dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    f32x16 sA, sB, dA, dB;                                          // S^T and dP^T of the unit in flight: key halves 0 / 1
+    union PK { bf16x8 v; unsigned u[4]; };
+    PK pk[4];                                                       // dS^T of the unit in flight as the four 16-key B operands
+    const int qabs = q0w + l31;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { pin(qf[ks]); pin(dof[ks]); }   // prologue loads have landed before the loop's LDS-DMA traffic
+    pin(nLq2); pin(Dq);
 
-    int kend = (qt + 1) * DQ_BQ; kend = kend < S ? kend : S;
-    const int nkt = (kend + 63) / 64;
-    // modality content of `n` (32 or 64) keys starting at mask word w0, valid keys only (wave-uniform by construction)
-    auto key_mods = [&](int w0, int n, bool& kV, bool& kL) {
-        unsigned long long m = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0]);
-        if (n == 64) m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kmask[w0 + 1]) << 32;
-        int nvalid = S - w0 * 32; nvalid = nvalid > n ? n : nvalid;
-        const unsigned long long full = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-        kV = (m & full) != 0; kL = ((~m) & full) != 0;
-    };
-    auto stage = [&](int buf, int t) {
-        bool kV, kL;
-        key_mods(2 * t, 64, kV, kL);
-        char* dst = smem + buf * DQ_STAGE_B;
-        if ((blkL && kL) || (blkV && kV)) {
-            stage_t64(ks_base, (unsigned)p.ldk * 2u, t * 64, S, dst, wave, lane);
-            stage_t64(vs_base, (unsigned)p.ldv * 2u, t * 64, S, dst + 16384, wave, lane);
+    union VA { bf16x8 v; s16x4 h2[2]; };
+    // M phase.  Fragment i: 0-15 = K_u^T (16-key step i >> 2, 32-line d block i & 3), transposed reads; 16-47 = row reads of the next
+    // unit, j = i - 16: k-step j >> 2, operand j & 3 = K half 0 / K half 1 / V half 0 / V half 1 (four accumulators in rotation).
+    // ONE ring of NF fragments, each requested NF - 1 MFMAs ahead of its consumer.
+    constexpr int NF = 4;
+    auto m_phase = [&](auto dq_c, auto nx_c, const char* cur, const char* nxt) {
+        constexpr bool DQ = decltype(dq_c)::value, NX = decltype(nx_c)::value;
+        constexpr int N = (DQ ? 16 : 0) + (NX ? 32 : 0), I0 = DQ ? 0 : 16;
+        bf16x8 F[NF];
+        auto fread = [&](const int i) -> bf16x8 {
+            if (i < 16) {
+                const char* a = cur + (i >> 2) * 4096;
+                VA t;
+                t.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + (xt0 ^ ((i & 3) << 6))));
+                t.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + (xt1 ^ ((i & 3) << 6))));
+                return t.v;
+            }
+            const int j = i - 16, ks = j >> 2, w = j & 3;
+            return *(const bf16x8*)(nxt + (w >> 1) * DQ_TILE + (w & 1) * 8192 + (xr ^ (ks << 5)));
+        };
+        if constexpr (N > 0) {
+#pragma unroll
+            for (int n = 0; n < NF; ++n) F[n] = fread(I0 + n);
+            if constexpr (NX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; dA[r] = 0.f; dB[r] = 0.f; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const int i = I0 + n;
+                if (i < 16) dq[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], pk[i >> 2].v, dq[i & 3], 0, 0, 0);
+                else {
+                    const int j = i - 16, ks = j >> 2, w = j & 3;
+                    if (w == 0) sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], qf[ks], sA, 0, 0, 0);
+                    else if (w == 1) sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], qf[ks], sB, 0, 0, 0);
+                    else if (w == 2) dA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], dof[ks], dA, 0, 0, 0);
+                    else dB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], dof[ks], dB, 0, 0, 0);
+                }
+                if (n + NF < N) F[n % NF] = fread(i + NF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if ((blkL && kV) || (blkV && kL)) {
-            stage_t64(kc_base, (unsigned)p.ldkc * 2u, t * 64, S, dst + DQ_VAR, wave, lane);
-            stage_t64(vc_base, (unsigned)p.ldvc * 2u, t * 64, S, dst + DQ_VAR + 16384, wave, lane);
-        }
     };
-    int xr = 0, xt0 = 0, xt1 = 0;
-    {
-        const int pp = lane & 15, g16 = (lane >> 4) & 1;
-        const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
-        xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
-        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
-        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
-    }
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-        if (!active) continue;
+    // per-lane key mask of a MASKED unit: key <= query (causal), key < len (padding), and the pair's modality relation == the
+    // unit's variant.  One 32-bit word per key half, shifted by 4 fk so that the bit positions below are compile-time.
+    auto key_masks = [&](const int kt, const int var, unsigned& v0, unsigned& v1) {
         const int kv0 = kt * 64;
-        if (kv0 > q0w + 31) continue;
-        asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1));
-        auto rd_row = [&](const char* tile, int ks) -> bf16x8 {
-            return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
-        };
-        auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
-            union { bf16x8 v; s16x4 h2[2]; } u;
-            u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
-            u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
-            return u.v;
-        };
-#pragma unroll 1
-        for (int kh = 0; kh < 2; ++kh) {
-            const int k0 = kv0 + kh * 32;
-            if (k0 > q0w + 31 || k0 >= S) break;
-            bool hV, hL;
-            key_mods(2 * kt + kh, 32, hV, hL);
-            const bool hsame = (wL && hL) || (wV && hV);
-            const bool hcross = (wL && hV) || (wV && hL);
-            const bool mixed = hsame && hcross;
-            const char* skc = smem + cur * DQ_STAGE_B + DQ_VAR + kh * 8192;     // cross variant: K rows of this half (V at +16384)
-            const char* img1 = hsame ? skc - DQ_VAR : skc;                      // primary variant
-            f32x16 s, dp;
+        const unsigned km0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt]);
+        const unsigned km1 = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + 1]);
+        const unsigned flip = ~((q_vis ? ~0u : 0u) ^ (var ? ~0u : 0u));   // cross pair <=> key bit != query bit; wanted <=> cross == var
+        const int hi = qabs < len - 1 ? qabs : len - 1;             // last valid key of this row
+        const u64 rng = bits_below64(hi - kv0 + 1);
+        v0 = ((km0 ^ flip) & (unsigned)rng) >> (4 * fk);
+        v1 = ((km1 ^ flip) & (unsigned)(rng >> 32)) >> (4 * fk);
+    };
+
+    const u64 act0 = __ballot((tab0 & 3u) != 0), act1 = __ballot((tab1 & 3u) != 0);
+    const int Uw = act1 ? 128 - (int)__builtin_clzll(act1) : (act0 ? 64 - (int)__builtin_clzll(act0) : 0);
+    auto stage_of = [&](const int u) -> const char* { return smem + (u & (DQ_NSTAGE - 1)) * DQ_STAGE_B; };
+    // DS phase of unit u (entry e): request stage u + 2 (entry e2), dS^T = P (dP - D) -> pk, wait for the stage the next M phase reads
+    auto ds_phase = [&](const int u, const unsigned e, const unsigned e2) {
+        const bool issue = u + 2 < U;
+        if (issue) stage_unit((int)(e2 >> 3), (int)((e2 >> 2) & 1u), (u + 2) & (DQ_NSTAGE - 1));
+        float a[16], c[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) {
+            a[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sA[r], p.sl2, nLq2));
+            c[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sB[r], p.sl2, nLq2));
+        }
+        if ((e & 3u) != 1u) {                                       // masked unit (or a skipped one inside the wave's range: empty key set)
+            unsigned v0 = 0u, v1 = 0u;
+            if ((e & 3u) == 2u) key_masks((int)(e >> 3), (int)((e >> 2) & 1u), v0, v1);
+            const float zero = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(img1, ks), qf[ks], s, 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(img1 + 16384, ks), dof[ks], dp, 0, 0, 0);
-            unsigned crossbits = 0;
-            if (mixed) {                                            // both variants present: per-element select
-                f32x16 t, u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { t[r] = 0.f; u[r] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(skc, ks), qf[ks], t, 0, 0, 0);
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(skc + 16384, ks), dof[ks], u, 0, 0, 0);
-                const unsigned km = (unsigned)__builtin_amdgcn_readfirstlane((int)kmask[2 * kt + kh]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    const bool cr = (((km >> kl) & 1u) != 0) != q_vis;
-                    s[r] = cr ? t[r] : s[r];
-                    dp[r] = cr ? u[r] : dp[r];
-                    crossbits |= (cr ? 1u : 0u) << r;
-                }
-            }
-            // P = exp2(S*sl2 - L) (recomputed), dS^T = P (dP - D)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.sl2, nLq2));
-            if (k0 + 31 > q0w || k0 + 32 > len) {                   // causal diagonal / padded keys inside this half
-                const int qabs = q0w + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    s[r] = (key <= qabs && key < len) ? s[r] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= dp[r] - Dq;
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                union { bf16x8 v; unsigned u[4]; } pk, pk2;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pk.u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
-                if (mixed) {                                        // split dS by variant (bf16 pair masks)
-                    const unsigned cr = crossbits >> (8 * sx);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned keep2 = (((cr >> (2 * j)) & 1u) ? 0xffffu : 0u) | (((cr >> (2 * j + 1)) & 1u) ? 0xffff0000u : 0u);
-                        pk2.u[j] = pk.u[j] & keep2;
-                        pk.u[j] &= ~keep2;
-                    }
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(img1, dt, sx), pk.v, dq[dt], 0, 0, 0);
-                if (mixed) {
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(skc, dt, sx), pk2.v, dq[dt], 0, 0, 0);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int bpos = (r & 3) + 8 * (r >> 2);            // local key of accumulator row r (minus 4 fk)
+                const u64 k0 = __builtin_amdgcn_ballot_w64(((v0 >> bpos) & 1u) != 0), k1 = __builtin_amdgcn_ballot_w64(((v1 >> bpos) & 1u) != 0);
+                asm volatile("v_cndmask_b32 %0, %2, %0, %1" : "+v"(a[r]) : "s"(k0), "v"(zero));
+                asm volatile("v_cndmask_b32 %0, %2, %0, %1" : "+v"(c[r]) : "s"(k1), "v"(zero));
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a[r] *= dA[r] - Dq; c[r] *= dB[r] - Dq; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r0_ = 8 * (st & 1) + 2 * j;
+                pk[st].u[j] = st < 2 ? pack2bf(a[r0_], a[r0_ + 1]) : pack2bf(c[r0_], c[r0_ + 1]);
+            }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) pin(pk[st].v);               // HERE: keep the dS arithmetic out of the M phase's MFMA stream
+        if (grp == 0) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto m_end = [&]() {
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 1: its pieces of stage u + 2, requested in its DS_u
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                // stages 0 and 1 landed
+    unsigned e_cur = entry(0), e_nxt = entry(1), e_dma = entry(2);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    if (Uw > 0) m_phase(std::false_type{}, std::true_type{}, nullptr, stage_of(0));
+    __builtin_amdgcn_s_barrier();
+    int u = 0;
+    for (; u + 1 < Uw; ++u) {
+        ds_phase(u, e_cur, e_dma);
+        __builtin_amdgcn_s_setprio(1);
+        m_phase(std::true_type{}, std::true_type{}, stage_of(u), stage_of(u + 1));
+        __builtin_amdgcn_s_setprio(0);
+        m_end();
+        e_cur = e_nxt; e_nxt = e_dma; e_dma = entry(u + 3);
     }
+    if (u < Uw) {                                                   // this wave's last unit: nothing to prepare
+        ds_phase(u, e_cur, e_dma);
+        __builtin_amdgcn_s_setprio(1);
+        m_phase(std::true_type{}, std::false_type{}, stage_of(u), nullptr);
+        __builtin_amdgcn_s_setprio(0);
+        m_end();
+        e_cur = e_nxt; e_nxt = e_dma; e_dma = entry(u + 3);
+        ++u;
+    }
+    for (; u < U; ++u) {                                            // units above this wave's diagonal: staging duty only
+        const bool issue = u + 2 < U;
+        if (issue) stage_unit((int)(e_dma >> 3), (int)((e_dma >> 2) & 1u), (u + 2) & (DQ_NSTAGE - 1));
+        if (grp == 0) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        m_end();
+        e_cur = e_nxt; e_nxt = e_dma; e_dma = entry(u + 3);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                     // re-align the two groups
+
     __syncthreads();
     constexpr int OROW = 264;
     char* so = smem + wave * (32 * OROW);
@@ -371,13 +501,19 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
     // the dispatch of each of its (8192 / 256 =) 32 one-per-CU workgroups.  An XCD's 32 workgroups stream the Q / dO tiles of the
     // same few (sequence, head) pairs at a time through that XCD's L2.
     const int nitems = p.B * p.H * p.n_t;
-    const int P = (int)gridDim.x;
-    const int w_id = xcd_remap(blockIdx.x, P);
     int npass = 0;
     if (tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;   // the pairs' sequence words count on across items
+#if LIBRA_DKV_PERSIST
+    const int P = (int)gridDim.x;
+    const int w_id = xcd_remap(blockIdx.x, P);
 #pragma unroll 1
     for (int step = 0, item = w_id; item < nitems; ++step, item += P) {
     const int ktile = (item % p.n_t + step) % p.n_t;
+#else
+    {
+    const int item = xcd_remap(blockIdx.x, nitems);
+    const int ktile = item % p.n_t;                              // low key tiles see the most queries: they come first
+#endif
     const int bh = item / p.n_t;
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
@@ -701,7 +837,9 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.n_t = (int)((S + 63) / 64);
     nblk = (long)B * H * a.n_t;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
+#if LIBRA_DKV_PERSIST
     nblk = persistent_grid(nblk, a.n_t);
+#endif
     hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -935,3 +935,34 @@ def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb,
                                           dqkv.stride(0), dkb.data_ptr(), dkb.stride(0), *extra, N, S, H, _ptr(positions), pstride,
                                           _stream())
     _lib.check(rc, "rope_bridge_bwd")
+
+
+# ---- per-launch timing of the attention and row kernels (bench.py's `roofline.by_kernel`) ----------------------------------
+# work = (FLOP, algorithmic HBM bytes, tag): attention FLOPs are the causal-minimal count bench.py's roofline uses
+# (2 products x 2 S(S+1)/2 x 128 per head forward, 2.5 x that backward); row kernels count each operand / result row once.
+def _attn_work(mult, tag):
+    def work(q, k_same, k_cross, v_same, v_cross, *rest, **kw):
+        B, S, H = [x for x in rest if isinstance(x, int)][:3]
+        n = q.shape[0] * H * 128 * 2
+        return (mult * B * H * 4.0 * (S * (S + 1) / 2) * 128, (5 if mult == 1.0 else 13) * n, tag)
+    return work
+
+
+def _rows_work(n_mats, tag, arg=0):
+    def work(*a, **kw):
+        t = a[arg]
+        return (0.0, float(n_mats) * t.shape[0] * t.shape[1] * 2, tag)
+    return work
+
+
+bridge_attn_fwd = _profiled("attn_fwd", _attn_work(1.0, "bridge_attn_fwd"))(bridge_attn_fwd)
+bridge_attn_bwd = _profiled("attn_bwd", _attn_work(2.5, "bridge_attn_bwd"))(bridge_attn_bwd)
+rmsnorm_routed = _profiled("row", _rows_work(2, "rmsnorm_routed"))(rmsnorm_routed)
+rmsnorm_routed_bwd = _profiled("row", _rows_work(4, "rmsnorm_routed_bwd"))(rmsnorm_routed_bwd)
+swiglu = _profiled("row", _rows_work(3, "swiglu"))(swiglu)
+swiglu_bwd = _profiled("row", _rows_work(5, "swiglu_bwd", arg=1))(swiglu_bwd)
+# rope_bridge: reads q | k | v ([N, 3 H 128] = 3 matrices of dq's width), writes q, k_same in place and K_cross, V_cross
+rope_bridge = _profiled("row", lambda qkv, *a, **kw: (0.0, 7.0 * qkv.shape[0] * (qkv.shape[1] // 3) * 2, "rope_bridge"))(rope_bridge)
+rope_bridge_bwd = _profiled("row", _rows_work(8, "rope_bridge_bwd"))(rope_bridge_bwd)
+ce_rows = _profiled("row", _rows_work(1, "ce_rows"))(ce_rows)
+ce_rows_bwd = _profiled("row", _rows_work(2, "ce_rows_bwd"))(ce_rows_bwd)

@@ -200,10 +200,19 @@ def test_vq_indices_at_baseline_batch_vs_fp64_oracle():
     parity_report(f"[configs[1] VQ encode B=32 E=512, two-sided] sign-bit flips vs the float64 chain: ours {nflip}, the reference's bf16 "
                   f"arithmetic (oracle op by op in bf16) {n_theirs}; ours vs theirs {n_ours_theirs} of {N * Q * 9} bits "
                   f"({int((idx_b != idx).sum())} of {N * Q} indices)")
-    assert n_ours_theirs <= max(8, 2 * n_theirs + 4), (n_ours_theirs, n_theirs)
+    # (bits where ours != theirs are bits where one of the two left the float64 chain: a count identity, not a tolerance)
+    assert n_ours_theirs <= nflip + n_theirs, (n_ours_theirs, nflip, n_theirs)
     parity_report(f"[configs[1] VQ encode B=32 E=512] {N * Q * 9} sign bits: stage A (h rounding) {nA} of {h2d.numel()} elements "
                   f"differ from bf16(h64), all within fp32 accumulation noise of a rounding boundary; stage B (bits on the kernel's own h) {nB} flips, max margin "
                   f"{mB:.2e}; end-to-end vs float64 chain: {nflip} bit flips in {nidx} of {N * Q} indices, largest |x64| among "
                   f"flips {mflip:.2e}, min |x64| over all bits {min_margin:.2e}")
-    assert nflip <= max(4, int(2e-4 * N * Q * 9)) and mflip < 2e-2, (nflip, mflip)
+    # Gate = the margin rule, nothing looser (observed on MI355X: 1 flip at |x64| = 1.7e-5; the reference's own bf16 arithmetic: 4).
+    # A bit may differ from the float64 chain only where the kernel's h is the ADJACENT bf16 of h64 (stage A, checked above) and
+    # that one-ulp difference, pushed through project_in, covers the pre-sign value:  |x64| <= sum_c |W_in[bit, c]| |h2d - hb|[c]
+    # (+ the stage-B margin 1e-5); and no more flips than the reference's own bf16 run makes, + 2.
+    reach = ((h2d.double() - hb.double()).abs() @ Wi.abs().t()).view(N, Q, 9)
+    if nflip:
+        over = (x64.abs().view(N, Q, 9) - reach)[flip]
+        assert float(over.max()) <= 1e-5, f"a sign bit flipped outside the reach of the h rounding: {float(over.max()):.3e}"
+    assert nflip <= n_theirs + 2 and mflip < 1e-3, (nflip, n_theirs, mflip)
     assert torch.equal(ids[:, :, 1:-1].permute(1, 2, 0).reshape(N, Q) - 32000, idx)
