@@ -581,6 +581,33 @@ def gflop_per_image(workload, seq=2048, full_finetune=False):
     return GFLOP_FWD_PER_IMG + (fwd + bwd) / 1e9
 
 
+class _Watchdog:
+    """If `cancel()` has not been called after `seconds`, print one line per rank and re-execute this rank with the plain
+    all-reduce and no probe (every rank of a hung collective trips its own watchdog within the same second; the new processes
+    rendezvous again on the launcher's MASTER_ADDR / MASTER_PORT).  A rank that is already a fallback gives up instead (exit 4)."""
+
+    def __init__(self, seconds, rank, what, argv, fallback):
+        import threading
+        self.t = threading.Timer(seconds, self._fire, (seconds, rank, what, list(argv), fallback))
+        self.t.daemon = True
+        if seconds > 0:
+            self.t.start()
+
+    def cancel(self):
+        self.t.cancel()
+
+    @staticmethod
+    def _fire(seconds, rank, what, argv, fallback):
+        print(f"[bench] rank {rank}: watchdog: {what} did not finish in {seconds:.0f} s", file=sys.stderr, flush=True)
+        if "--fallback-from" in argv:
+            os._exit(4)
+        args = [a for a in argv[1:]]
+        if "--exchange" in args:
+            i = args.index("--exchange")
+            del args[i:i + 2]
+        os.execv(sys.executable, [sys.executable, os.path.abspath(argv[0])] + args + ["--exchange", "allreduce", "--fallback-from", fallback])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -598,6 +625,13 @@ def main():
                     help="configs[4]: every parameter trainable (instruction recipe) instead of the frozen-language pretraining policy")
     ap.add_argument("--exchange", choices=["auto", "allreduce", "rs_ag", "zero1"], default="auto",
                     help="N>1 gradient exchange; auto = probe allreduce and rs_ag during warm-up and keep the faster")
+    ap.add_argument("--cu-reserve", type=int, default=0,
+                    help="N>1: run the step on a CU-masked stream that leaves this many compute units to RCCL's reduction kernels "
+                         "(and size the persistent attention grids to the rest); reported in extra.cu_budget")
+    ap.add_argument("--probe-watchdog-s", type=float, default=120.0,
+                    help="N>1: if the exchange probe has not finished after this many seconds every rank re-executes itself with "
+                         "--exchange allreduce (no probe), so that a mode that hangs on this node still yields a result")
+    ap.add_argument("--fallback-from", default=None, help=argparse.SUPPRESS)   # set by the watchdog's re-exec: what hung
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)         # child-process entry of cpu_baseline()
     ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
@@ -661,17 +695,47 @@ def main():
     if world > 1 and rank == 0:
         extra["preflight"] = preflight(world, backend, init_output)
         note(f"preflight: {extra['preflight']}")
+    cu = None
+    if args.cu_reserve > 0:
+        from libra_amd import kernels as K
+        cu = K.ReservedCUStream(args.cu_reserve)
+        cu.__enter__()                                   # every step below (probe, timed region, diagnostics) runs on the masked stream
+        extra["cu_budget"] = {"reserved_for_rccl": cu.reserve, "compute_cus": cu.cus, "physical_cus": K.cu_count()}
+        note(f"cu budget: {extra['cu_budget']}")
+    if args.fallback_from:
+        extra["exchange_fallback"] = f"the probe of {args.fallback_from!r} did not finish in {args.probe_watchdog_s:.0f} s; re-executed with allreduce"
     if world > 1 and args.exchange == "auto" and not args.with_optimizer:
         # probe both exchange algorithms on this node (xGMI full mesh: direct reduce-scatter + all-gather vs whatever RCCL's
-        # all-reduce picks) and keep the faster for the timed region; both numbers are reported
-        probe = {}
+        # all-reduce picks) and keep the faster for the timed region; both numbers are reported.  A mode that RAISES on any rank is
+        # dropped on every rank (the ranks agree through a MIN all-reduce of their success flags, made in the mode that worked);
+        # a mode that HANGS trips the watchdog, which re-executes every rank with the plain all-reduce.
+        probe, failed = {}, {}
         for m in ("allreduce", "rs_ag"):
-            w.buckets.mode = m
-            probe[m] = timed(w, 2, 1, world, device) / 2 * 1e3
+            dog = _Watchdog(args.probe_watchdog_s, rank, f"exchange probe '{m}'", sys.argv, fallback=m)
+            ok = 1.0
+            try:
+                w.buckets.mode = m
+                probe[m] = timed(w, 2, 1, world, device) / 2 * 1e3
+            except Exception as e:
+                ok = 0.0
+                failed[m] = repr(e)[:200]
+                print(f"[bench] rank {rank}: exchange probe '{m}' failed: {failed[m]}", file=sys.stderr, flush=True)
+            finally:
+                dog.cancel()
+            w.buckets.mode = "allreduce"
+            flag = torch.tensor([ok], device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                probe.pop(m, None)
+                failed.setdefault(m, "failed on another rank")
+        if not probe:
+            raise SystemExit(f"every exchange mode failed on this node: {failed}")
         mode = min(probe, key=probe.get)
         w.buckets.mode = mode
         extra["exchange_probe_ms_per_step"] = {k: round(v, 2) for k, v in probe.items()}
-        note(f"exchange probe {extra['exchange_probe_ms_per_step']} -> {mode}")
+        if failed:
+            extra["exchange_probe_failed"] = failed
+        note(f"exchange probe {extra['exchange_probe_ms_per_step']} -> {mode}" + (f" (failed: {failed})" if failed else ""))
 
     dt = timed(w, args.steps, args.warmup, world, device)
     ms = dt / args.steps * 1e3

@@ -3,4 +3,4 @@
 set -u
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_decoder_kernels_gpu.py tests/test_decoder_model_gpu.py tests/test_trainer_gpu.py tests/test_dp_gpu.py tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout 600 bash tools/gpu_ab_step.sh
+timeout 600 bash experiments/visit_scripts/gpu_ab_step.sh

@@ -1,6 +1,6 @@
 #!/bin/bash
 # one GPU visit for an attention change: parity of the working tree's library first, then a same-box A/B of prebuilt libraries
-#   gpurun -- './tools/gpu_attn_visit.sh fwd base v3 v3np'      (first argument: fwd | bwd | all)
+#   gpurun -- './experiments/visit_scripts/gpu_attn_visit.sh fwd base v3 v3np'      (first argument: fwd | bwd | all)
 set -u
 mkdir -p gpurun_out
 cd "$(dirname "$0")/.."

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 evidence visit A: HBM-traffic PMC passes of the headline workload FIRST (so the bench line of the same visit carries a
 # non-stale roofline.traffic), then the driver's bench command, rocprof kernel stats, and the configs[3] / configs[4] shaped steps.
-#   gpurun -- 'LIBRA_HEAD=<git rev-parse --short HEAD> tools/gpu_r4_final.sh'
+#   gpurun -- 'LIBRA_HEAD=<git rev-parse --short HEAD> experiments/visit_scripts/gpu_r4_final.sh'
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box sweep of prebuilt libraries over a GEMM shape set:  gpurun -- 'SWEEP_TILES=256,X tools/gpu_sweep_ab.sh text lib1 lib2'
+# same-box sweep of prebuilt libraries over a GEMM shape set:  gpurun -- 'SWEEP_TILES=256,X experiments/visit_scripts/gpu_sweep_ab.sh text lib1 lib2'
 set -u
 mkdir -p gpurun_out
 cd "$(dirname "$0")/.."

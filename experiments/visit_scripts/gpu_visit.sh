@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit (round 2): parity tests, smoke, the driver's bench command, rocprof kernel stats of exactly that
-# workload.  Everything lands in gpurun_out/.   usage: gpurun -- ./tools/gpu_visit.sh [tests|notests] [extra pytest args]
+# workload.  Everything lands in gpurun_out/.   usage: gpurun -- ./experiments/visit_scripts/gpu_visit.sh [tests|notests] [extra pytest args]
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -255,9 +255,9 @@ int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_same, int64_
  * dq [B*S,H*128] (w.r.t. the rotated q) and the four operand gradients dK_same, dK_cross, dV_same, dV_cross
  * ([B*S, H*128], row stride ldg).  `out` (+ optional `out_lo`) is the forward output (D = rowsum(dO*O) is formed by the dQ pass
  * from the dO fragments it already holds and handed to the dK / dV pass through `delta` [B,H,S], scratch).
- * err_word (device int32, 4-byte aligned, or NULL): sticky error bits OR-ed in by the kernels, never cleared by them - bit 0 =
- * a bounded in-workgroup wait of the dK / dV pass ran out (its results are then undefined).  The launch itself still returns
- * LIBRA_OK (the library never synchronises); the caller reads the word when it next reads from the device anyway.          */
+ * err_word (device int32, 4-byte aligned, or NULL): sticky error word.  Rounds 3-4 raised bit 0 when the dK / dV pass's bounded
+ * in-workgroup wait ran out; since round 5 the pass synchronises with workgroup barriers only and never writes the word (the
+ * parameter stays for ABI stability and for future device-side checks).                                                      */
 int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                           int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
                           const void* out, const void* out_lo, int64_t ldout, const void* dout, int64_t lddo, const uint8_t* flag,
@@ -390,6 +390,20 @@ int libra_adamw_step(float* master, float* m, float* v, const void* grad, void* 
 size_t libra_sumsq_workspace_bytes(int64_t n);
 int libra_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* ---- compute-unit budget (data-parallel overlap) ------------------------------------------------------------
+ * The reference overlaps DeepSpeed's reduce-scatter with backward (libra/configs/deepspeed_configs/ZeRO-2.json:15-21,
+ * "overlap_comm": true); on MI355X RCCL's reduction kernels need compute units of their own while the GEMM / attention kernels
+ * (one 128-KiB-LDS workgroup per CU) occupy all 256.  Two knobs, both off by default:
+ *  - libra_stream_create_cu_reserved: a HIP stream whose kernels may use all CUs EXCEPT `reserve_cus` of them (a CU mask with
+ *    the highest `reserve_cus` bits cleared - the mask is dealt round-robin over the 8 XCDs, so 8 = one CU per XCD); the caller
+ *    runs the step on it (torch.cuda.ExternalStream) and leaves RCCL on its own unmasked stream.  *cus_out = CUs left.
+ *  - libra_set_cu_budget: the PERSISTENT kernels (bridge attention forward / dQ pass) size their grid to `cus` workgroups
+ *    instead of one per physical CU (0 = all).  Returns the previous value.  Thread-safe, takes effect at the next launch. */
+int libra_stream_create_cu_reserved(int32_t reserve_cus, void** stream_out, int32_t* cus_out);
+int libra_stream_destroy(void* stream);
+int libra_set_cu_budget(int32_t cus);
+int libra_get_cu_count(void);
 
 #ifdef __cplusplus
 }

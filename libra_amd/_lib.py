@@ -82,9 +82,13 @@ SIGNATURES = {
     "libra_rank_outer_wgrad": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I, _I64, _I64, _P, C.c_size_t, _P],
     "libra_sumsq_workspace_bytes": [_I64],
     "libra_sumsq_bf16": [_P, _I64, _P, _I, _P, C.c_size_t, _P],
+    "libra_stream_create_cu_reserved": [C.c_int32, _P, _P],
+    "libra_stream_destroy": [_P],
+    "libra_set_cu_budget": [C.c_int32],
+    "libra_get_cu_count": [],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class LibraHipError(RuntimeError):

@@ -595,16 +595,8 @@ extern "C" int libra_bridge_attn_fwd(const void* q, int64_t ldq, const void* k_s
     a.sl2 = scale * 1.4426950408889634f;
     const long nitems = (long)B * H * a.n_qt;
     if (nitems > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-    // persistent grid: one workgroup per CU, rounded down to a multiple of n_qt (the kernel's rotation needs it), at most one per item
-    static std::atomic<int> n_cu{0};              // (benign race: every thread stores the same value)
-    if (!n_cu) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        n_cu = cus;
-    }
-    long nblk = (long)n_cu / a.n_qt * a.n_qt;
-    if (nblk < a.n_qt) nblk = a.n_qt;
-    if (nblk > nitems) nblk = nitems;
+    // persistent grid: one workgroup per (budgeted) CU, a multiple of n_qt (the kernel's rotation needs it), at most one per item
+    const long nblk = persistent_grid(nitems, a.n_qt);
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS);

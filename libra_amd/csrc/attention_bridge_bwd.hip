@@ -6,24 +6,14 @@
 // (the four operand gradients dK_same, dK_cross, dV_same, dV_cross are folded back onto k, kb, v, vb by
 //  libra_rope_bridge_bwd).  Deterministic: two passes, no atomics.
 //
-//   dq pass  : forward-like (lane <-> query, 128 queries / workgroup, 32-key tiles, same variant skipping);
-//              K and V tiles are staged once in the reduction-major image and read BOTH ways: 16-byte row reads
-//              for S^T = K Q^T and dP^T = V dO^T, LDS transpose reads for dQ^T += K^T dS^T.
-//   dkv pass : lane <-> key.  Workgroup = 64 keys, 4 waves = 2 key halves x 2 ROLES: a "dV wave" recomputes P
-//              (S = Q K^T) and accumulates dV_same / dV_cross, a "dK wave" recomputes P and dP = dO V^T and
-//              accumulates dK_same / dK_cross (two [128 d x 32 keys] accumulators = 128 VGPRs per wave, no
-//              first-stage work duplicated for the same output).  The workgroup's K/V operand tiles stay
-//              resident in LDS (64 KiB); Q / dO tiles of 32 queries stream through a double buffer in BOTH
-//              images (row image for the first-stage A operand, reduction-major image for the transpose reads).
+//   dq pass  : lane <-> query, 256 queries / workgroup; work list of units (64-key tile, operand variant), two wave groups one
+//              phase apart (the forward kernel's structure); writes D = dO . O for the second pass.
+//   dkv pass : lane <-> key; item = (128-key block, operand variant), units = 64-query tiles; the dV waves and the dK waves are
+//              the two groups, K / V fragments in registers, P handed over through LDS one barrier later.
 #include <atomic>
 #include <type_traits>
 #include "hip_common.hpp"
-#include "gemm_tiles.hpp"
 #include "../../include/libra_hip.h"
-
-#ifndef LIBRA_DKV_PERSIST       // 1: persistent dK/dV workgroups with the rotation schedule (measured SLOWER in round 5: see DESIGN)
-#define LIBRA_DKV_PERSIST 0
-#endif
 
 namespace libra {
 
@@ -42,7 +32,7 @@ struct BridgeBwdArgs {
     bf16_t* dk_same; bf16_t* dk_cross; bf16_t* dv_same; bf16_t* dv_cross; long ldg;   // [B*S, H*128] each
     int B, S, H, n_t;
     float sl2, scale;
-    int* err;                                          // sticky device-side error word (or null): bit 0 = a dK/dV P hand-over timed out
+    int* err;                                          // sticky device-side error word (or null): unused since round 5 (no in-kernel wait left)
 };
 
 // Reduction-major image of a [rows][128 d] tile: 256-byte rows, 16-byte chunk c of row r stored at position
@@ -52,19 +42,6 @@ struct BridgeBwdArgs {
 // (A operand with k = rows).  [With only the (r&3) term, row reads were 4-way conflicted: 65 % of the dQ pass's LDS
 // cycles in the round-1 PMC profile.]
 __device__ __forceinline__ int tswz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
-
-// [64 rows][128 d] image, 16 pieces of 1 KiB over 8 waves; base is wave-uniform, ld_b = row stride in bytes
-__device__ __forceinline__ void stage_t64(const bf16_t* __restrict__ base, unsigned ld_b, int row0, int nrows, char* dst,
-                                          int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pc = wave * 2 + j;
-        const int r = pc * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ tswz(r);
-        int row = row0 + r; row = row < nrows ? row : nrows - 1;
-        glds16_off(base, (unsigned)row * ld_b + (unsigned)(c * 16), dst + pc * 1024);
-    }
-}
 
 // ================================================================================================
 // dQ pass, round-5 structure = the forward kernel's (attention_bridge.hip): 8 waves x 32 queries per workgroup, the work list is
@@ -453,295 +430,149 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dq_kernel(const Bridge
 }
 
 // ================================================================================================
-// dK / dV pass.  One workgroup owns 64 keys of one (sequence, head): their four operand tiles (K/V, same/cross) stay
-// resident in LDS; 64-query tiles of Q and dO stream through a 2-deep ring (one reduction-major image each: row reads
-// for S = Q K^T / dP = dO V^T, transposed reads for dV^T += dO^T P / dK^T += Q^T dS).  8 waves = 2 roles (waves 0-3
-// accumulate dV, waves 4-7 dK: a workgroup's waves w and w+4 share a SIMD, so every SIMD carries one of each) x 2 key
-// sub-blocks of 32 x 2 query halves of the streamed tile; the two query halves' partial sums meet in LDS at the end.
-constexpr int KV_RES = 4 * 16384;             // resident K_same, K_cross, V_same, V_cross: [64 keys][128 d] each
-constexpr int QD_STAGE = 2 * 16384 + 512;     // Q image, dO image (64 queries each), L[64], D[64]
-// + the P hand-over slots of the four (dV wave, dK wave) pairs (2 slots x 2 KiB each) and their sequence words
-constexpr int DKV_XP = KV_RES + 2 * QD_STAGE + 1024;
-constexpr int DKV_LDS_B = DKV_XP + 4 * 2 * 2048 + 64;
+// dK / dV pass, round-5 structure ("dkv6").  Item = (sequence, head, 128-key block, operand VARIANT): one variant per item halves
+// the accumulators (a wave carries ONE [128 d x 32 keys] block), so a wave also keeps its 32 keys' K (or V) fragments in
+// REGISTERS for the whole item - nothing is resident in LDS, the two query halves of the old structure (and their exchange
+// epilogue) are gone, and every first-stage MFMA reads ONE operand from LDS instead of two.  8 waves = 4 key sub-blocks x 2 ROLES,
+// and the two roles ARE the forward kernel's two wave groups, one phase apart (waves w and w + 4 share a SIMD):
+//     dV wave (group 0):  SM_u : P_u = exp2(S_u sl2 - L) masked -> bf16 registers + the pair's LDS slot
+//                         M_u  : dV^T += dO_u^T P_u  (16 MFMAs, transposed reads)   S_{u+1} = Q_{u+1} K^T  (16 MFMAs, row reads)
+//     dK wave (group 1):  DS_u : dS_u = P_u (dP_u - D)   (P_u from the slot: one barrier after it was written)
+//                         M'_u : dK^T += Q_u^T dS_u (16)                            dP_{u+1} = dO_{u+1} V^T (16)
+// A unit u is a 64-query tile holding at least one (query, key) pair of the item's variant for some wave; per wave it is skipped,
+// PLAIN (no per-element test) or MASKED (per-lane 64-bit query mask: causal, sequence end, pair kind), decided once in the
+// prologue.  A unit's Q | dO tile (+ its L and D rows) travels through a ring of 4 stages exactly as in the forward kernel.
+constexpr int KV6_TILE = 16384;                       // [64 queries][128 d] image
+constexpr int KV6_STAGE = 2 * KV6_TILE + 512;         // Q image | dO image | L[64] | D[64]
+constexpr int KV6_NSTAGE = 4;
+constexpr int KV6_SLOT_OFF = KV6_NSTAGE * KV6_STAGE;  // P hand-over: 4 pairs x 4 KiB
+constexpr int KV6_MASK_OFF = KV6_SLOT_OFF + 4 * 4096; // query-modality words (<= 130; 1 KiB)
+constexpr int KV6_BLK_OFF = KV6_MASK_OFF + 1024;      // block-level unit set (2 words)
+constexpr int KV6_TAB_OFF = KV6_BLK_OFF + 64;         // per-wave unit tables: 8 x 64 x 2 B
+constexpr int KV6_LDS_B = KV6_TAB_OFF + 8 * 128;
+constexpr int KV6_KEYS = 128;
 
-// resident operand tile: two N-type [64 keys][64 d] sub-tiles (128-byte rows, chunk ^ ((row>>1)&7)), 16 KiB; 8 waves
-__device__ __forceinline__ void stage_res64(const bf16_t* __restrict__ base, unsigned ld_b, int key0, int S, char* dst, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pc = wave * 2 + j;                 // 16 pieces of 1 KiB: sub-tile pc>>3, rows 8*(pc&7)..
-        const int sub = pc >> 3, r = (pc & 7) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int key = key0 + r; key = key < S ? key : S - 1;
-        glds16_off(base, (unsigned)key * ld_b + (unsigned)(sub * 128 + c * 16), dst + pc * 1024);
-    }
-}
-
-// Lane-constant LDS addressing: every fragment address is a per-lane constant XOR a compile-time constant (one VALU op per
-// read) instead of the swizzle arithmetic rebuilt per read (the round-1 PMC profile counted 12.4 VALU per MFMA in this kernel).
-// The dV wave and the dK wave of a (key sub-block, query half) pair sit on the same SIMD and used to compute the SAME
-// S = Q K^T block each (40 MFMAs per 32 x 32 block pair for 32 of arithmetic, and the dK wave - S, dP, dK - was the long pole of
-// every iteration; round 2, A/B in profiles/r03_attn_dkv_shared_p_ab.txt).  Now the dV wave alone forms P (exp2, masks, variant select), hands the bf16-packed block to its partner
-// through LDS (2 KiB, a sequence word; only the two waves of the pair synchronise - their control flow is identical - the
-// workgroup barrier at the loop top covers slot reuse) and the dK wave computes dP = dO V^T meanwhile: 16 MFMAs per wave and
-// iteration on both sides.  dS = bf16(P) (dP - D): P enters in bf16, as it does in the reference (softmax(..).to(q.dtype)).
-__global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const BridgeBwdArgs p) {
+__global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const BridgeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* res = smem;                                            // Ks, Kc, Vs, Vc
-    char* qd = smem + KV_RES;
-    unsigned* qmask = (unsigned*)(smem + KV_RES + 2 * QD_STAGE); // per 32 queries: bit i = query i is a vision token
+    unsigned* qmask = (unsigned*)(smem + KV6_MASK_OFF);
+    unsigned* blk = (unsigned*)(smem + KV6_BLK_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kw = wave & 1, qh = (wave >> 1) & 1;
-    const bool role_dk = (wave >> 2) != 0;                       // waves 0-3: dV; waves 4-7: dK
+    const int role = wave >> 2;                                   // 0: dV wave (group 0), 1: dK wave (group 1, one phase behind)
+    const int ksub = wave & 3;
     const int fk = lane >> 5, l31 = lane & 31;
-    // Persistent workgroups, static schedule (as in bridge_attn_fwd_kernel): the launcher starts P workgroups (one per CU, P a
-    // multiple of n_t); workgroup w handles the items i = w + k P, k = 0, 1, ...: (sequence, head) i / n_t and key tile
-    // (i + k) mod n_t.  A key tile's weight is the number of query tiles at or below it (1 .. n_t): the rotation by k hands every
-    // workgroup every weight once per n_t steps, so the CUs finish together without a queue, and a CU no longer waits ~7 us for
-    // the dispatch of each of its (8192 / 256 =) 32 one-per-CU workgroups.  An XCD's 32 workgroups stream the Q / dO tiles of the
-    // same few (sequence, head) pairs at a time through that XCD's L2.
-    const int nitems = p.B * p.H * p.n_t;
-    int npass = 0;
-    if (tid < 16) ((int*)(smem + DKV_XP + 4 * 4096))[tid] = 0;   // the pairs' sequence words count on across items
-#if LIBRA_DKV_PERSIST
-    const int P = (int)gridDim.x;
-    const int w_id = xcd_remap(blockIdx.x, P);
-#pragma unroll 1
-    for (int step = 0, item = w_id; item < nitems; ++step, item += P) {
-    const int ktile = (item % p.n_t + step) % p.n_t;
-#else
-    {
+    const int n_kb = p.n_t;                                       // 128-key blocks per sequence
+    const int nitems = p.B * p.H * n_kb * 2;
     const int item = xcd_remap(blockIdx.x, nitems);
-    const int ktile = item % p.n_t;                              // low key tiles see the most queries: they come first
-#endif
-    const int bh = item / p.n_t;
+    const int var = item & 1;
+    const int kb = (item >> 1) % n_kb;                            // low key blocks see the most queries: they come first
+    const int bh = (item >> 1) / n_kb;
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
     const long tok0 = (long)b * S;
     int len = p.kv_len ? p.kv_len[b] : S;
     len = len < S ? len : S;
-    const int key0 = ktile * 64;
-    const int kbase_w = key0 + kw * 32;
+    const int kbase_w = kb * KV6_KEYS + ksub * 32;
     int key = kbase_w + l31;
     const bool kin = key < S;
     key = kin ? key : S - 1;
-    // One memory round trip for the whole prologue (it was three in series, with one workgroup per CU and nothing to cover them):
-    // this lane's key modality byte, the four resident operand tiles and the first Q / dO tile (LDS-DMA) are requested first, the
-    // mask pass's own flag loads last - its wait then covers everything.
-    int k_vis_i = p.flag[tok0 + key] != 0;
-    stage_res64(p.k_same + tok0 * p.ldk + h * D128, (unsigned)p.ldk * 2u, key0, S, res, wave, lane);
-    stage_res64(p.k_cross + tok0 * p.ldkc + h * D128, (unsigned)p.ldkc * 2u, key0, S, res + 16384, wave, lane);
-    stage_res64(p.v_same + tok0 * p.ldv + h * D128, (unsigned)p.ldv * 2u, key0, S, res + 32768, wave, lane);
-    stage_res64(p.v_cross + tok0 * p.ldvc + h * D128, (unsigned)p.ldvc * 2u, key0, S, res + 49152, wave, lane);
+    const int nqt = (S + 63) / 64;
+    const int t_first = (kb * KV6_KEYS) / 64;                     // first query tile that can see the block
 
     const bf16_t* qbase = p.q + tok0 * p.ldq + h * D128;
     const bf16_t* dobase = p.dout + tok0 * p.ldo + h * D128;
     const float* lbase = p.lse + ((long)b * p.H + h) * S;
     const float* dbase = p.delta + ((long)b * p.H + h) * S;
-    auto stage_q = [&](int buf, int t) {
-        char* dst = qd + buf * QD_STAGE;
-        stage_t64(qbase, (unsigned)p.ldq * 2u, t * 64, S, dst, wave, lane);
-        stage_t64(dobase, (unsigned)p.ldo * 2u, t * 64, S, dst + 16384, wave, lane);
-        if (wave < 2) {                                          // 64 fp32 each: one 4-byte direct-to-LDS op
+    const unsigned lds0 = (unsigned)(unsigned long)(LIBRA_LDS char*)smem;
+
+    // ---- direct-to-LDS pieces of a stage: wave w moves pieces 2w, 2w + 1 (rows 8w + (lane >> 4), + 4) of the Q and of the dO image;
+    // waves 4 and 5 (group 1: it waits with vmcnt(0), no counting) also move the tile's 64 L and 64 D values
+    const int r0 = wave * 8 + (lane >> 4);
+    const int c0 = (lane & 15) ^ tswz(r0);
+    const int d16 = (c0 & 1) ? -16 : 16;
+    const unsigned ldqb = (unsigned)(p.ldq * 2), ldob = (unsigned)(p.ldo * 2);
+    const unsigned oQ = (unsigned)(lane >> 4) * ldqb + (unsigned)(c0 << 4), oO = (unsigned)(lane >> 4) * ldob + (unsigned)(c0 << 4);
+    auto stage_tile = [&](const int t, const int st) {
+        const unsigned dst = lds0 + (unsigned)(st * KV6_STAGE + wave * 2048);
+        if (t * 64 + 64 <= S) {
+            const bf16_t* qb = qbase + ((long)t * 64 + wave * 8) * p.ldq;
+            const bf16_t* ob = dobase + ((long)t * 64 + wave * 8) * p.ldo;
+            glds16_off_at(qb, oQ, dst); glds16_off_at(qb + 4 * p.ldq, oQ + (unsigned)d16, dst + 1024);
+            glds16_off_at(ob, oO, dst + KV6_TILE); glds16_off_at(ob + 4 * p.ldo, oO + (unsigned)d16, dst + KV6_TILE + 1024);
+        } else {                                                  // ragged last tile: rows clamped to the last token (masked)
+            const int lim = S - 1 - t * 64;
+            const bf16_t* qb = qbase + (long)t * 64 * p.ldq;
+            const bf16_t* ob = dobase + (long)t * 64 * p.ldo;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int row = r0 + 4 * j;
+                row = row < lim ? row : lim;
+                const unsigned cc = (unsigned)((c0 ^ j) << 4);
+                glds16_off_at(qb, (unsigned)row * ldqb + cc, dst + j * 1024);
+                glds16_off_at(ob, (unsigned)row * ldob + cc, dst + KV6_TILE + j * 1024);
+            }
+        }
+        if (wave == 4 || wave == 5) {
             int qi = t * 64 + lane; qi = qi < S ? qi : S - 1;
-            glds4((wave == 0 ? lbase : dbase) + qi, dst + 32768 + wave * 256);
+            glds4((wave == 4 ? lbase : dbase) + qi, smem + st * KV6_STAGE + 2 * KV6_TILE + (wave - 4) * 256);
         }
     };
-    const int it0 = key0 / 64;                                   // first query tile that can see this key block
-    const int nqt = (S + 63) / 64;
-    // this pair's two P slots and its sequence word (the number of P blocks published so far)
-    char* xp = smem + DKV_XP + (qh * 2 + kw) * 4096;
-    // (an LDS-space pointer: through a generic `volatile int*` the poll compiled to `flat_load_dword .. sc0 sc1` + `s_waitcnt vmcnt(0)`,
-    //  which also drained the next tile's direct-to-LDS queue in every iteration of the dK waves)
-    volatile LIBRA_LDS int* xseq = (volatile LIBRA_LDS int*)(LIBRA_LDS char*)(smem + DKV_XP + 4 * 4096) + (qh * 2 + kw);
-    f32x16 acc_s[4], acc_c[4];                                   // dV (or dK) for the same / cross variant, [128 d x 32 keys]
+
+    // ---- prologue: the first two stages on a guess (the first two tiles that can see the block), this lane's key modality and
+    // its 8 B-operand fragments (K rows for a dV wave, V rows for a dK wave, of the item's variant), the query modality words
+    if (t_first < nqt) stage_tile(t_first, 0);
+    if (t_first + 1 < nqt) stage_tile(t_first + 1, 1);
+    int k_vis_i = p.flag[tok0 + key] != 0;
+    bf16x8 bfr[8];
+    {
+        const bf16_t* src = role == 0 ? (var ? p.k_cross : p.k_same) : (var ? p.v_cross : p.v_same);
+        const long ld = role == 0 ? (var ? p.ldkc : p.ldk) : (var ? p.ldvc : p.ldv);
+        const bf16_t* kp = src + (tok0 + key) * ld + h * D128 + fk * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bfr[ks] = *(const bf16x8*)(kp + ks * 16);
+    }
+    modality_masks(p.flag + tok0, S, qmask, tid, 512);
+    if (tid < 2) blk[tid] = 0;
+    pin(k_vis_i);
+    const bool k_vis = k_vis_i != 0;
+    const bool kval = kin && (kbase_w + l31) < len;               // this lane's key exists and is not padding
+    const bool wkV = __ballot(k_vis && kval) != 0, wkL = __ballot(!k_vis && kval) != 0;
+    __syncthreads();
+
+    // ---- per-wave classification of every query tile, lane = tile
+    unsigned mode = 0;
+    {
+        const int q0 = lane * 64;
+        const u64 qm = (u64)qmask[2 * lane] | ((u64)qmask[2 * lane + 1] << 32);
+        const u64 rng = bits_below64(S - q0);
+        const bool qV = (qm & rng) != 0, qL = (~qm & rng) != 0;
+        const bool wsame = (qL && wkL) || (qV && wkV), wcross = (qL && wkV) || (qV && wkL);
+        const bool in = lane < nqt && q0 + 63 >= kbase_w && kbase_w < len;
+        const bool has = in && (var ? wcross : wsame);
+        const bool full = q0 >= kbase_w + 31 && q0 + 64 <= S && kbase_w + 32 <= len;
+        const bool plain = full && !(wsame && wcross);
+        mode = has ? (plain ? 1u : 2u) : 0u;
+        const u64 bset = __ballot(has);
+        if (lane == 0) {
+            if ((unsigned)bset) atomicOr(&blk[0], (unsigned)bset);
+            if ((unsigned)(bset >> 32)) atomicOr(&blk[1], (unsigned)(bset >> 32));
+        }
+    }
+    __syncthreads();
+    const u64 uset = (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[0]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)blk[1]) << 32);
+    const int U = __popcll(uset);                                 // units of this item (<= 64)
+
+    // ---- store of a wave's [128 d x 32 keys] block, transposed through a private LDS region (32 rows x 264 B)
+    f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_s[i][r] = 0.f; acc_c[i][r] = 0.f; }
-    if (it0 < nqt) stage_q(0, it0);
-    modality_masks(p.flag + tok0, S, qmask, tid, 512);
-    pin(k_vis_i);
-    const bool k_vis = k_vis_i != 0;
-    const bool wkV = __ballot(k_vis && kin) != 0, wkL = __ballot(!k_vis && kin) != 0;
-
-    const char* rK = res + kw * 32 * 128;                         // this wave's 32 key rows inside each 64-row sub-tile
-    // lane constants: row image (xr), resident image (xv), transposed reads (xt0 / xt1) - each read is then
-    // `constant ^ (k-step or d-tile bits)`
-    int xr = 0, xv = 0, xt0 = 0, xt1 = 0;
-    {
-        const int pp = lane & 15, g16 = (lane >> 4) & 1;
-        const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
-        xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
-        xv = l31 * 128 + ((fk ^ ((l31 >> 1) & 7)) << 4);
-        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
-        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4);
-    }
-    for (int it = it0; it < nqt; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = (it - it0) & 1;
-        if (it + 1 < nqt) stage_q(cur ^ 1, it + 1);
-        const int q0 = it * 64 + qh * 32;
-        if (kbase_w >= S || q0 >= S || q0 + 31 < kbase_w) continue;   // no (query >= key) pair for this wave in the tile
-        asm volatile("" : "+v"(xr), "+v"(xt0), "+v"(xt1), "+v"(xv));
-        auto rd_row = [&](const char* tile, int ks) -> bf16x8 {
-            return *(const bf16x8*)(tile + (xr ^ (ks << 5)));
-        };
-        auto rd_res = [&](const char* tile, int ks) -> bf16x8 {
-            return *(const bf16x8*)(tile + (ks >> 2) * 8192 + (xv ^ ((ks & 3) << 5)));
-        };
-        auto rd_tr = [&](const char* tile, int dt, int sx) -> bf16x8 {
-            union { bf16x8 v; s16x4 h2[2]; } u;
-            u.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + (xt0 ^ (dt << 6))));
-            u.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(tile + sx * 4096 + 2048 + (xt1 ^ (dt << 6))));
-            return u.v;
-        };
-        const char* sq = qd + cur * QD_STAGE + qh * 8192;         // this wave's 32 query rows of the Q image (dO at +16384)
-        const float* sL = (const float*)(qd + cur * QD_STAGE + 32768) + qh * 32;
-        const float* sD = sL + 64;
-        const unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[2 * it + qh]);
-        int nvalid = S - q0; nvalid = nvalid > 32 ? 32 : nvalid;
-        const unsigned full = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
-        const bool qV = (qm & full) != 0, qL = ((~qm) & full) != 0;
-        const bool wsame = (qL && wkL) || (qV && wkV);
-        const bool wcross = (qL && wkV) || (qV && wkL);
-        const bool masked = q0 < kbase_w + 31 || q0 + 32 > S || kbase_w + 32 > len;
-
-        // accumulator row r <-> query q0 + (r&3) + 8(r>>2) + 4fk ; column <-> this lane's key
-        // S = Q K^T (both roles), dP = dO V^T (dK waves only): A = row fragments of the streamed tile, B = resident fragments
-        auto score_s = [&](const char* rk, f32x16& s) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq, ks), rd_res(rk, ks), s, 0, 0, 0);
-        };
-        auto score_dp = [&](const char* rk, f32x16& dp) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-            if (role_dk) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sq + 16384, ks), rd_res(rk + 32768, ks), dp, 0, 0, 0);
-            }
-        };
-        // s <- P = exp2(S*sl2 - L), masked (dV waves; the dK waves apply (dP - D) to the bf16 P they are handed)
-        auto finish = [&](f32x16& s) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ql = 8 * g + 4 * fk;
-                const f32x4 Lv = *(const f32x4*)(sL + ql);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * g + e], p.sl2, -Lv[e] * LOG2E));
-            }
-            if (masked) {
-                const int kabs = kbase_w + l31;
-                const bool kok = kabs < len;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qa = q0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    s[r] = (qa >= kabs && qa < S && kok) ? s[r] : 0.f;
-                }
-            }
-        };
-        const char* st = role_dk ? sq : sq + 16384;               // Q^T fragments (dK) or dO^T fragments (dV)
-        const bool mixed = wsame && wcross;
-        // one pass per variant present (a tile pair with both modalities on either side - rare - pays S twice): every
-        // accumulator set is touched from exactly one place, which keeps all 128 of them in registers
-        auto pass = [&](const char* rk, bool cross, f32x16* acc) {
-            union { bf16x8 v; unsigned u[4]; } pk[2];
-            ++npass;
-            char* slot = xp + (npass & 1) * 2048 + lane * 16;
-            if (!role_dk) {                                       // producer: P (masked, variant-selected), bf16
-                f32x16 s;
-                score_s(rk, s);
-                finish(s);
-                if (mixed) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ql = (r & 3) + 8 * (r >> 2) + 4 * fk;
-                        s[r] = ((((qm >> ql) & 1u) != 0) != k_vis) == cross ? s[r] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[sx].u[j] = pack2bf(s[8 * sx + 2 * j], s[8 * sx + 2 * j + 1]);
-                *(bf16x8*)slot = pk[0].v;
-                *(bf16x8*)(slot + 1024) = pk[1].v;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) *xseq = npass;                     // (LDS serves one wave's operations in order: data, then the word)
-            } else {                                              // consumer: dP while P is being formed, then dS = P (dP - D)
-                f32x16 dp;
-                score_dp(rk, dp);
-                // Bounded wait (a lost partner must not hang the GPU).  The two waves of a pair run the same control flow on the
-                // same wave-uniform conditions, so the bound is never reached by design; if it ever is, the cold branch raises the
-                // sticky error word of the launch (the host checks it once per backward) instead of silently using a stale P.
-                int spins = 0;
-                while (*xseq < npass) {
-                    if (++spins >= (1 << 22)) {
-                        if (lane == 0 && p.err) atomicOr(p.err, 1);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                pk[0].v = *(const bf16x8*)slot;
-                pk[1].v = *(const bf16x8*)(slot + 1024);
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r0 = 8 * sx + 2 * j;             // accumulator rows r0, r0 + 1 <-> queries 8 (r0 >> 2) + 4 fk + (r0 & 3), + 1
-                        const float d0 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3)], d1 = sD[8 * (r0 >> 2) + 4 * fk + (r0 & 3) + 1];
-                        const float p0 = __uint_as_float(pk[sx].u[j] << 16), p1 = __uint_as_float(pk[sx].u[j] & 0xffff0000u);
-                        pk[sx].u[j] = pack2bf(p0 * (dp[r0] - d0), p1 * (dp[r0 + 1] - d1));
-                    }
-            }
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(st, dt, sx), pk[sx].v, acc[dt], 0, 0, 0);
-            }
-        };
-        if (wsame) pass(rK, false, acc_s);
-        if (wcross) pass(rK + 16384, true, acc_c);
-    }
-    // ---- combine the two query halves' partial sums through LDS: the qh = 0 wave finishes (and stores) the "same" variant, the
-    // qh = 1 wave the "cross" variant - each hands the other half of its sums over (a + b = b + a: the same bits as a one-sided sum)
-    __syncthreads();
-    {
-        float* xch = (float*)smem + ((wave >> 2) * 2 + kw) * 8192;   // 32 KiB per (role, key sub-block) pair: [acc][reg quad][lane] x4
-        float* gdst = xch + (qh == 1 ? 0 : 4096);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 a;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = qh == 1 ? acc_s[i][4 * g + e] : acc_c[i][4 * g + e];
-                *(f32x4*)(gdst + ((i * 4 + g) * 64 + lane) * 4) = a;
-            }
-        __syncthreads();
-        const float* gsrc = xch + (qh == 0 ? 0 : 4096);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = *(const f32x4*)(gsrc + ((i * 4 + g) * 64 + lane) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (qh == 0) acc_s[i][4 * g + e] += a[e];
-                    else acc_c[i][4 * g + e] += a[e];
-                }
-            }
-        __syncthreads();
-    }
-    // ---- store: each wave's two [128 d x 32 keys] blocks, transposed through a private LDS region (32 rows x 264 B)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     constexpr int OROW = 264;
-    char* so = smem + wave * (32 * OROW);
-    auto store = [&](const f32x16* acc, float mul, bf16_t* dst) {
+    auto store_out = [&]() {
+        char* so = smem + wave * (32 * OROW);
+        bf16_t* dst = role == 0 ? (var ? p.dv_cross : p.dv_same) : (var ? p.dk_cross : p.dk_same);
+        const float mul = role == 0 ? 1.0f : p.scale;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -767,31 +598,215 @@ __global__ __launch_bounds__(512, 1) void bridge_attn_bwd_dkv_kernel(const Bridg
             }
         }
     };
-    if (kbase_w < S) {
-        if (qh == 0) { if (role_dk) store(acc_s, p.scale, p.dk_same); else store(acc_s, 1.0f, p.dv_same); }
-        else { if (role_dk) store(acc_c, p.scale, p.dk_cross); else store(acc_c, 1.0f, p.dv_cross); }
+    if (U == 0) {                                                 // no pair of this variant: the block's gradients are zero
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // everybody's guessed pieces have landed: LDS is free
+        store_out();
+        return;
     }
-    __syncthreads();                                             // the next item's staging overwrites the store rows' LDS
-    }   // persistent item loop
+
+    unsigned tab0;                                                // lane i: entry of unit i = mode | tile << 3 (0 past the end)
+    {
+        unsigned short* tab = (unsigned short*)(smem + KV6_TAB_OFF) + wave * 64;
+        if ((uset >> lane) & 1ull) tab[__popcll(uset & bits_below64(lane))] = (unsigned short)(mode | (unsigned)(lane << 3));
+        tab0 = lane < U ? tab[lane] : 0u;                         // (same wave, in-order LDS queue: no barrier)
+    }
+    auto entry = [&](const int u) -> unsigned {                   // u wave-uniform; 0 past the end
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)tab0, u & 63);
+        return u < 64 ? a : 0u;
+    };
+    {
+        const unsigned e0 = entry(0), e1 = entry(1);
+        const bool ok0 = (int)(e0 >> 3) == t_first, ok1 = U < 2 || (int)(e1 >> 3) == t_first + 1;
+        if (!ok0 || !ok1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!ok0) stage_tile((int)(e0 >> 3), 0);
+            if (!ok1 && U >= 2) stage_tile((int)(e1 >> 3), 1);
+        }
+    }
+
+    // ---- fragment addressing (lane constants XOR compile-time constants), role offsets (wave-uniform)
+    int xr, xt0, xt1;
+    {
+        const int pp = lane & 15, g16 = (lane >> 4) & 1;
+        const int r1 = 4 * fk + (pp >> 2), lp = 2 * g16 + ((pp & 3) >> 1);
+        xr = l31 * 256 + ((fk ^ tswz(l31)) << 4);
+        xt0 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1)) << 4);
+        xt1 = r1 * 256 + ((pp & 1) << 3) + ((lp ^ tswz(r1 + 8)) << 4) + 2048;
+    }
+    const int tr_off = role == 0 ? KV6_TILE : 0;                  // dV: dO^T fragments; dK: Q^T fragments
+    const int row_off = role == 0 ? 0 : KV6_TILE;                 // dV: Q rows (S); dK: dO rows (dP)
+    char* slot = smem + KV6_SLOT_OFF + ksub * 4096 + lane * 16;
+
+    f32x16 sA, sB;                                                // S (dV wave) or dP (dK wave) of the unit in flight: query halves 0 / 1
+    union PK { bf16x8 v; unsigned u[4]; };
+    PK pk[4];                                                     // P (dV wave) / dS (dK wave) as the four 16-query B operands
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) pin(bfr[ks]);                  // prologue loads have landed before the loop's LDS-DMA traffic
+
+    union VA { bf16x8 v; s16x4 h2[2]; };
+    constexpr int NF = 6;
+    auto m_phase = [&](auto ac_c, auto nx_c, const char* cur, const char* nxt) {
+        constexpr bool AC = decltype(ac_c)::value, NX = decltype(nx_c)::value;
+        constexpr int N = (AC ? 16 : 0) + (NX ? 16 : 0), I0 = AC ? 0 : 16;
+        bf16x8 F[NF];
+        auto fread = [&](const int i) -> bf16x8 {
+            if (i < 16) {
+                const char* a = cur + tr_off + (i >> 2) * 4096;
+                VA t;
+                t.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + (xt0 ^ ((i & 3) << 6))));
+                t.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LIBRA_LDS s16x4*)(a + (xt1 ^ ((i & 3) << 6))));
+                return t.v;
+            }
+            const int j = i - 16, ks = j >> 1, hh = j & 1;
+            return *(const bf16x8*)(nxt + row_off + hh * 8192 + (xr ^ (ks << 5)));
+        };
+        if constexpr (N > 0) {
+#pragma unroll
+            for (int n = 0; n < NF; ++n) F[n] = fread(I0 + n);
+            if constexpr (NX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const int i = I0 + n;
+                if (i < 16) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], pk[i >> 2].v, acc[i & 3], 0, 0, 0);
+                else if (i & 1) sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], bfr[(i - 16) >> 1], sB, 0, 0, 0);
+                else sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[n % NF], bfr[(i - 16) >> 1], sA, 0, 0, 0);
+                if (n + NF < N) F[n % NF] = fread(i + NF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // per-lane query mask of a MASKED unit: query >= key (causal), query < S, key < len, pair kind == the item's variant.
+    // One 32-bit word per query half, shifted by 4 fk so that the bit positions below are compile-time.
+    const int kabs = kbase_w + l31;
+    auto query_masks = [&](const int qt, unsigned& v0, unsigned& v1) {
+        const int q0 = qt * 64;
+        const unsigned qm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[2 * qt]);
+        const unsigned qm1 = (unsigned)__builtin_amdgcn_readfirstlane((int)qmask[2 * qt + 1]);
+        const unsigned flip = ~((k_vis ? ~0u : 0u) ^ (var ? ~0u : 0u));   // cross pair <=> query bit != key bit; wanted <=> cross == var
+        u64 rng = bits_below64(S - q0) & ~bits_below64(kabs - q0);
+        rng = kval ? rng : 0ull;
+        v0 = ((qm0 ^ flip) & (unsigned)rng) >> (4 * fk);
+        v1 = ((qm1 ^ flip) & (unsigned)(rng >> 32)) >> (4 * fk);
+    };
+    auto stage_of = [&](const int u) -> const char* { return smem + (u & (KV6_NSTAGE - 1)) * KV6_STAGE; };
+
+    const u64 act = __ballot((tab0 & 3u) != 0);
+    const int Uw = act ? 64 - (int)__builtin_clzll(act) : 0;
+    // VALU phase of unit u (entry e): request stage u + 2 (entry e2), then
+    //   dV wave: P = exp2(S sl2 - L) masked -> pk and the slot;      dK wave: dS = P (dP - D) -> pk, P read from the slot
+    auto v_phase = [&](const int u, const unsigned e, const unsigned e2) {
+        const bool issue = u + 2 < U;
+        if (issue) stage_tile((int)(e2 >> 3), (u + 2) & (KV6_NSTAGE - 1));
+        const float* sL = (const float*)(stage_of(u) + 2 * KV6_TILE);
+        if (role == 0) {
+            float a[16], c[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 La = *(const f32x4*)(sL + 8 * g + 4 * fk), Lc = *(const f32x4*)(sL + 32 + 8 * g + 4 * fk);
+#pragma unroll
+                for (int e_ = 0; e_ < 4; ++e_) {
+                    a[4 * g + e_] = __builtin_amdgcn_exp2f(__builtin_fmaf(sA[4 * g + e_], p.sl2, -La[e_] * LOG2E));
+                    c[4 * g + e_] = __builtin_amdgcn_exp2f(__builtin_fmaf(sB[4 * g + e_], p.sl2, -Lc[e_] * LOG2E));
+                }
+            }
+            if ((e & 3u) != 1u) {                                 // masked unit (or a skipped one inside the wave's range: empty pair set)
+                unsigned v0 = 0u, v1 = 0u;
+                if ((e & 3u) == 2u) query_masks((int)(e >> 3), v0, v1);
+                const float zero = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int bpos = (r & 3) + 8 * (r >> 2);      // local query of accumulator row r (minus 4 fk)
+                    const u64 k0 = __builtin_amdgcn_ballot_w64(((v0 >> bpos) & 1u) != 0), k1 = __builtin_amdgcn_ballot_w64(((v1 >> bpos) & 1u) != 0);
+                    asm volatile("v_cndmask_b32 %0, %2, %0, %1" : "+v"(a[r]) : "s"(k0), "v"(zero));
+                    asm volatile("v_cndmask_b32 %0, %2, %0, %1" : "+v"(c[r]) : "s"(k1), "v"(zero));
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r0_ = 8 * (st & 1) + 2 * j;
+                    pk[st].u[j] = st < 2 ? pack2bf(a[r0_], a[r0_ + 1]) : pack2bf(c[r0_], c[r0_ + 1]);
+                }
+                *(bf16x8*)(slot + st * 1024) = pk[st].v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the slot is written before the barrier that releases its reader
+            if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const float* sD = sL + 64;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                PK pv;
+                pv.v = *(const bf16x8*)(slot + st * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r0_ = 8 * (st & 1) + 2 * j;         // accumulator rows r0, r0 + 1 <-> queries 32 (st >> 1) + 8 (r0 >> 2) + 4 fk + (r0 & 3), + 1
+                    const int ql = 32 * (st >> 1) + 8 * (r0_ >> 2) + 4 * fk + (r0_ & 3);
+                    const float d0 = sD[ql], d1 = sD[ql + 1];
+                    const float p0 = __uint_as_float(pv.u[j] << 16), p1 = __uint_as_float(pv.u[j] & 0xffff0000u);
+                    const float x0 = st < 2 ? sA[r0_] : sB[r0_], x1 = st < 2 ? sA[r0_ + 1] : sB[r0_ + 1];
+                    pk[st].u[j] = pack2bf(p0 * (x0 - d0), p1 * (x1 - d1));
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) pin(pk[st].v);             // HERE: keep this phase's arithmetic out of the M phase's MFMA stream
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto m_end = [&]() {
+        if (role == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 1: its pieces of stage u + 2, requested in its DS_u
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                              // stages 0 and 1 landed
+    unsigned e_cur = entry(0), e_nxt = entry(1), e_dma = entry(2);
+    if (role == 1) __builtin_amdgcn_s_barrier();
+    if (Uw > 0) m_phase(std::false_type{}, std::true_type{}, nullptr, stage_of(0));
+    __builtin_amdgcn_s_barrier();
+    int u = 0;
+    for (; u + 1 < Uw; ++u) {
+        v_phase(u, e_cur, e_dma);
+        __builtin_amdgcn_s_setprio(1);
+        m_phase(std::true_type{}, std::true_type{}, stage_of(u), stage_of(u + 1));
+        __builtin_amdgcn_s_setprio(0);
+        m_end();
+        e_cur = e_nxt; e_nxt = e_dma; e_dma = entry(u + 3);
+    }
+    if (u < Uw) {                                                 // this wave's last unit: nothing to prepare
+        v_phase(u, e_cur, e_dma);
+        __builtin_amdgcn_s_setprio(1);
+        m_phase(std::true_type{}, std::false_type{}, stage_of(u), nullptr);
+        __builtin_amdgcn_s_setprio(0);
+        m_end();
+        e_cur = e_nxt; e_nxt = e_dma; e_dma = entry(u + 3);
+        ++u;
+    }
+    for (; u < U; ++u) {                                          // units past this wave's last pair: staging duty only
+        const bool issue = u + 2 < U;
+        if (issue) stage_tile((int)(e_dma >> 3), (u + 2) & (KV6_NSTAGE - 1));
+        if (role == 0) { if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        m_end();
+        e_cur = e_nxt; e_nxt = e_dma; e_dma = entry(u + 3);
+    }
+    if (role == 0) __builtin_amdgcn_s_barrier();                  // re-align the two groups
+    __syncthreads();
+    store_out();
 }
 
 }  // namespace libra
 
 using namespace libra;
-
-// persistent grid: one workgroup per CU, rounded down to a multiple of the rotation period (the kernels' static schedules need
-// it), at least one period, at most one workgroup per item
-static long persistent_grid(long nitems, int period) {
-    static std::atomic<int> n_cu{0};              // (benign race: every thread stores the same value)
-    if (!n_cu) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        n_cu = cus;
-    }
-    long nblk = (long)n_cu / period * period;
-    if (nblk < period) nblk = period;
-    return nblk > nitems ? nitems : nblk;
-}
 
 extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_same, int64_t ldk, const void* k_cross,
                                      int64_t ldkc, const void* v_same, int64_t ldv, const void* v_cross, int64_t ldvc,
@@ -825,7 +840,7 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     static std::atomic<bool> attr_set{false};     // (idempotent call; atomic only so that concurrent first launches do not race on the flag)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_B);
-        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_B);
+        (void)hipFuncSetAttribute((const void*)bridge_attn_bwd_dkv6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV6_LDS_B);
         attr_set = true;
     }
     a.n_t = (int)((S + DQ_BQ - 1) / DQ_BQ);
@@ -834,12 +849,9 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     // (other dK/dV structures that were built and measured in round 2: profiles/r02_attn_bwd_anatomy.md)
     hipLaunchKernelGGL(bridge_attn_bwd_dq_kernel, dim3((unsigned)persistent_grid(nblk, a.n_t)), dim3(512), DQ_LDS_B, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
-    a.n_t = (int)((S + 63) / 64);
-    nblk = (long)B * H * a.n_t;
+    a.n_t = (int)((S + KV6_KEYS - 1) / KV6_KEYS);
+    nblk = (long)B * H * a.n_t * 2;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
-#if LIBRA_DKV_PERSIST
-    nblk = persistent_grid(nblk, a.n_t);
-#endif
-    hipLaunchKernelGGL(bridge_attn_bwd_dkv_kernel, dim3((unsigned)nblk), dim3(512), DKV_LDS_B, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bridge_attn_bwd_dkv6_kernel, dim3((unsigned)nblk), dim3(512), KV6_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }

@@ -169,6 +169,10 @@ __device__ __forceinline__ void wave_sum16(const float* v, float* out) {
 }
 constexpr float DEFER_THR = 8.f;   // online-softmax running max is only advanced when a tile exceeds it by 2^8
 
+// runtime.hip: physical CU count and the grid size of a persistent kernel under the caller's CU budget (libra_set_cu_budget)
+int cu_count();
+long persistent_grid(long nitems, int period);
+
 // XCD-aware, bijective remap of a linear block id so that each of the 8 XCDs (block b runs on
 // XCD b % 8) receives a contiguous range of the logical tile space (L2 locality; speed only).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

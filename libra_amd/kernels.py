@@ -937,6 +937,51 @@ def rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S: int, H: int, dqkv, dkb,
     _lib.check(rc, "rope_bridge_bwd")
 
 
+# ---- compute-unit budget (include/libra_hip.h, "compute-unit budget") --------------------------------------------------------
+def cu_count() -> int:
+    return int(_lib.lib().libra_get_cu_count())
+
+
+def set_cu_budget(cus: int) -> int:
+    """Persistent kernels launch at most `cus` workgroups (0 = one per physical CU).  Returns the previous budget."""
+    prev = _lib.lib().libra_set_cu_budget(int(cus))
+    if prev < 0:
+        _lib.check(prev, "set_cu_budget")
+    return int(prev)
+
+
+class ReservedCUStream:
+    """A compute stream that leaves `reserve` CUs to other streams (RCCL's reduction kernels under backward) + the matching budget
+    for the persistent kernels.  `with rs: step()` runs the step on it; close() restores the budget and destroys the stream."""
+
+    def __init__(self, reserve: int):
+        import ctypes
+        h, cus = ctypes.c_void_p(), ctypes.c_int32()
+        _lib.check(_lib.lib().libra_stream_create_cu_reserved(int(reserve), ctypes.byref(h), ctypes.byref(cus)), "stream_create_cu_reserved")
+        self.handle, self.cus, self.reserve = h.value, int(cus.value), int(reserve)
+        self.stream = torch.cuda.ExternalStream(self.handle)
+        self._prev = set_cu_budget(self.cus)
+        self._ctx = None
+
+    def __enter__(self):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        r = self._ctx.__exit__(*a)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return r
+
+    def close(self):
+        if self.handle:
+            self.stream.synchronize()
+            set_cu_budget(self._prev)
+            _lib.check(_lib.lib().libra_stream_destroy(self.handle), "stream_destroy")
+            self.handle = None
+
+
 # ---- per-launch timing of the attention and row kernels (bench.py's `roofline.by_kernel`) ----------------------------------
 # work = (FLOP, algorithmic HBM bytes, tag): attention FLOPs are the causal-minimal count bench.py's roofline uses
 # (2 products x 2 S(S+1)/2 x 128 per head forward, 2.5 x that backward); row kernels count each operand / result row once.

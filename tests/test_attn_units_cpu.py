@@ -120,3 +120,96 @@ def test_units_cover_every_attended_pair_once_with_the_right_variant(case):
                         assert cover.get((q, key)) == int(flag[q] != flag[key]), ("missing / wrong variant", q, key)
                     else:
                         assert (q, key) not in cover, ("pair should be masked", q, key)
+
+
+# ---- the backward's dK / dV pass (attention_bridge_bwd.hip, "dkv6"): item = (128-key block, variant), unit = 64-query tile -------------
+KV_KEYS, QT = 128, 64
+
+
+def plan_dkv_item(flag, S, length, kb, var):
+    """-> per wave (4 key sub-blocks; the dV and the dK wave of a pair share it): list of units (query tile, mode); the kernel's lane-parallel
+    classification restated tile by tile."""
+    n32 = (S + 31) // 32
+    qmask = [0] * (2 * 64 + 2)
+    for t in range(n32):
+        for i in range(32):
+            tok = t * 32 + i
+            if tok < S and flag[tok]:
+                qmask[t] |= 1 << i
+    length = min(length, S)
+    nqt = (S + QT - 1) // QT
+    per_wave, uset = [], 0
+    for ksub in range(4):
+        kbase = kb * KV_KEYS + ksub * 32
+        keys = [k for k in range(kbase, kbase + 32) if k < S and k < length]
+        wkV, wkL = any(flag[k] for k in keys), any(not flag[k] for k in keys)
+        tiles = []
+        for t in range(64):
+            q0 = t * QT
+            qm = qmask[2 * t] | (qmask[2 * t + 1] << 32)
+            rng = bits_below(S - q0)
+            qV, qL = (qm & rng) != 0, (~qm & rng & ((1 << 64) - 1)) != 0
+            wsame, wcross = (qL and wkL) or (qV and wkV), (qL and wkV) or (qV and wkL)
+            inn = t < nqt and q0 + 63 >= kbase and kbase < length
+            has = inn and (wcross if var else wsame)
+            full = q0 >= kbase + 31 and q0 + 64 <= S and kbase + 32 <= length
+            plain = full and not (wsame and wcross)
+            tiles.append((1 if plain else 2) if has else 0)
+            if has: uset |= 1 << t
+        per_wave.append(tiles)
+    return [[(t, per_wave[w][t]) for t in range(64) if (uset >> t) & 1] for w in range(4)], qmask
+
+
+def dkv_element_valid(qmask, flag, q, key, t, var, S, length):
+    q0 = t * QT
+    rng = bits_below(S - q0) & ~bits_below(key - q0)
+    if not (key < S and key < min(length, S)):
+        rng = 0
+    j = q - q0
+    qbit = (qmask[2 * t + (j >> 5)] >> (j & 31)) & 1
+    cross = qbit != (1 if flag[key] else 0)
+    return bool((rng >> j) & 1) and (cross == bool(var))
+
+
+@pytest.mark.parametrize("case", ["bench", "two_spans", "random", "right_pad", "ragged", "text_only"])
+def test_dkv_items_cover_every_attended_pair_once(case):
+    """Over the two variant items of a key block, every (query, key) pair the reference attends to (query >= key, key < len) is covered
+    exactly once, by the item of the variant the closed form asks for; a plain unit has no pair to mask; every unit of an item is
+    computed by some wave; an item without units is exactly a block with no pair of that variant (its gradients are zero)."""
+    rs = np.random.RandomState(hash(case) % 1000)
+    S, length = 1024, 1024
+    flag = np.zeros(S, dtype=bool)
+    if case == "bench":
+        flag[1:579] = True
+    elif case == "two_spans":
+        flag[5:200] = True; flag[500:800] = True
+    elif case == "random":
+        S = length = 700; flag = rs.rand(S) < 0.4
+    elif case == "right_pad":
+        length = 801; flag[1:579] = True
+    elif case == "ragged":
+        S = length = 1000; flag = np.zeros(S, dtype=bool); flag[300:878] = True
+    for kb in range((S + KV_KEYS - 1) // KV_KEYS):
+        cover = {}
+        for var in (0, 1):
+            units, qmask = plan_dkv_item(flag, S, length, kb, var)
+            assert all([t for t, _ in u] == [t for t, _ in units[0]] for u in units)      # one unit list / barrier schedule per workgroup
+            for i in range(len(units[0])):
+                assert any(units[w][i][1] for w in range(4))                               # no unit that nobody computes
+            for ksub in range(4):
+                kbase = kb * KV_KEYS + ksub * 32
+                for (t, mode) in units[ksub]:
+                    if mode == 0:
+                        continue
+                    for key in range(kbase, min(kbase + 32, S)):
+                        for q in range(t * QT, min(t * QT + QT, S)):
+                            ok = True if mode == 1 else dkv_element_valid(qmask, flag, q, key, t, var, S, length)
+                            if ok:
+                                assert (q, key) not in cover, ("pair covered twice", q, key)
+                                cover[(q, key)] = var
+        for key in range(kb * KV_KEYS, min(kb * KV_KEYS + KV_KEYS, S)):
+            for q in range(S):
+                if q >= key and key < length:
+                    assert cover.get((q, key)) == int(flag[q] != flag[key]), ("missing / wrong variant", q, key)
+                else:
+                    assert (q, key) not in cover, ("pair should be masked", q, key)

@@ -39,7 +39,7 @@ CFG4 = [("7036x22016x4096", 64), ("22016x4096x7040 aT bT", 32), ("7036x4096x2201
         ("3x[1156x4096x1024]", 64), ("1156x4096x1024", 96), ("5504x4096x1216 aT bT", 32), ("3x[1156x1024x4096 bT]", 32)]
 TEXT = HEADLINE[:6] + HEADLINE[9:11] + [("4624x4096x1024", 64), ("4624x5504x4096", 32), ("11008x2752x4672 aT bT", 64)]
 SETS = {"text": TEXT, "headline": HEADLINE, "vit": VIT, "cfg3": CFG3, "cfg4": CFG4}
-TILES = [("auto", 0), ("128", 1), ("256", 2), ("W", 3)]        # (+ ("X", 4) with tools/r04_experiments/gemm_bf16_x_*.hip built in)
+TILES = [("auto", 0), ("128", 1), ("256", 2), ("W", 3)]        # (+ ("X", 4) with experiments/r04/gemm_bf16_x_*.hip built in)
 if os.environ.get("SWEEP_TILES"):
     TILES = [t for t in TILES if t[0] in os.environ["SWEEP_TILES"].split(",")]
 
