@@ -700,7 +700,8 @@ def main():
         from libra_amd import kernels as K
         cu = K.ReservedCUStream(args.cu_reserve)
         cu.__enter__()                                   # every step below (probe, timed region, diagnostics) runs on the masked stream
-        extra["cu_budget"] = {"reserved_for_rccl": cu.reserve, "compute_cus": cu.cus, "physical_cus": K.cu_count()}
+        extra["cu_budget"] = {"reserved_for_rccl": cu.reserve, "compute_cus": cu.cus, "persistent_kernel_cus": cu.persistent_cus,
+                              "physical_cus": K.cu_count()}
         note(f"cu budget: {extra['cu_budget']}")
     if args.fallback_from:
         extra["exchange_fallback"] = f"the probe of {args.fallback_from!r} did not finish in {args.probe_watchdog_s:.0f} s; re-executed with allreduce"

@@ -395,15 +395,24 @@ int libra_sumsq_bf16(const void* x, int64_t n, float* out, int accumulate, float
  * The reference overlaps DeepSpeed's reduce-scatter with backward (libra/configs/deepspeed_configs/ZeRO-2.json:15-21,
  * "overlap_comm": true); on MI355X RCCL's reduction kernels need compute units of their own while the GEMM / attention kernels
  * (one 128-KiB-LDS workgroup per CU) occupy all 256.  Two knobs, both off by default:
- *  - libra_stream_create_cu_reserved: a HIP stream whose kernels may use all CUs EXCEPT `reserve_cus` of them (a CU mask with
- *    the highest `reserve_cus` bits cleared - the mask is dealt round-robin over the 8 XCDs, so 8 = one CU per XCD); the caller
- *    runs the step on it (torch.cuda.ExternalStream) and leaves RCCL on its own unmasked stream.  *cus_out = CUs left.
+ *  - libra_stream_create_cu_reserved: a HIP stream whose kernels may use all CUs EXCEPT `reserve_cus` of them (a CU mask with the
+ *    highest `reserve_cus` bits cleared: mask bit b is a CU of XCC b % 8, shader engine (b / 8) % 4 - measured,
+ *    profiles/r05_cu_mask_layout.txt - so 8 = one CU per XCD).  The hardware deals workgroups to the shader engines of an XCC
+ *    round-robin whatever their CU counts: a reserve that is not a multiple of 32 (one CU per SE per XCC) leaves SE 3 of every
+ *    XCC short and a one-workgroup-per-CU grid waits for it (measured: GEMM +4 %, persistent attention forward +90 % at 8 reserved,
+ *    +20 % at 32; profiles/r05_cu_budget_probe*.txt).  The caller runs the step on the stream (torch.cuda.ExternalStream) and
+ *    leaves RCCL on its own unmasked stream.  *cus_out = CUs left.
  *  - libra_set_cu_budget: the PERSISTENT kernels (bridge attention forward / dQ pass) size their grid to `cus` workgroups
  *    instead of one per physical CU (0 = all).  Returns the previous value.  Thread-safe, takes effect at the next launch. */
 int libra_stream_create_cu_reserved(int32_t reserve_cus, void** stream_out, int32_t* cus_out);
 int libra_stream_destroy(void* stream);
 int libra_set_cu_budget(int32_t cus);
 int libra_get_cu_count(void);
+/* Diagnostics of the above: a stream with a caller-given raw CU mask (nwords x 32 bits), and a kernel that records, per workgroup
+ * (one per CU: 128 KiB of LDS each, resident for ~spin x 64 x 64 clocks), HW_REG_HW_ID and HW_REG_XCC_ID into out[2 b], out[2 b + 1]:
+ * which physical CUs a mask enables (tools/cu_mask_probe.py -> profiles/r05_cu_mask_layout.txt). */
+int libra_stream_create_cu_mask(const uint32_t* mask, int32_t nwords, void** stream_out);
+int libra_debug_cu_map(uint32_t* out, int32_t nblocks, int32_t spin, void* stream);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,8 @@ SIGNATURES = {
     "libra_stream_destroy": [_P],
     "libra_set_cu_budget": [C.c_int32],
     "libra_get_cu_count": [],
+    "libra_stream_create_cu_mask": [_P, C.c_int32, _P],
+    "libra_debug_cu_map": [_P, C.c_int32, C.c_int32, _P],
 }
 
 ABI_VERSION = 12

@@ -15,6 +15,16 @@
 #include "hip_common.hpp"
 #include "../../include/libra_hip.h"
 
+#ifndef LIBRA_DKV_GUESS_CROSS   // A/B switches of the dK/dV pass (compile time; the shipped values are the defaults)
+#define LIBRA_DKV_GUESS_CROSS 0
+#endif
+#ifndef LIBRA_DKV_NF
+#define LIBRA_DKV_NF 6
+#endif
+#ifndef LIBRA_DKV_DBG
+#define LIBRA_DKV_DBG 0
+#endif
+
 namespace libra {
 
 constexpr int D128 = 128;
@@ -449,7 +459,14 @@ constexpr int KV6_SLOT_OFF = KV6_NSTAGE * KV6_STAGE;  // P hand-over: 4 pairs x 
 constexpr int KV6_MASK_OFF = KV6_SLOT_OFF + 4 * 4096; // query-modality words (<= 130; 1 KiB)
 constexpr int KV6_BLK_OFF = KV6_MASK_OFF + 1024;      // block-level unit set (2 words)
 constexpr int KV6_TAB_OFF = KV6_BLK_OFF + 64;         // per-wave unit tables: 8 x 64 x 2 B
+#if LIBRA_DKV_DBG & 128          // timing-only anatomy build: cycle stamps of one heavy item (key block 5, "same"), dumped over the start of dk_same
+constexpr int KV6_STAMP_OFF = KV6_TAB_OFF + 8 * 128;
+constexpr int KV6_LDS_B = KV6_STAMP_OFF + 8 * 1024;
+#define KSTAMP() do { if (dbg_item) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); if (lane == 0 && n_stamp < 256) ((unsigned*)(smem + KV6_STAMP_OFF))[wave * 256 + n_stamp] = t_; ++n_stamp; } } while (0)
+#else
 constexpr int KV6_LDS_B = KV6_TAB_OFF + 8 * 128;
+#define KSTAMP() ((void)0)
+#endif
 constexpr int KV6_KEYS = 128;
 
 __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const BridgeBwdArgs p) {
@@ -466,6 +483,11 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     const int item = xcd_remap(blockIdx.x, nitems);
     const int var = item & 1;
     const int kb = (item >> 1) % n_kb;                            // low key blocks see the most queries: they come first
+#if LIBRA_DKV_DBG & 128
+    const bool dbg_item = item == 10;
+    int n_stamp = 0;
+    const unsigned long long t_item0 = __builtin_readcyclecounter();
+#endif
     const int bh = (item >> 1) / n_kb;
     const int h = bh % p.H, b = bh / p.H;
     const int S = p.S;
@@ -520,8 +542,11 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
 
     // ---- prologue: the first two stages on a guess (the first two tiles that can see the block), this lane's key modality and
     // its 8 B-operand fragments (K rows for a dV wave, V rows for a dK wave, of the item's variant), the query modality words
-    if (t_first < nqt) stage_tile(t_first, 0);
-    if (t_first + 1 < nqt) stage_tile(t_first + 1, 1);
+    // (guessed for the "same" variant only: a "cross" item's first pair is usually far from the block's diagonal - text queries
+    //  behind an image - or it has none at all, and then nothing is in flight when it finds that out)
+    const bool guess = var == 0 || LIBRA_DKV_GUESS_CROSS;
+    if (guess && t_first < nqt) stage_tile(t_first, 0);
+    if (guess && t_first + 1 < nqt) stage_tile(t_first + 1, 1);
     int k_vis_i = p.flag[tok0 + key] != 0;
     bf16x8 bfr[8];
     {
@@ -617,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     };
     {
         const unsigned e0 = entry(0), e1 = entry(1);
-        const bool ok0 = (int)(e0 >> 3) == t_first, ok1 = U < 2 || (int)(e1 >> 3) == t_first + 1;
+        const bool ok0 = guess && (int)(e0 >> 3) == t_first, ok1 = U < 2 || (guess && (int)(e1 >> 3) == t_first + 1);
         if (!ok0 || !ok1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -646,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     for (int ks = 0; ks < 8; ++ks) pin(bfr[ks]);                  // prologue loads have landed before the loop's LDS-DMA traffic
 
     union VA { bf16x8 v; s16x4 h2[2]; };
-    constexpr int NF = 6;
+    constexpr int NF = LIBRA_DKV_NF;
     auto m_phase = [&](auto ac_c, auto nx_c, const char* cur, const char* nxt) {
         constexpr bool AC = decltype(ac_c)::value, NX = decltype(nx_c)::value;
         constexpr int N = (AC ? 16 : 0) + (NX ? 16 : 0), I0 = AC ? 0 : 16;
@@ -701,6 +726,7 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     // VALU phase of unit u (entry e): request stage u + 2 (entry e2), then
     //   dV wave: P = exp2(S sl2 - L) masked -> pk and the slot;      dK wave: dS = P (dP - D) -> pk, P read from the slot
     auto v_phase = [&](const int u, const unsigned e, const unsigned e2) {
+        KSTAMP();                                                 // [0] V phase start
         const bool issue = u + 2 < U;
         if (issue) stage_tile((int)(e2 >> 3), (u + 2) & (KV6_NSTAGE - 1));
         const float* sL = (const float*)(stage_of(u) + 2 * KV6_TILE);
@@ -737,6 +763,7 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
                 *(bf16x8*)(slot + st * 1024) = pk[st].v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the slot is written before the barrier that releases its reader
+            KSTAMP();                                             // [1] arithmetic + slot write done (dV wave)
             if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             const float* sD = sL + 64;
@@ -757,12 +784,17 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) pin(pk[st].v);             // HERE: keep this phase's arithmetic out of the M phase's MFMA stream
+        if (role == 1) KSTAMP();                                  // [1] arithmetic done (dK wave)
+        KSTAMP();                                                 // [2] staging wait done
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        KSTAMP();                                                 // [3] barrier passed = M start
     };
     auto m_end = [&]() {
+        KSTAMP();                                                 // [4] MFMAs issued
         if (role == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // group 1: its pieces of stage u + 2, requested in its DS_u
+        KSTAMP();                                                 // [5] staging wait done
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -801,6 +833,15 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     }
     if (role == 0) __builtin_amdgcn_s_barrier();                  // re-align the two groups
     __syncthreads();
+#if LIBRA_DKV_DBG & 128
+    if (dbg_item) {
+        unsigned* dump = (unsigned*)p.dk_same;
+        for (int i = tid; i < 2048; i += 512) dump[i] = ((unsigned*)(smem + KV6_STAMP_OFF))[i];
+        if (tid == 0) { dump[2048] = (unsigned)U; dump[2058] = (unsigned)(__builtin_readcyclecounter() - t_item0); }
+        if (lane == 0) dump[2049 + wave] = (unsigned)Uw;
+    }
+    return;
+#endif
     store_out();
 }
 

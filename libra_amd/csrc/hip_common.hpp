@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;        // one MFMA A/B
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;       // 32x32 accumulator fragment
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;         // operand of the packed fp32 VALU ops (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 

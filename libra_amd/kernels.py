@@ -960,7 +960,10 @@ class ReservedCUStream:
         _lib.check(_lib.lib().libra_stream_create_cu_reserved(int(reserve), ctypes.byref(h), ctypes.byref(cus)), "stream_create_cu_reserved")
         self.handle, self.cus, self.reserve = h.value, int(cus.value), int(reserve)
         self.stream = torch.cuda.ExternalStream(self.handle)
-        self._prev = set_cu_budget(self.cus)
+        # persistent kernels: one workgroup per CU only where every shader engine still has its full CU count - the hardware deals
+        # workgroups to an XCC's four SEs round-robin, so the grid is sized for the SE-symmetric part (multiples of 32 reserved)
+        self.persistent_cus = cu_count() - 32 * ((int(reserve) + 31) // 32)
+        self._prev = set_cu_budget(max(self.persistent_cus, 32))
         self._ctx = None
 
     def __enter__(self):
