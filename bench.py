@@ -344,7 +344,7 @@ def hbm_traffic(workload):
     """Mean HBM bytes per GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/) -> (bytes, file name,
     provenance dict); (None, None, None) if absent.  The PMC passes cannot run inside the timed command (they serialise kernels),
     so the number is read from the newest committed file and marked `stale` when the GEMM sources changed since it was measured."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{workload}.json")
         try:
             with open(path) as f:

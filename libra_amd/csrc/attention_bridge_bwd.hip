@@ -24,6 +24,9 @@
 #ifndef LIBRA_DKV_DBG
 #define LIBRA_DKV_DBG 0
 #endif
+#ifndef LIBRA_DKV_ROWPRE        // 1: a unit's L (dV wave) / D (dK wave) rows are read from LDS one phase early, ahead of the M phase's fragments
+#define LIBRA_DKV_ROWPRE 0
+#endif
 
 namespace libra {
 
@@ -723,6 +726,12 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
 
     const u64 act = __ballot((tab0 & 3u) != 0);
     const int Uw = act ? 64 - (int)__builtin_clzll(act) : 0;
+    f32x4 rowv[8];                                                // L (dV wave) / D (dK wave) of the next unit's 64 queries, this lane's rows
+    auto load_rows = [&](const int u_) {
+        const float* sv = (const float*)(stage_of(u_) + 2 * KV6_TILE) + role * 64;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) rowv[g] = *(const f32x4*)(sv + 8 * g + 4 * fk);
+    };
     // VALU phase of unit u (entry e): request stage u + 2 (entry e2), then
     //   dV wave: P = exp2(S sl2 - L) masked -> pk and the slot;      dK wave: dS = P (dP - D) -> pk, P read from the slot
     auto v_phase = [&](const int u, const unsigned e, const unsigned e2) {
@@ -734,7 +743,11 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
             float a[16], c[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+#if LIBRA_DKV_ROWPRE
+                const f32x4 La = rowv[g], Lc = rowv[4 + g];
+#else
                 const f32x4 La = *(const f32x4*)(sL + 8 * g + 4 * fk), Lc = *(const f32x4*)(sL + 32 + 8 * g + 4 * fk);
+#endif
 #pragma unroll
                 for (int e_ = 0; e_ < 4; ++e_) {
                     a[4 * g + e_] = __builtin_amdgcn_exp2f(__builtin_fmaf(sA[4 * g + e_], p.sl2, -La[e_] * LOG2E));
@@ -775,7 +788,11 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
                 for (int j = 0; j < 4; ++j) {
                     const int r0_ = 8 * (st & 1) + 2 * j;         // accumulator rows r0, r0 + 1 <-> queries 32 (st >> 1) + 8 (r0 >> 2) + 4 fk + (r0 & 3), + 1
                     const int ql = 32 * (st >> 1) + 8 * (r0_ >> 2) + 4 * fk + (r0_ & 3);
+#if LIBRA_DKV_ROWPRE
+                    const float d0 = rowv[2 * st + (j >> 1)][2 * (j & 1)], d1 = rowv[2 * st + (j >> 1)][2 * (j & 1) + 1];   // = sD[ql], sD[ql + 1]
+#else
                     const float d0 = sD[ql], d1 = sD[ql + 1];
+#endif
                     const float p0 = __uint_as_float(pv.u[j] << 16), p1 = __uint_as_float(pv.u[j] & 0xffff0000u);
                     const float x0 = st < 2 ? sA[r0_] : sB[r0_], x1 = st < 2 ? sA[r0_ + 1] : sB[r0_ + 1];
                     pk[st].u[j] = pack2bf(p0 * (x0 - d0), p1 * (x1 - d1));
@@ -803,12 +820,18 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     __syncthreads();                                              // stages 0 and 1 landed
     unsigned e_cur = entry(0), e_nxt = entry(1), e_dma = entry(2);
     if (role == 1) __builtin_amdgcn_s_barrier();
+#if LIBRA_DKV_ROWPRE
+    if (Uw > 0) load_rows(0);
+#endif
     if (Uw > 0) m_phase(std::false_type{}, std::true_type{}, nullptr, stage_of(0));
     __builtin_amdgcn_s_barrier();
     int u = 0;
     for (; u + 1 < Uw; ++u) {
         v_phase(u, e_cur, e_dma);
         __builtin_amdgcn_s_setprio(1);
+#if LIBRA_DKV_ROWPRE
+        load_rows(u + 1);                                         // stage u + 1 has landed (this M phase reads its rows)
+#endif
         m_phase(std::true_type{}, std::true_type{}, stage_of(u), stage_of(u + 1));
         __builtin_amdgcn_s_setprio(0);
         m_end();
