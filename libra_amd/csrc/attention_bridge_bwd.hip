@@ -25,7 +25,7 @@
 #define LIBRA_DKV_DBG 0
 #endif
 #ifndef LIBRA_DKV_ROWPRE        // 1: a unit's L (dV wave) / D (dK wave) rows are read from LDS one phase early, ahead of the M phase's fragments
-#define LIBRA_DKV_ROWPRE 0
+#define LIBRA_DKV_ROWPRE 1
 #endif
 
 namespace libra {
