@@ -113,7 +113,10 @@ def _attn_ref(q, ks, kc, vs, vc, flag, lens, B, S, H, scale):
 @pytest.mark.parametrize("B,S,H,mode", [(1, 16, 1, "span"), (2, 33, 2, "random"), (1, 128, 1, "none"), (2, 200, 2, "span"),
                                         (1, 640, 2, "random"), (1, 257, 1, "allvis"), (2, 1024, 2, "span"),
                                         # BASELINE sequence lengths (configs[2]: 2048, configs[4]: 4096), one or two heads
-                                        (2, 2048, 1, "span"), (1, 4096, 1, "random")])
+                                        (2, 2048, 1, "span"), (1, 4096, 1, "random"),
+                                        # 640 items on <= 256 persistent workgroups: every workgroup walks 2-3 items (the rotation
+                                        # schedule, LDS reuse across items) - the training shape's regime, at a size the reference finishes
+                                        (2, 512, 160, "span")])
 def test_bridge_attention_fwd(K, B, S, H, mode):
     N, D = B * S, H * 128
     q, ks, kc, vs, vc = [rnd(N, D, seed=10 + i) for i in range(5)]
@@ -133,7 +136,8 @@ def test_bridge_attention_fwd(K, B, S, H, mode):
 
 @pytest.mark.parametrize("B,S,H,mode", [(1, 16, 1, "span"), (2, 33, 2, "random"), (1, 128, 1, "none"), (2, 200, 2, "span"),
                                         (1, 320, 1, "random"), (2, 512, 2, "span"),
-                                        (2, 2048, 1, "span"), (1, 4096, 1, "random")])     # BASELINE sequence lengths
+                                        (2, 2048, 1, "span"), (1, 4096, 1, "random"),      # BASELINE sequence lengths
+                                        (2, 512, 160, "span")])                            # several items per persistent workgroup (dQ pass)
 def test_bridge_attention_bwd(K, B, S, H, mode):
     N, D = B * S, H * 128
     q, ks, kc, vs, vc = [rnd(N, D, seed=20 + i) for i in range(5)]
