@@ -24,6 +24,14 @@
 #ifndef LIBRA_DKV_DBG
 #define LIBRA_DKV_DBG 0
 #endif
+#ifndef LIBRA_DKV6_PERSIST      // 1: persistent dK/dV workgroups with the rotation schedule
+#define LIBRA_DKV6_PERSIST 0
+#endif
+#if LIBRA_DKV6_PERSIST
+#define KV6_NEXT_ITEM continue
+#else
+#define KV6_NEXT_ITEM return
+#endif
 #ifndef LIBRA_DKV_ROWPRE        // 1: a unit's L (dV wave) / D (dK wave) rows are read from LDS one phase early, ahead of the M phase's fragments
 #define LIBRA_DKV_ROWPRE 1
 #endif
@@ -483,7 +491,19 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     const int fk = lane >> 5, l31 = lane & 31;
     const int n_kb = p.n_t;                                       // 128-key blocks per sequence
     const int nitems = p.B * p.H * n_kb * 2;
+#if LIBRA_DKV6_PERSIST
+    // persistent workgroups, static rotation (the forward kernel's schedule): item i = w + k P is (sequence, head) i / (2 n_kb) and
+    // (block, variant) index (i + k) mod 2 n_kb - every workgroup meets every (block, variant) weight once per 2 n_kb steps
+    const int P = (int)gridDim.x;
+    const int per_bh = 2 * n_kb;
+    const int w_id = xcd_remap(blockIdx.x, P);
+#pragma unroll 1
+    for (int step = 0, item0 = w_id; item0 < nitems; ++step, item0 += P) {
+    const int item = (item0 / per_bh) * per_bh + (item0 % per_bh + step) % per_bh;
+#else
+    {
     const int item = xcd_remap(blockIdx.x, nitems);
+#endif
     const int var = item & 1;
     const int kb = (item >> 1) % n_kb;                            // low key blocks see the most queries: they come first
 #if LIBRA_DKV_DBG & 128
@@ -630,7 +650,8 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                          // everybody's guessed pieces have landed: LDS is free
         store_out();
-        return;
+        __syncthreads();                                          // (persistent: the next item's staging overwrites the store rows)
+        KV6_NEXT_ITEM;
     }
 
     unsigned tab0;                                                // lane i: entry of unit i = mode | tile << 3 (0 past the end)
@@ -866,6 +887,8 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     return;
 #endif
     store_out();
+    __syncthreads();                                              // (persistent: the next item's staging overwrites the store rows)
+    }   // item loop
 }
 
 }  // namespace libra
@@ -916,6 +939,9 @@ extern "C" int libra_bridge_attn_bwd(const void* q, int64_t ldq, const void* k_s
     a.n_t = (int)((S + KV6_KEYS - 1) / KV6_KEYS);
     nblk = (long)B * H * a.n_t * 2;
     if (nblk > 0x7fffffffL) return LIBRA_ERR_SHAPE;
+#if LIBRA_DKV6_PERSIST
+    nblk = persistent_grid(nblk, 2 * a.n_t);
+#endif
     hipLaunchKernelGGL(bridge_attn_bwd_dkv6_kernel, dim3((unsigned)nblk), dim3(512), KV6_LDS_B, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
 }
