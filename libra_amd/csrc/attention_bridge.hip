@@ -76,10 +76,9 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* kmask = (unsigned*)(smem + MASK_OFF);               // per 32 keys: bit j = key j is a vision token
     unsigned* blk = (unsigned*)(smem + BLK_OFF);                  // [0,1] tiles with a same unit, [2,3] tiles with a cross unit
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int grp = wave >> 2;                                    // waves w and w + 4 share a SIMD: one of each group
-    const int fk = lane >> 5, l31 = lane & 31;
 
     // ---- persistent workgroups, static schedule.  The launcher starts P workgroups (one per CU, P a multiple of n_qt); workgroup
     // w (after the XCD remap: XCD x owns w in [32x, 32x + 32)) handles the items i = w + k P, k = 0, 1, ...: sequence-head
@@ -93,6 +92,10 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_fwd_kernel(const BridgeArg
     const int w_id = xcd_remap(blockIdx.x, P);
 #pragma unroll 1
     for (int step = 0, item = w_id; item < nitems; ++step, item += P) {
+    int tid = tid0;                                                 // opaque per item: lane constants are re-derived inside the item instead of
+    asm volatile("" : "+v"(tid));                                   // being hoisted out of the persistent loop and held in registers across it
+    const int lane = tid & 63;
+    const int fk = lane >> 5, l31 = lane & 31;
     const int qt = p.n_qt - 1 - ((item % p.n_qt + step) % p.n_qt);
     const int bh = item / p.n_qt;
     const int h = bh % p.H, b = bh / p.H;

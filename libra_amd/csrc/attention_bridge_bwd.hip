@@ -24,16 +24,17 @@
 #ifndef LIBRA_DKV_DBG
 #define LIBRA_DKV_DBG 0
 #endif
-#ifndef LIBRA_DKV6_PERSIST      // 1: persistent dK/dV workgroups with the rotation schedule
-#define LIBRA_DKV6_PERSIST 0
+#ifndef LIBRA_DKV6_PERSIST      // 1: persistent dK/dV workgroups with the rotation schedule (-0.13 ms per layer: profiles/r05_attn/dkv_switches_ab.txt)
+#define LIBRA_DKV6_PERSIST 1
 #endif
 #if LIBRA_DKV6_PERSIST
 #define KV6_NEXT_ITEM continue
 #else
 #define KV6_NEXT_ITEM return
 #endif
-#ifndef LIBRA_DKV_ROWPRE        // 1: a unit's L (dV wave) / D (dK wave) rows are read from LDS one phase early, ahead of the M phase's fragments
-#define LIBRA_DKV_ROWPRE 1
+#ifndef LIBRA_DKV_ROWPRE        // 1: a unit's L / D rows are read from LDS one phase early (-0.03 ms in the one-item-per-workgroup build, +0.05 ms in the
+                                // persistent one: its 25 registers push lane constants into scratch around the item loop)
+#define LIBRA_DKV_ROWPRE 0
 #endif
 
 namespace libra {
@@ -89,10 +90,9 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dq_kernel(const Bridge
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* kmask = (unsigned*)(smem + DQ_MASK_OFF);
     unsigned* blk = (unsigned*)(smem + DQ_BLK_OFF);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int grp = wave >> 2;
-    const int fk = lane >> 5, l31 = lane & 31;
     // persistent workgroups with the forward kernel's static rotation schedule (bridge_attn_fwd_kernel): item i = w + k P is
     // (sequence, head) i / n_t, query block (i + k) mod n_t
     const int nitems = p.B * p.H * p.n_t;
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dq_kernel(const Bridge
     const int w_id = xcd_remap(blockIdx.x, P);
 #pragma unroll 1
     for (int step = 0, item = w_id; item < nitems; ++step, item += P) {
+    int tid = tid0;                                                 // opaque per item: lane constants are re-derived inside the item, not
+    asm volatile("" : "+v"(tid));                                   // hoisted out of the persistent loop and held across it (see the dK/dV pass)
+    const int lane = tid & 63;
+    const int fk = lane >> 5, l31 = lane & 31;
     const int qt = p.n_t - 1 - ((item % p.n_t + step) % p.n_t);
     const int bh = item / p.n_t;
     const int h = bh % p.H, b = bh / p.H;
@@ -484,11 +488,10 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* qmask = (unsigned*)(smem + KV6_MASK_OFF);
     unsigned* blk = (unsigned*)(smem + KV6_BLK_OFF);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int role = wave >> 2;                                   // 0: dV wave (group 0), 1: dK wave (group 1, one phase behind)
     const int ksub = wave & 3;
-    const int fk = lane >> 5, l31 = lane & 31;
     const int n_kb = p.n_t;                                       // 128-key blocks per sequence
     const int nitems = p.B * p.H * n_kb * 2;
 #if LIBRA_DKV6_PERSIST
@@ -504,6 +507,13 @@ __global__ __launch_bounds__(512, 2) void bridge_attn_bwd_dkv6_kernel(const Brid
     {
     const int item = xcd_remap(blockIdx.x, nitems);
 #endif
+    // (the thread id is made opaque per item: every lane constant below is then re-derived inside the item instead of being
+    //  hoisted out of the persistent loop and kept in registers across it - ~50 VGPRs, which is what made the first persistent
+    //  build spill inside its unit loop)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int fk = lane >> 5, l31 = lane & 31;
     const int var = item & 1;
     const int kb = (item >> 1) % n_kb;                            // low key blocks see the most queries: they come first
 #if LIBRA_DKV_DBG & 128
