@@ -34,6 +34,9 @@
 #ifndef TO256
 #define TO256 4, 8, 4, 2
 #endif
+#ifndef LIBRA_GEMM256_PERSIST
+#define LIBRA_GEMM256_PERSIST 1
+#endif
 namespace libra {
 
 constexpr int HB = 16384;               // one 128x64 half-tile
@@ -41,16 +44,25 @@ constexpr int KTB = 4 * HB;             // one K tile: A_lo A_hi B_lo B_hi
 constexpr int G256_LDS = 2 * KTB;       // 128 KiB
 constexpr int G256_THREADS = 512;
 
-template <bool AT, bool BT>
+// PERS: persistent workgroups (round 5) - the launcher starts one workgroup per CU and workgroup w walks the tiles w, w + P, w + 2 P, ...
+// in the order the hardware would have dispatched them (so the lock-step L2 sharing of a wave of tiles is kept); every per-lane
+// constant is re-derived per tile from an opaque copy of the thread id (hoisted out of the tile loop they cost the registers that
+// made the round-2 persistent attempt spill).
+template <bool AT, bool BT, bool PERS>
 __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+#pragma unroll 1
+    for (int bid = blockIdx.x; bid < ntiles; bid += PERS ? (int)gridDim.x : ntiles) {
+    int tid = tid0;
+    if (PERS) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int l31 = lane & 31, fk = lane >> 5;
 
-    const TileRC trc = tile_order<TO256>(blockIdx.x, p.tiles_m, p.tiles_n);
+    const TileRC trc = tile_order<TO256>(bid, p.tiles_m, p.tiles_n);
     const int tm = trc.tm, tn = trc.tn;
     const int m0 = tm * 256, n0 = tn * 256;
     // grouped launch (same shapes / strides / row maps, different operands): blockIdx.z picks the group
@@ -229,6 +241,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
     float* ct = (float*)(smem + wave * 8192);
     if (m0 + 256 <= p.M && n0 + 256 <= p.N) gemm_wave_epilogue<true>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
     else gemm_wave_epilogue<false>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
+    if (PERS) __syncthreads();                                 // the next tile's staging overwrites the epilogue's LDS slabs
+    }   // tile loop
 }
 
 // out[row(m)][n] = bf16( sum_s slab[s][m][n] (+ resid[row(m)][n]) ), row(m) = c_rows ? c_rows[m] : m; 8 elements per thread
@@ -284,15 +298,20 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     p.slab = slab; p.splitk = splitk < 1 ? 1 : splitk;
     p.a_rows = a_rows; p.c_rows = c_rows;
     const int at = (flags & LIBRA_GEMM_A_T) ? 1 : 0, bt = (flags & LIBRA_GEMM_B_T) ? 1 : 0;
+    long nblk = (long)p.tiles_m * p.tiles_n;
+    // persistent form: plain launches (no split-K, no groups) with more tiles than CUs
+    const bool pers = LIBRA_GEMM256_PERSIST && p.splitk == 1 && groups <= 1 && nblk > cu_count();
     void (*kern)(const Gemm256Args) =
-        at ? (bt ? gemm_bf16_nt_256_kernel<true, true> : gemm_bf16_nt_256_kernel<true, false>)
-           : (bt ? gemm_bf16_nt_256_kernel<false, true> : gemm_bf16_nt_256_kernel<false, false>);
-    static std::atomic<bool> attr_set[4];           // zero-initialised; idempotent call, atomic so concurrent first launches do not race
-    if (!attr_set[at * 2 + bt]) {
+        pers ? (at ? (bt ? gemm_bf16_nt_256_kernel<true, true, true> : gemm_bf16_nt_256_kernel<true, false, true>)
+                   : (bt ? gemm_bf16_nt_256_kernel<false, true, true> : gemm_bf16_nt_256_kernel<false, false, true>))
+             : (at ? (bt ? gemm_bf16_nt_256_kernel<true, true, false> : gemm_bf16_nt_256_kernel<true, false, false>)
+                   : (bt ? gemm_bf16_nt_256_kernel<false, true, false> : gemm_bf16_nt_256_kernel<false, false, false>));
+    static std::atomic<bool> attr_set[8];           // zero-initialised; idempotent call, atomic so concurrent first launches do not race
+    if (!attr_set[(pers ? 4 : 0) + at * 2 + bt]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-        attr_set[at * 2 + bt] = true;
+        attr_set[(pers ? 4 : 0) + at * 2 + bt] = true;
     }
-    const long nblk = (long)p.tiles_m * p.tiles_n;
+    if (pers) nblk = persistent_grid(nblk, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)p.splitk, (unsigned)(groups < 1 ? 1 : groups)), dim3(G256_THREADS), G256_LDS,
                        (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
