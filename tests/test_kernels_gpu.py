@@ -132,7 +132,10 @@ TILES = {"128": 1, "256": 2, "W": 3}      # include/libra_hip.h LIBRA_GEMM_TILE_
 @pytest.mark.parametrize("M,N,K_,a_t,b_t", [(256, 128, 64, False, False), (300, 264, 192, False, False), (1000, 1024, 1024, False, False),
                                             (4624, 1024, 1024, False, False), (4624, 4096, 1024, False, True),
                                             (1024, 1024, 4672, True, True), (2752, 520, 1152, True, False), (130, 136, 192, True, True),
-                                            (976, 4096, 2048, False, True), (577, 200, 128, False, False), (8, 72, 64, False, False)])
+                                            (976, 4096, 2048, False, True), (577, 200, 128, False, False), (8, 72, 64, False, False),
+                                            # 20 x 28 = 560 tiles of 256^2 on <= 256 persistent workgroups: 2-3 tiles per workgroup, ragged edges,
+                                            # an odd K-tile count (the prefetched next tile lands in the other K-tile buffer)
+                                            (5000, 7000, 192, False, False), (5000, 7000, 320, True, True)])
 def test_gemm_every_tile_structure(K, M, N, K_, a_t, b_t, tile):
     """The three tile structures (128^2 x two per CU, 256^2 x one per CU, W = 256x128 x two per CU) share one contract; the
     caller-pinned entry point runs each of them on ragged, transposed and multi-K-tile problems against fp32 math.  The three
