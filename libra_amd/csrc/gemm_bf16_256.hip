@@ -58,7 +58,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_nt_256_kernel(const
 #pragma unroll 1
     for (int bid = blockIdx.x; bid < ntiles; bid += PERS ? (int)gridDim.x : ntiles) {
     int tid = tid0;
-    if (PERS) asm volatile("" : "+v"(tid));
+    asm volatile("" : "+v"(tid));          // (also in the one-tile form: 17-29 VGPR spills around its K loop become 0-2)
     const int lane = tid & 63;
     const int l31 = lane & 31, fk = lane >> 5;
 
