@@ -828,6 +828,9 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             extra["vit_leg"] = {"error": repr(e)[:200]}
+    if cu is not None:                                   # leave the CU-masked stream: restore the persistent-grid budget, destroy the stream
+        cu.__exit__(None, None, None)
+        cu.close()
     if extra:
         out["extra"] = extra
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -155,3 +155,41 @@ def test_two_rank_decoder_exchange_with_a_text_only_rank(mode):
     for rank, worst, nbytes, launches in res:
         assert worst < 1e-2, (mode, rank, worst)
         assert nbytes > 0 and launches >= 2
+
+
+def test_cu_reserved_stream_runs_the_kernels_and_restores_the_budget():
+    """The CU-budget knob of the data-parallel layer (include/libra_hip.h "compute-unit budget"): a GEMM and the persistent
+    bridge-attention kernels launched on a CU-masked stream (32 CUs left to RCCL, persistent grids sized to the rest) give the
+    bit-identical results of the default stream; the budget is restored when the stream is closed; the CU map diagnostic sees
+    fewer distinct CUs under the mask."""
+    import ctypes
+    from libra_amd import _lib, kernels as K
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    a, b = rnd(5000, 512), rnd(7000, 512)                      # 560 tiles of 256^2: the persistent GEMM path
+    B, S, H = 2, 512, 160                                      # 640 attention items
+    q, ks, kc, vs, vc = [rnd(B * S, H * 128) for _ in range(5)]
+    flag = torch.zeros(B * S, dtype=torch.uint8, device="cuda"); flag[100:300] = 1
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+
+    def run():
+        c = K.gemm_nt(a, b)
+        o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, 128 ** -0.5, need_lse=True)
+        return c, o, lse
+    ref = run()
+    total = K.cu_count()
+    assert K.set_cu_budget(0) == 0                             # default: no budget
+    rs = K.ReservedCUStream(32)
+    assert rs.cus == total - 32 and rs.persistent_cus == total - 32
+    with rs:
+        got = run()
+        out = torch.zeros(2 * 512, dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib().libra_debug_cu_map(out.data_ptr(), 512, 20, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "cu_map")
+    torch.cuda.synchronize()
+    rs.close()
+    assert K.set_cu_budget(0) == 0                             # restored by close()
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
+    w = out.cpu().numpy().astype("int64") & 0xffffffff
+    seen = {(int(w[2 * i + 1]) & 15, (int(w[2 * i]) >> 8) & 0xff) for i in range(512)}
+    assert 1 <= len(seen) <= total - 32, len(seen)
