@@ -399,7 +399,7 @@ __device__ __forceinline__ void stage_kv4(const bf16_t* __restrict__ kp, unsigne
 // spent ~200 v_accvgpr moves per tile and spilled).  Every MFMA of the kernel is inline asm (with builtin MFMAs hipcc may pick the
 // AGPR form and allocate the same registers); the arch VGPRs carry S^T, Q, the fragments and the softmax.  hipcc neither inserts
 // wait states for these statements nor sees their latency: they are placed here (cdna_hip_programming.md 5.7).  Audit after every
-// edit (tools/isa_blocks.py): no spills, no scratch, and no v_accvgpr / a[..] outside these statements.
+// edit (experiments/tools/isa_blocks.py): no spills, no scratch, and no v_accvgpr / a[..] outside these statements.
 #define LIBRA_A16(n) "a" #n
 #define LIBRA_ACC_CLOBBER                                                                                                  \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19",   \

@@ -14,7 +14,7 @@
 //     wave 100-185 cycles next to ds_reads but ~50 among MFMAs; with the pieces next to the reads the "read" interval of
 //     one wave group outlasted the 256-cycle MFMA interval of the other - moving them took the step GEMMs from 7.43 to
 //     7.10 ms (positions 0|4: no gain, 3|7: half; phase 4's two pieces back in its read-free load part: 7.25), a steady-state loop body without tail tests and one LDS address-space
-//     cast per kernel instead of per piece to 6.83 ms (tools/gemm_big.py; sq8k 1265 -> 1394 TFLOP/s).  Also tried: a PERSISTENT
+//     cast per kernel instead of per piece to 6.83 ms (experiments/tools/gemm_big.py; sq8k 1265 -> 1394 TFLOP/s).  Also tried: a PERSISTENT
 //     workgroup looping over output tiles with the next tile's first K tile staged under the epilogue - 7.16 ms (spills in the
 //     per-tile part, and static tile assignment loses the dispatcher's load balancing); a 4-barrier K tile (16 MFMAs per
 //     interval) cannot keep the lagging wave group's prefetch distance - not built.]

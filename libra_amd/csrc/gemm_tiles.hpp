@@ -10,7 +10,7 @@
 //           wgrad, W[N_out, K_in] used as B for dgrad) — no transposed copy is ever materialised.
 //           LDS image [64 k][128 lines] = 256-byte rows, chunk c of row r stored at c ^ ((r & 3) << 2).
 //           Fragment = two ds_read_b64_tr_b16 (hardware transpose read: 4 k x 16 lines per 16-lane group;
-//           semantics measured with tools/probe_tr.hip), conflict free: the 32 lanes of a service group
+//           semantics measured with experiments/tools/probe_tr.hip), conflict free: the 32 lanes of a service group
 //           read 4 rows x 64 B that the swizzle spreads over all 64 banks.
 //
 // Both images are filled by 16-byte direct-to-LDS loads (lane-linear destination), so the swizzle is
