@@ -213,3 +213,64 @@ def test_dkv_items_cover_every_attended_pair_once(case):
                     assert cover.get((q, key)) == int(flag[q] != flag[key]), ("missing / wrong variant", q, key)
                 else:
                     assert (q, key) not in cover, ("pair should be masked", q, key)
+
+
+# ---- the persistent kernels' static schedules (attention_bridge.hip, attention_bridge_bwd.hip, runtime.hip persistent_grid, gemm_bf16_256.hip) --------
+def persistent_grid(nitems, period, cus=256, budget=0):
+    if 0 < budget < cus:
+        cus = budget
+    nblk = cus // period * period
+    if nblk < period:
+        nblk = period
+    return min(nblk, nitems)
+
+
+def xcd_remap(bid, nblk):
+    q, r = nblk >> 3, nblk & 7
+    xcd, j = bid & 7, bid >> 3
+    return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + j
+
+
+@pytest.mark.parametrize("B,H,S", [(8, 32, 2048), (2, 160, 512), (1, 1, 16), (3, 5, 700), (2, 32, 4096), (1, 7, 300)])
+@pytest.mark.parametrize("budget", [0, 224, 24])
+def test_persistent_schedules_visit_every_item_exactly_once(B, H, S, budget):
+    """Forward / dQ pass: item i = w + k P -> (sequence-head i / n_qt, query block n_qt - 1 - (i + k) mod n_qt); dK/dV pass: item0 = w + k P ->
+    (item0 / per_bh) per_bh + (item0 mod per_bh + k) mod per_bh with per_bh = 2 n_kb; persistent GEMM: tile w + k P.  For every grid the
+    launchers can produce (CU budget or not) the map must be a bijection onto the items, and in the balanced case (P a multiple of the
+    period, the training shape) every workgroup must meet every weight class equally often."""
+    n_qt = (S + 255) // 256
+    nitems = B * H * n_qt
+    P = persistent_grid(nitems, n_qt, budget=budget)
+    assert P % n_qt == 0 or P == nitems
+    seen = []
+    per_wg = {}
+    for blk in range(P):
+        w = xcd_remap(blk, P)
+        k, item = 0, w
+        while item < nitems:
+            qt = n_qt - 1 - ((item % n_qt + k) % n_qt)
+            seen.append((item // n_qt, qt))
+            per_wg.setdefault(w, []).append(qt)
+            k += 1; item += P
+    assert sorted(seen) == [(bh, qt) for bh in range(B * H) for qt in range(n_qt)]
+    if nitems % P == 0 and (nitems // P) % n_qt == 0:            # e.g. B=8 H=32 S=2048: 8 steps, every workgroup sees each block once
+        for w, qts in per_wg.items():
+            assert sorted(qts) == sorted(list(range(n_qt)) * (len(qts) // n_qt)), (w, qts)
+    # dK/dV pass
+    n_kb = (S + 127) // 128
+    per_bh = 2 * n_kb
+    nit = B * H * per_bh
+    P = persistent_grid(nit, per_bh, budget=budget)
+    assert P % per_bh == 0 or P == nit
+    seen = []
+    for blk in range(P):
+        w = xcd_remap(blk, P)
+        k, item0 = 0, w
+        while item0 < nit:
+            seen.append((item0 // per_bh) * per_bh + (item0 % per_bh + k) % per_bh)
+            k += 1; item0 += P
+    assert sorted(seen) == list(range(nit))
+    # persistent GEMM: tiles in dispatch order
+    ntiles = 560
+    P = persistent_grid(ntiles, 1, budget=budget)
+    assert sorted(t for w in range(P) for t in range(w, ntiles, P)) == list(range(ntiles))

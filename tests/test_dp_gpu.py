@@ -172,10 +172,13 @@ def test_cu_reserved_stream_runs_the_kernels_and_restores_the_budget():
     flag = torch.zeros(B * S, dtype=torch.uint8, device="cuda"); flag[100:300] = 1
     lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
 
+    do = rnd(B * S, H * 128)
+
     def run():
         c = K.gemm_nt(a, b)
         o, lse = K.bridge_attn_fwd(q, ks, kc, vs, vc, flag, lens, B, S, H, 128 ** -0.5, need_lse=True)
-        return c, o, lse
+        grads = K.bridge_attn_bwd(q, ks, kc, vs, vc, o, do, flag, lens, lse, B, S, H, 128 ** -0.5)     # persistent dQ and dK/dV passes
+        return (c, o, lse) + tuple(grads)
     ref = run()
     total = K.cu_count()
     assert K.set_cu_budget(0) == 0                             # default: no budget
