@@ -605,6 +605,10 @@ class _Watchdog:
         if "--exchange" in args:
             i = args.index("--exchange")
             del args[i:i + 2]
+        try:                                   # the HIP / RCCL context's descriptors (KFD, dmabufs, sockets) need not all be CLOEXEC:
+            os.closerange(3, 1 << 16)          # nothing of this image may leak into the re-executed rank
+        except OSError:
+            pass
         os.execv(sys.executable, [sys.executable, os.path.abspath(argv[0])] + args + ["--exchange", "allreduce", "--fallback-from", fallback])
 
 
@@ -721,11 +725,17 @@ def main():
                 ok = 0.0
                 failed[m] = repr(e)[:200]
                 print(f"[bench] rank {rank}: exchange probe '{m}' failed: {failed[m]}", file=sys.stderr, flush=True)
+            # the watchdog stays armed ACROSS the agreement: if this rank's probe raised while the others hang inside the failed
+            # mode's collective, their watchdogs re-execute them - and this rank, blocked in the flag all-reduce they never join,
+            # must re-execute too or the new rendezvous waits for it forever
+            try:
+                w.buckets.mode = "allreduce"
+                flag = torch.tensor([ok], device=device if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if backend == "nccl":
+                    torch.cuda.synchronize()
             finally:
                 dog.cancel()
-            w.buckets.mode = "allreduce"
-            flag = torch.tensor([ok], device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag.item()) < 1.0:
                 probe.pop(m, None)
                 failed.setdefault(m, "failed on another rank")
@@ -795,7 +805,7 @@ def main():
                       "grad_accum": args.accum},
            "roofline": roof}
     if check is not None:
-        out["step_check"] = check         # loss + gradient norm of exactly the timed step (tests/test_fullsize_step_gpu.py bounds them)
+        out["step_check"] = check         # loss + gradient norm of exactly the timed step (tests/test_configs_gpu.py::test_headline_step_full_size_loss_and_recompute_identity bounds them)
 
     if world == 1 and rank == 0 and not args.no_extra and args.workload == "bridge" and not args.with_optimizer \
             and not args.full_finetune:

@@ -377,10 +377,11 @@ class FlatAdamW:
         per-bucket all-gathers of the new parameters overlap the next bucket's update."""
         dev = self.buckets.device
         if torch.device(dev).type == "cuda":
-            # a bounded in-kernel wait of the attention backward that ran out leaves the gradients undefined and sets a device
-            # error word the backward polled asynchronously: never apply such gradients (one host wait, only if a poll is queued)
+            # the device error word is polled asynchronously by the backward; raise here only if a poll has ALREADY landed - the
+            # optimizer never blocks the host (no kernel of the current library writes the word: a blocking wait here only
+            # removed CPU run-ahead and would fail under graph capture)
             from . import kernels as K
-            K.errors.check(dev, wait=True, pending_only=True)
+            K.errors.check(dev, wait=False)
         self.t += 1
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
@@ -422,7 +423,8 @@ class FlatAdamW:
     def load_state_dict(self, sd: dict, *, strict_hyper: bool = False) -> None:
         """Resume: restores step count, master weights and moments, and re-derives the bf16 parameters from the masters (so a
         resumed run continues from the fp32 values, not from bf16-rounded weights with zero moments).  A ZeRO-1 shard must come from the
-        same world size / rank; un-sharded state loads on any rank of any world size.  Hyper-parameters are the CONSTRUCTOR's (as torch.optim lets a resumed run change
+        same world size / rank; un-sharded state loads on any rank of any world size (only the unpadded payload of a bucket is
+        compared and copied: the tail padding to a multiple of world·ALIGN is the one thing that depends on the world size).  Hyper-parameters are the CONSTRUCTOR's (as torch.optim lets a resumed run change
         lr or clipping), but a difference from the saved ones is never silent: a warning, or ValueError with strict_hyper."""
         # the sharding MODE must match; world size and rank only matter when the state is a shard (un-sharded state is the same on
         # every rank: rank 0 saves, every rank loads, and a resume on another world size is legitimate)
@@ -449,11 +451,23 @@ class FlatAdamW:
         if len(sd["buckets"]) != len(self.state):
             raise ValueError("FlatAdamW.load_state_dict: bucket count differs (different parameter set or bucket size)")
         for b, st, pf, src in zip(self.buckets.buckets, self.state, self.pflat, sd["buckets"]):
-            if src["names"] != list(b.names) or src["numel"] != b.flat.numel() or (src["lo"], src["hi"]) != (st["lo"], st["hi"]):
-                raise ValueError("FlatAdamW.load_state_dict: bucket layout / shard range differs from the saved one "
-                                 "(same parameters, bucket_bytes, world size and rank are required)")
+            if src["names"] != list(b.names):
+                raise ValueError("FlatAdamW.load_state_dict: bucket membership differs from the saved one (same parameters and "
+                                 "bucket_bytes are required)")
+            if sharded:
+                if src["numel"] != b.flat.numel() or (src["lo"], src["hi"]) != (st["lo"], st["hi"]):
+                    raise ValueError("FlatAdamW.load_state_dict: shard range differs from the saved one (the bucket length is padded "
+                                     "to a multiple of world_size * ALIGN: same world size and rank are required for a ZeRO-1 shard)")
+                n = st["hi"] - st["lo"]
+            else:
+                # payload = end of the last slot; everything past it is world-size padding (zero gradient, never a parameter)
+                off, k, _ = b.slots[b.names[-1]]
+                n = off + (k + ALIGN - 1) // ALIGN * ALIGN
+                if min(src["numel"], b.flat.numel()) < n or src["master"].numel() < n:
+                    raise ValueError("FlatAdamW.load_state_dict: saved bucket is shorter than this layout's payload")
             for k in ("master", "m", "v"):
-                st[k].copy_(src[k].to(st[k].device))
+                st[k][:n].copy_(src[k][:n].to(st[k].device))
+                st[k][n:].zero_()
             pf[st["lo"]:st["hi"]].copy_(st["master"])                     # bf16(master), in place: the parameters are views
         self.t = int(sd["t"])
         if self.shard:

@@ -22,7 +22,7 @@ from transformers.modeling_outputs import CausalLMOutputWithPast
 
 from .. import decoder_engine as DE
 from ..common.registry import registry
-from ..llama.modeling_llama import LlamaRMSNorm          # noqa: F401  (re-exported: trainer.py:3 imports the name)
+from ..llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding     # noqa: F401  (re-exported: trainer.py:3 imports the name)
 from .configuration_libra import LibraConfig
 from .generation import LibraGenerationMixin
 
@@ -61,6 +61,8 @@ class LibraAttention(_EngineOwned):        # modeling_libra.py:245-265 (+ LlamaA
             setattr(self, n, nn.Linear(H, H, bias=False))
         for n in ("vision_q_proj", "vision_k_proj", "vision_v_proj", "vision_o_proj"):
             setattr(self, n, LibraLinear(H, H, down_ratio=c.vision_down_ratio))
+        # modeling_llama.py:224 - its persistent `inv_freq` buffer is part of every reference checkpoint's key set
+        self.rotary_emb = LlamaRotaryEmbedding(H // c.num_attention_heads, max_position_embeddings=c.max_position_embeddings)
         if c.use_bridge:                   # :258 - without the bridge the layer is plain routed attention (no such parameters)
             for n in ("vision_v_bridge_on_language", "vision_v_bridge_on_vision", "vision_k_bridge_on_language",
                       "vision_k_bridge_on_vision"):
@@ -181,6 +183,14 @@ class LibraForCausalLM(LibraGenerationMixin, PreTrainedModel):
         self.vision_hidden_placeholder = nn.Parameter(torch.empty(c.hidden_size))
         self.vision_hidden_placeholder.data.normal_(mean=0.0, std=c.initializer_range)
         self.max_vision_token_length = c.max_vision_token_length
+        # the reference's four persistent buffers (modeling_libra.py:870-882): part of the checkpoint key set.  The fused
+        # CE / logits kernels write the -inf padding and the EOI -> newline rule themselves; the buffers are carried, saved and loaded.
+        self.register_buffer("naive_placeholder", torch.zeros(c.hidden_size))
+        self.register_buffer("vision_logits_placeholder", torch.full([1, c.vision_vocab_size], -float("inf")))
+        self.register_buffer("language_logits_placeholder", torch.full([1, c.vocab_size], -float("inf")))
+        e2n = torch.full([1, 1, 1, c.vocab_size + c.vision_vocab_size], -float("inf"))
+        e2n[:, :, :, c.newline_token_id] = float("inf")
+        self.register_buffer("eoi_to_newline_logits_placeholder", e2n)
         self._dims = DE.DecDims(hidden=c.hidden_size, inter=c.intermediate_size, layers=c.num_hidden_layers,
                                 heads=c.num_attention_heads, vocab=c.vocab_size, vision_vocab=c.vision_vocab_size,
                                 codebooks=c.vision_codebook_num, max_vision_len=c.max_vision_token_length,

@@ -54,7 +54,11 @@ def assemble_inputs(text_ids: torch.Tensor, attention_mask: torch.Tensor, image_
     upstream spelling, that LibraTrainWrapper.forward consumes: modeling_libra.py:1425-1430).
     plan: plan_assembly(text_ids, ...) computed earlier (default: computed here)."""
     dev = text_ids.device
-    ph, (pb, ps) = plan if plan is not None else plan_assembly(text_ids, img_ph_token_id=img_ph_token_id)
+    if plan is None and image_inputs is not None:
+        plan = plan_assembly(text_ids, img_ph_token_id=img_ph_token_id)
+    pb = ps = None                                                              # text-only batch: nothing to place, no host read
+    if plan is not None:
+        _, (pb, ps) = plan
     gen = text_ids == img_gen_token_id
     ids = text_ids.masked_fill(gen, boi_token_id)                               # :253-254
     ids = ids[None, ...].repeat(num_codebook, 1, 1)                             # :256

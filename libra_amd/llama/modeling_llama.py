@@ -22,3 +22,21 @@ class LlamaRMSNorm(nn.Module):
         with torch.no_grad():
             y = K.rmsnorm_routed(x, self.weight.detach().to(torch.bfloat16), None, None, self.variance_epsilon)
         return y.view(shape)
+
+
+class LlamaRotaryEmbedding(nn.Module):
+    """State-dict holder of the reference's per-layer `self_attn.rotary_emb.inv_freq`, a PERSISTENT buffer upstream
+    (/root/reference/libra/models/llama/modeling_llama.py:136-139; instantiated per attention layer at :224): a real Libra checkpoint
+    carries one per layer and `load_state_dict(strict=True)` expects it.  The cos / sin tables themselves (upstream: non-persistent
+    `cos_cached` / `sin_cached`, :146-148, built in fp32 at construction and cast with the model) are built by
+    `decoder_engine.rope_tables` from the same formula - from constants, not from this buffer, exactly as upstream's cached tables
+    do not follow a later `.to(bfloat16)` of `inv_freq`."""
+
+    def __init__(self, dim, max_position_embeddings=2048, base=10000, device=None):
+        super().__init__()
+        self.dim, self.max_position_embeddings, self.base = dim, max_position_embeddings, base
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float().to(device) / dim))
+        self.register_buffer("inv_freq", inv_freq)
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("LlamaRotaryEmbedding only owns the `inv_freq` buffer in libra_amd: RoPE runs inside libra_rope_bridge")

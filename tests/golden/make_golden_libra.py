@@ -72,10 +72,11 @@ def make_libra():
     t = {"in.input_ids": ids, "in.attention_mask": am, "in.vision_indices": vi, "in.signal": sig, "in.labels": labels,
          "out.logits": out.logits, "out.loss": out.loss.reshape(1), "out.hidden": out.hidden_states[-1],
          "out.embeds": out.hidden_states[0], "out.layer0": out.hidden_states[1]}
+    # the UNFILTERED reference state dict: parameters AND its persistent buffers (naive_placeholder, the three -inf logits
+    # placeholders, modeling_libra.py:870-882; one rotary_emb.inv_freq per attention layer, modeling_llama.py:139) - the key set
+    # a real checkpoint carries and `load_state_dict(strict=True)` of the product model must accept (boundary)
     for k, v in model.state_dict().items():
-        if v.is_floating_point() and "placeholder" not in k.replace("vision_hidden_placeholder", "x") or k == "vision_hidden_placeholder":
-            if v.is_floating_point() and not k.endswith(("naive_placeholder", "logits_placeholder")) and "rotary_emb" not in k:
-                t["w." + k] = v
+        t["w." + k] = v
     for n, p in model.named_parameters():
         if p.grad is not None:
             t["grad." + n] = p.grad.to(torch.float16)      # halves the fixture; compared at 1e-3

@@ -22,6 +22,17 @@ def sub(t, prefix):
     return {k[len(prefix):]: v for k, v in t.items() if k.startswith(prefix)}
 
 
+def is_ref_buffer(name: str) -> bool:
+    """The reference state dict's persistent BUFFERS (modeling_libra.py:870-882, modeling_llama.py:139): carried by the fixtures'
+    `w.` tensors since round 6 (the unfiltered key set), but not parameters - no gradient, no freeze policy, -inf values."""
+    return name.endswith(("naive_placeholder", "logits_placeholder", "rotary_emb.inv_freq"))
+
+
+def sub_params(t, prefix):
+    """`sub` without the reference's persistent buffers: the PARAMETERS of the fixture's model."""
+    return {k: v for k, v in sub(t, prefix).items() if not is_ref_buffer(k)}
+
+
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max|a-b| / max|b|  — the max-norm relative error SURVEY §8(d) gates on."""
     a = a.double()

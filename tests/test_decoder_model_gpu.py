@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from helpers import load_golden, rel_err, sub
+from helpers import load_golden, rel_err, sub, sub_params
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -60,7 +60,7 @@ def test_libra_tiny_backward_vs_reference_fixture():
     sig, lab = t["in.signal"].to(BF).cuda(), t["in.labels"].cuda()
     out = m(input_ids=ids, attention_mask=am, vision_indices=vi, contiguous_signal=sig, labels=lab)
     out.loss.backward()
-    sdf = {k: v.to(BF).float().requires_grad_(True) for k, v in sub(t, "w.").items()}
+    sdf = {k: v.to(BF).float().requires_grad_(True) for k, v in sub_params(t, "w.").items()}
     kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=c["vocab_size"],
               max_vision_token_length=c["max_vision_token_length"], eps=c["rms_norm_eps"], max_pos=c["max_position_embeddings"])
     hid, flag = LO.model_forward(sdf, t["in.input_ids"], t["in.attention_mask"], t["in.vision_indices"],
@@ -313,7 +313,7 @@ def test_libra_model_path_at_seq_4096_vs_oracle():
     out = m(input_ids=ids.cuda(), attention_mask=am.cuda(), vision_indices=vi.cuda(), contiguous_signal=sig.to(BF).cuda(),
             labels=labels.cuda(), output_hidden_states=True)
     out.loss.backward()
-    sdf = {k: v.to(BF).float().requires_grad_(True) for k, v in sub(t, "w.").items()}
+    sdf = {k: v.to(BF).float().requires_grad_(True) for k, v in sub_params(t, "w.").items()}
     kw = dict(layers=c["num_hidden_layers"], heads=c["num_attention_heads"], vocab=V, max_vision_token_length=L, eps=c["rms_norm_eps"],
               max_pos=4096)
     hid, flag = LO.model_forward(sdf, ids, am, vi, sig.to(BF).float(), **kw)

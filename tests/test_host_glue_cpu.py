@@ -5,7 +5,7 @@ import os
 import pytest
 import torch
 
-from helpers import load_golden
+from helpers import load_golden, sub_params
 
 
 def test_assemble_inputs_matches_reference_tokenizer():
@@ -263,7 +263,7 @@ def test_packed_operands_refresh_policy():
     from libra_amd import decoder_engine as DE
     t, meta = load_golden("libra_tiny.safetensors")
     c = meta["cfg"]
-    sd = {k[2:]: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in t.items() if k.startswith("w.")}
+    sd = {k: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in sub_params(t, "w.").items()}
     d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
                    heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
                    codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
@@ -295,7 +295,7 @@ def test_packed_operands_adopt_makes_parameters_views_of_the_fused_operands():
     from libra_amd import decoder_engine as DE
     t, meta = load_golden("libra_tiny.safetensors")
     c = meta["cfg"]
-    sd = {k[2:]: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in t.items() if k.startswith("w.")}
+    sd = {k: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in sub_params(t, "w.").items()}
     d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
                    heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
                    codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
@@ -327,7 +327,7 @@ def test_adopt_leaves_parameters_of_a_flat_buffer_optimizer_alone():
     from helpers import torch_adamw_update, torch_sumsq
     t, meta = load_golden("libra_tiny.safetensors")
     c = meta["cfg"]
-    sd = {k[2:]: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in t.items() if k.startswith("w.")}
+    sd = {k: torch.nn.Parameter(v.to(torch.bfloat16)) for k, v in sub_params(t, "w.").items()}
     for k, p in sd.items():
         p.requires_grad_("vision" in k)                                  # the pretrain freeze policy
     d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
@@ -376,6 +376,37 @@ def test_flat_adamw_unsharded_state_loads_on_any_rank_sharded_state_does_not():
     assert opt2.t == 1 and all(torch.equal(p.detach(), q.detach()) for (_, p), (_, q) in zip(ps, ps2))
     with pytest.raises(ValueError, match="sharded"):
         opt2.load_state_dict(dict(sd, sharded=True))
+
+
+def test_flat_adamw_unsharded_state_resumes_on_a_different_real_world_size(monkeypatch):
+    """the bucket LENGTH is padded to a multiple of world * ALIGN, so state saved at world 8 has longer buckets than the
+    same layout at world 1 / 3.  Un-sharded state must load across that: only the payload is compared and copied."""
+    from libra_amd import dp
+    from helpers import torch_adamw_update, torch_sumsq
+    import torch.distributed as dist
+
+    def make(world, src=None):
+        monkeypatch.setattr(dist, "is_initialized", lambda: world > 1)
+        monkeypatch.setattr(dist, "get_world_size", lambda group=None: world)
+        monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
+        g = torch.Generator().manual_seed(3)
+        ps = [("a.weight", torch.nn.Parameter((torch.randn(8, 16, generator=g) if src is None else torch.zeros(8, 16)).to(torch.bfloat16))),
+              ("b.weight", torch.nn.Parameter((torch.randn(24, generator=g) if src is None else torch.zeros(24)).to(torch.bfloat16)))]
+        st = dp.GradBuckets(ps, bucket_bytes=1 << 12)
+        return ps, st, dp.FlatAdamW(st, ps, lr=1e-2, update_fn=torch_adamw_update, sumsq_fn=torch_sumsq)
+    ps8, st8, opt8 = make(8)
+    for n, _ in ps8:
+        st8.view(n).fill_(0.25)
+    opt8.step()                                                         # un-sharded (allreduce mode): no collective in step()
+    sd = opt8.state_dict()
+    for world in (1, 3):
+        psw, stw, optw = make(world, src=sd)
+        assert stw.buckets[0].flat.numel() != st8.buckets[0].flat.numel(), "the case must really change the padded length"
+        optw.load_state_dict(sd)
+        assert optw.t == 1 and all(torch.equal(p.detach(), q.detach()) for (_, p), (_, q) in zip(ps8, psw))
+        for a, b in zip(opt8.state, optw.state):
+            n = min(a["m"].numel(), b["m"].numel())
+            assert torch.equal(a["m"][:n], b["m"][:n]) and torch.equal(a["v"][:n], b["v"][:n])
 
 
 def test_row_arena_lease_follows_the_lifetime_of_the_saved_forward():

@@ -2,7 +2,7 @@
 LibraForCausalLM / LibraTrainWrapper.get_labels / LibraTokenizer.forward.  CPU only."""
 import torch
 
-from helpers import load_golden, rel_err, sub
+from helpers import load_golden, rel_err, sub, sub_params
 from oracle import libra_oracle as LO
 
 
@@ -47,7 +47,7 @@ def test_libra_embeddings_and_first_layer():
 
 def test_libra_backward_matches_reference_autograd():
     t, meta = load_golden("libra_tiny.safetensors")
-    sd = {k: v.clone().requires_grad_(True) for k, v in sub(t, "w.").items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sub_params(t, "w.").items()}
     hid, flag, logits = _run(t, meta, sd)
     LO.causal_lm_loss(logits, t["in.labels"]).backward()
     n = 0
