@@ -85,6 +85,26 @@ int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* co
                                int64_t alpha_cols, int flags, const int32_t* a_rows, int64_t a_phys_rows,
                                const int32_t* c_rows, int tile, void* stream);
 
+/* Multi-problem launch (round 6): up to LIBRA_GEMM_MULTI_MAX INDEPENDENT GEMMs - each with its own shapes, strides, operand
+ * layouts (A_T / B_T), row maps and fused epilogue, i.e. each one a complete libra_gemm_bf16_nt_routed call - as ONE persistent
+ * launch over a common list of 256x256 tiles, longest K first, handed out dynamically.  What it replaces on the reference side is
+ * still the per-module F.linear calls of cal_language_vision (modeling_libra.py:111-147): the language module's product on the
+ * text rows and the vision module's products on the vision rows are independent and share a launch here (e.g. q|k|v of the text
+ * rows + the three LibraLinear.weight_B expansions of the vision rows, modeling_libra.py:192-199), and so do the weight
+ * gradients of a layer, which nothing inside the layer waits for.  Per output element the arithmetic is that of
+ * libra_gemm_bf16_nt_tile(..., LIBRA_GEMM_TILE_256), bit for bit.  No problem may read what another problem of the same call writes.
+ * queue_ws: 64 bytes of device memory, 16-byte aligned, ALL ZERO at the first use and owned by one stream - the kernel leaves it
+ * zero again (its tile queues clear themselves), so it is allocated and cleared once, not per call.                              */
+#define LIBRA_GEMM_MULTI_MAX 12
+typedef struct libra_gemm_problem {
+    const void* A; int64_t lda; const void* B; int64_t ldb; void* C; int64_t ldc;
+    int64_t M, N, K;
+    const void* bias; const void* resid; int64_t ldr; const void* aux; int64_t ldaux; void* preact; int64_t ldpre;
+    float alpha; int32_t flags; int64_t alpha_cols;
+    const int32_t* a_rows; int64_t a_phys_rows; const int32_t* c_rows;
+} libra_gemm_problem;
+int libra_gemm_bf16_multi(const libra_gemm_problem* problems, int64_t n_problems, void* queue_ws, void* stream);
+
 /* The first half of LlamaMLP for a generation step (M <= 16 rows) in one launch: Y[M, I] = silu(A W_gate^T) * (A W_up^T),
  * modeling_llama.py:199-201 (act_fn(gate_proj(x)) * up_proj(x)), W_gate_up = [2I, K] = gate rows then up rows (the packed operand
  * the training GEMM uses).  Arithmetic = libra_gemm_bf16_nt followed by libra_swiglu, bit for bit (both products rounded to bf16,

@@ -15,6 +15,18 @@ OK, ERR_SHAPE, ERR_ALIGN, ERR_LAUNCH = 0, -1, -2, -3
 
 _P, _I64, _F, _I = C.c_void_p, C.c_int64, C.c_float, C.c_int
 
+GEMM_MULTI_MAX = 12          # include/libra_hip.h LIBRA_GEMM_MULTI_MAX
+
+
+class GemmProblem(C.Structure):
+    """include/libra_hip.h `libra_gemm_problem`: one GEMM of a multi-problem launch (libra_gemm_bf16_multi)."""
+    _fields_ = [("A", _P), ("lda", _I64), ("B", _P), ("ldb", _I64), ("C", _P), ("ldc", _I64),
+                ("M", _I64), ("N", _I64), ("K", _I64),
+                ("bias", _P), ("resid", _P), ("ldr", _I64), ("aux", _P), ("ldaux", _I64), ("preact", _P), ("ldpre", _I64),
+                ("alpha", _F), ("flags", C.c_int32), ("alpha_cols", _I64),
+                ("a_rows", _P), ("a_phys_rows", _I64), ("c_rows", _P)]
+
+
 # name -> argtypes, exactly the prototypes of include/libra_hip.h
 SIGNATURES = {
     "libra_hip_abi_version": [],
@@ -25,6 +37,7 @@ SIGNATURES = {
     "libra_gemm_bf16_nt_tile": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _I64,
                                 _F, _I64, _I, _P, _I64, _P, _I, _P],
     "libra_gemm_bf16_nt_grouped": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _F, _I64, _I, _P, _I64, _P, _I, _P],
+    "libra_gemm_bf16_multi": [C.POINTER(GemmProblem), _I64, _P, _P],
     "libra_gemm_swiglu_skinny": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "libra_gemm_splitk_plan": [_I64, _I64, _I64],
     "libra_gemm_splitk_workspace_bytes": [_I64, _I64, _I64],
@@ -90,7 +103,7 @@ SIGNATURES = {
     "libra_debug_cu_map": [_P, C.c_int32, C.c_int32, _P],
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class LibraHipError(RuntimeError):

@@ -132,7 +132,7 @@ static inline int launched() { return hipGetLastError() == hipSuccess ? LIBRA_OK
 
 using namespace libra;
 
-extern "C" int libra_hip_abi_version(void) { return 12; }
+extern "C" int libra_hip_abi_version(void) { return 13; }
 
 extern "C" int libra_patch_im2col(const void* pixel, void* cols, int64_t B, int64_t C, int64_t H, int64_t W,
                                   int64_t P, int64_t Kpad, void* stream) {

@@ -317,6 +317,113 @@ def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tenso
     return outs
 
 
+class GemmSpec:
+    """One problem of a multi-problem launch (gemm_multi): the arguments of a gemm_nt call, validated, as the C ABI's
+    `libra_gemm_problem` - plus the tensors it points into (kept alive until the launch is queued) and its work for the profile."""
+    __slots__ = ("c", "out", "keep", "work")
+
+
+def gemm_spec(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+              resid: Optional[torch.Tensor] = None, quick_gelu: bool = False, qgelu_grad_of: Optional[torch.Tensor] = None,
+              preact_out: Optional[torch.Tensor] = None, alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None,
+              a_t: bool = False, b_t: bool = False, a_rows: Optional[torch.Tensor] = None,
+              c_rows: Optional[torch.Tensor] = None) -> GemmSpec:
+    """The operands of `gemm_nt(a, b, ...)` (same conventions, same checks) as one problem of a `gemm_multi` launch."""
+    _chk2d(a, "a"); _chk2d(b, "b")
+    (Ka, M) = a.shape if a_t else a.shape[::-1]
+    a_phys = a.shape[0]
+    if a_rows is not None:
+        if a_t or a_rows.dtype != torch.int32:
+            raise ValueError("gemm_spec: a_rows needs a K-contiguous A and an int32 index tensor")
+        M = a_rows.numel()
+    (Kb, N) = b.shape if b_t else b.shape[::-1]
+    K = k if k is not None else Ka
+    if K > Ka or K > Kb or (k is None and Ka != Kb):
+        raise ValueError(f"gemm_spec: inner dims differ: a {tuple(a.shape)} b {tuple(b.shape)} k={k} a_t={a_t} b_t={b_t}")
+    if c_rows is not None:
+        if out is None or c_rows.dtype != torch.int32 or c_rows.numel() != M or out.shape[1] != N:
+            raise ValueError("gemm_spec: c_rows (int32 [M]) scatters into a caller-provided out [rows, N]")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    if c_rows is None and out.shape != (M, N):
+        raise ValueError(f"gemm_spec: out is {tuple(out.shape)}, expected {(M, N)}")
+    flags = (GEMM_A_T if a_t else 0) | (GEMM_B_T if b_t else 0)
+    if bias is not None:
+        if bias.numel() != N or bias.dtype != BF16:
+            raise ValueError("gemm_spec: bias must be bf16 [N]")
+        flags |= GEMM_BIAS
+    ldr = ldaux = ldpre = 0
+    for t, nm in ((resid, "resid"), (qgelu_grad_of, "qgelu_grad_of"), (preact_out, "preact_out")):
+        if t is not None:
+            _chk2d(t, nm)
+            if t.shape != out.shape:
+                raise ValueError(f"gemm_spec: {nm} shape")
+    if resid is not None:
+        flags |= GEMM_RESIDUAL; ldr = resid.stride(0)
+    if qgelu_grad_of is not None:
+        flags |= GEMM_MUL_QGELU_GRAD; ldaux = qgelu_grad_of.stride(0)
+    if preact_out is not None:
+        flags |= GEMM_STORE_PREACT; ldpre = preact_out.stride(0)
+    if quick_gelu:
+        flags |= GEMM_QUICK_GELU
+    sp = GemmSpec()
+    sp.c = _lib.GemmProblem(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                            _ptr(bias), _ptr(resid), ldr, _ptr(qgelu_grad_of), ldaux, _ptr(preact_out), ldpre, float(alpha), flags,
+                            int(alpha_cols), _ptr(a_rows), a_phys, _ptr(c_rows))
+    sp.out = out
+    sp.keep = (a, b, out, bias, resid, qgelu_grad_of, preact_out, a_rows, c_rows)
+    sp.work = (2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), f"{M}x{N}x{K}{' aT' if a_t else ''}{' bT' if b_t else ''}")
+    return sp
+
+
+_MULTI_WS = {}
+
+
+def _multi_ws(device) -> torch.Tensor:
+    """The 64-byte tile-queue workspace of libra_gemm_bf16_multi: one per (device, stream), zeroed ONCE (the kernel leaves it zero)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    ws = _MULTI_WS.get(key)
+    if ws is None:
+        ws = _MULTI_WS[key] = torch.zeros(16, dtype=torch.int32, device=dev)
+    return ws
+
+
+def gemm_multi(specs: Sequence[GemmSpec]) -> list:
+    """The problems `specs` (gemm_spec(...), each what one gemm_nt call would compute) as ONE persistent launch over a common tile
+    list, longest reduction first (libra_gemm_bf16_multi).  The problems must be independent: none reads what another one writes
+    (two may write disjoint rows of the same tensor through their row maps).  More than 12 problems go out as several launches.
+    -> [out of each problem]."""
+    specs = list(specs)
+    if not specs:
+        return []
+    dev = specs[0].out.device
+    n_max = _lib.GEMM_MULTI_MAX
+    for i0 in range(0, len(specs), n_max):
+        chunk = specs[i0:i0 + n_max]
+        arr = (_lib.GemmProblem * len(chunk))(*[sp.c for sp in chunk])
+        prof = LaunchProfile.active
+        if prof is not None:
+            tag = "multi{" + " + ".join(_tag_counts([sp.work[2] for sp in chunk])) + "}"
+            ev = prof.bracket("gemm", (sum(sp.work[0] for sp in chunk), sum(sp.work[1] for sp in chunk), tag))
+            ev[0].record()
+        rc = _lib.lib().libra_gemm_bf16_multi(arr, len(chunk), _multi_ws(dev).data_ptr(), _stream())
+        if prof is not None:
+            ev[1].record()
+        _lib.check(rc, f"gemm_multi [{', '.join(sp.work[2] for sp in chunk)}]")
+    return [sp.out for sp in specs]
+
+
+def _tag_counts(tags):
+    out, seen = [], {}
+    for t in tags:
+        seen[t] = seen.get(t, 0) + 1
+    for t in dict.fromkeys(tags):
+        out.append(t if seen[t] == 1 else f"{seen[t]}x[{t}]")
+    return out
+
+
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, *, save_stats: bool = True,
                   out: Optional[torch.Tensor] = None):
     _chk2d(x, "x")

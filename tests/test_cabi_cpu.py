@@ -53,7 +53,9 @@ def test_host_prototypes_match_header(lib_path):
     for name, args in d.items():
         assert len(args) == len(_lib.SIGNATURES[name]), (name, len(args), len(_lib.SIGNATURES[name]))
         for a, ct in zip(args, _lib.SIGNATURES[name]):
-            if "*" in a:
+            if "libra_gemm_problem*" in a:                      # the one struct of the ABI: a typed pointer, layout checked below
+                assert ct is ctypes.POINTER(_lib.GemmProblem), (name, a)
+            elif "*" in a:
                 assert ct is ctypes.c_void_p, (name, a)
             elif a.startswith("size_t"):
                 assert ct is ctypes.c_size_t, (name, a)
@@ -64,6 +66,28 @@ def test_host_prototypes_match_header(lib_path):
             elif a.startswith("int "):
                 assert ct is ctypes.c_int, (name, a)
     _lib.load()
+
+
+def test_gemm_problem_struct_matches_header():
+    """`libra_gemm_problem` (the per-problem record of libra_gemm_bf16_multi): the ctypes Structure has the header's fields, in the
+    header's order, with the header's types - and therefore its layout (both sides use the platform's natural alignment)."""
+    from libra_amd import _lib
+    src = open(os.path.join(ROOT, "include", "libra_hip.h")).read()
+    body = re.search(r"typedef struct libra_gemm_problem \{(.*?)\} libra_gemm_problem;", src, re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const void\*|void\*|const int32_t\*|int64_t|int32_t|float) (.*)", decl)
+        assert m, decl
+        for nm in m.group(2).split(","):
+            fields.append((nm.strip(), m.group(1)))
+    ctype = {"const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "int64_t": ctypes.c_int64,
+             "int32_t": ctypes.c_int32, "float": ctypes.c_float}
+    assert [(n, ctype[t]) for n, t in fields] == list(_lib.GemmProblem._fields_)
+    assert ctypes.sizeof(_lib.GemmProblem) == 168          # = static_assert in gemm_bf16_multi.hip
+    assert int(re.search(r"#define LIBRA_GEMM_MULTI_MAX (\d+)", src).group(1)) == _lib.GEMM_MULTI_MAX
 
 
 def test_shipped_library_reads_no_environment_variable(lib_path):
