@@ -640,7 +640,14 @@ def main():
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)         # child-process entry of cpu_baseline()
     ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ViT leg, optimizer leg) at N=1")
+    ap.add_argument("--no-multi", action="store_true",
+                    help="A/B switch: the round-5 launch schedule (one launch per GEMM) instead of the multi-problem launches")
     args = ap.parse_args()
+    if args.no_multi:
+        from libra_amd import decoder_engine as _DE, vit_engine as _VE
+        _DE.MULTI = False
+        if hasattr(_VE, "MULTI"):
+            _VE.MULTI = False
     if args.workload == "libra":
         args.workload = "bridge"
     if args.cpu_leg:
@@ -802,7 +809,8 @@ def main():
                       "algorithmic_gflop_per_image": round(gpi, 1), "value_per_gpu": round(ips / world, 3),
                       "optimizer_in_step": bool(args.with_optimizer), "recompute": bool(args.recompute),
                       "full_finetune": bool(args.full_finetune),
-                      "grad_accum": args.accum},
+                      "grad_accum": args.accum,
+                      "gemm_schedule": "one launch per GEMM (--no-multi)" if args.no_multi else "multi-problem launches (libra_gemm_bf16_multi)"},
            "roofline": roof}
     if check is not None:
         out["step_check"] = check         # loss + gradient norm of exactly the timed step (tests/test_configs_gpu.py::test_headline_step_full_size_loss_and_recompute_identity bounds them)

@@ -364,6 +364,17 @@ class KVCache:
         return self.length
 
 
+# Round 6: a text GEMM and the vision GEMMs / weight gradients that do not depend on it go out as ONE multi-problem launch
+# (K.gemm_multi -> libra_gemm_bf16_multi): the low-rank vision branch's 0.3 - 1.9-wave launches fill the text GEMM's last wave
+# instead of each paying their own.  False = the round-5 schedule (one launch per GEMM / grouped launch), kept for same-process A/Bs
+# (bench.py --no-multi) and as the schedule of addition_mode and of generation steps.
+MULTI = True
+
+
+def _multi_ok(d: "DecDims", n_l: int, n_v: int) -> bool:
+    return MULTI and not d.addition and n_l > 16 and n_v > 0
+
+
 def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None, *,
                   cache: Optional[KVCache] = None, positions: Optional[torch.Tensor] = None,
                   slot: Optional[torch.Tensor] = None, need_out: bool = True, kv_start: Optional[torch.Tensor] = None):
@@ -386,11 +397,21 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     qkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)       # [q | k | v | bridge low-rank activations t_k t_v 0..]
     qkv, tb = qkvt[:, :3 * H], qkvt[:, 3 * H:]
     t = None
-    if d.addition:
+    multi = _multi_ok(d, n_l, n_v) and slot is None              # (a cached decode step keeps its own, graph-captured schedule)
+    G = K.gemm_spec
+    if multi:
+        # vision A stage first (the expansions need it); then text q|k|v (+ bridge A) and the three rank-r expansions together
+        t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save, "t_ext"))      # [n_v, 3r + 64]
+        t = t_ext[:, :3 * r]
+        tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])
+        K.gemm_multi([G(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)]
+                     + [G(t[:, j * r:(j + 1) * r], sd[a + f"vision_{nm}_proj.weight_B"], out=qkv[:, j * H:(j + 1) * H], c_rows=vis_idx)
+                        for j, nm in enumerate(("q", "k", "v"))])
+    elif d.addition:
         K.gemm_nt(h, pk["wqkv_ab"], out=qkvt)                        # language projections (+ language bridge A) on every row
     elif n_l:
         K.gemm_nt(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)
-    if n_v:
+    if n_v and not multi:
         t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save, "t_ext"))      # [n_v, 3r + 64]
         t = t_ext[:, :3 * r]
         tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])          # 64 columns of the vision rows: plumbing copy (the bridges stay routed)
@@ -427,11 +448,15 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
                                       (H // d.heads) ** -0.5, kv_start=kv_start), None
     x_mid = torch.empty_like(x)
     to = None
-    if d.addition:
+    if multi:
+        to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save, "to"))
+        K.gemm_multi([G(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x),
+                      G(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x)])
+    elif d.addition:
         K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, resid=x)    # every row
     elif n_l:
         K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x)
-    if n_v:
+    if n_v and not multi:
         to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save, "to"))
         K.gemm_nt(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x_mid if d.addition else x)
     # ---- MLP block
@@ -439,15 +464,27 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
                                  sd[pre + "vision_post_attention_layernorm.weight"], flag, d.eps, save_rstd=True)
     x_out = torch.empty_like(x) if need_out else None      # (a recompute pass stops before the last down projections)
     gu = act = tg = guv = actv = td = None
-    if n_l and n_l <= 16 and not save:                       # generation step: gate | up GEMM + SwiGLU as one weight-streaming launch
+    if multi:
+        tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save, "tg"))               # [n_v, 2 rg]
+        guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
+        gu = K.gemm_multi([G(h2, pk["wgu"], a_rows=lang_idx),                                               # [n_l, 2I]
+                           G(tg[:, :rg], sd[m + "vision_gate_proj.weight_B"], out=guv[:, :I]),
+                           G(tg[:, rg:], sd[m + "vision_up_proj.weight_B"], out=guv[:, I:])])[0]
+        act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save, "act"))
+        actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save, "actv"))
+        td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save, "td"))
+        if need_out:
+            K.gemm_multi([G(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid),
+                          G(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)])
+    elif n_l and n_l <= 16 and not save:                     # generation step: gate | up GEMM + SwiGLU as one weight-streaming launch
         act = K.gemm_swiglu_skinny(h2, pk["wgu"], a_rows=lang_idx)
     elif n_l:
         gu = K.gemm_nt(h2, pk["wgu"], a_rows=lang_idx)                                 # [n_l, 2I]
         act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save, "act"))
-    if n_l:
+    if n_l and not multi:
         if need_out:
             K.gemm_nt(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid)
-    if n_v:
+    if n_v and not multi:
         tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save, "tg"))               # [n_v, 2 rg]
         guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
         K.gemm_nt_grouped([tg[:, :rg], tg[:, rg:]], [sd[m + "vision_gate_proj.weight_B"], sd[m + "vision_up_proj.weight_B"]],
@@ -1059,7 +1096,174 @@ def _zero_fill(g, names, sd):
             g[n] = buf.zero_() if buf is not None else torch.zeros_like(sd[n], dtype=BF16)
 
 
+def _layer_backward_multi(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w, positions=None):
+    """layer_backward with the round-6 launch schedule (both modalities present, no addition_mode): per stage ONE multi-problem
+    launch = the text dgrad + the vision dgrads that do not wait for one another + the weight gradients whose operands exist by
+    then (nothing in the layer consumes a weight gradient, so they ride wherever they fill a launch's tail).  Only the first
+    low-rank stage of each vision pair, which everything else of the stage waits for, stays a launch of its own:
+        dtd | B1 {dact_l, dact_v, dW down_B, dW down_A} | swiglu' x2 | B2 {dh2_l, dtg x2, dW gate_B, dW up_B} | B3 {dh2_v, dW gate|up_A}
+        | norm' | dto | B4 {do_l, do_v, dW o_B, dW o_A} | attention' | rope' | B5 {dh_l, dt x3, dW q|k|v_B} | B6 {dh_v, dW q|k|v_A + bridge A} | norm'
+    Same kernels' arithmetic per problem, same results bit for bit as the one-launch-per-GEMM schedule (tests/test_decoder_model_gpu.py)."""
+    H, I, r, rg = d.hidden, d.inter, d.r, d.rg
+    N = B * S
+    dev = dx_out.device
+    n_l, n_v = lang_idx.numel(), vis_idx.numel()
+    pre = f"model.layers.{i}."
+    a, m = pre + "self_attn.", pre + "mlp."
+    any_l = lambda names: any(w(n) for n in names)
+    G = K.gemm_spec
+
+    def WG(dy_c, x_c, name=None):            # weight-gradient problem: dW[out, in] = dy^T x, straight into the bucket slot when capturing
+        return G(_full(dy_c), _full(x_c), a_t=True, b_t=True, out=dp.grad_out(name) if name is not None else None)
+
+    # ================= MLP =================
+    dh2 = torch.empty((N, H), dtype=BF16, device=dev)
+    h2, gu = sv["h2"], sv["gu"]
+    tg, guv, actv, td = sv["tg"], sv["guv"], sv["actv"], sv["td"]
+    dxo_v = _compact(dx_out, vis_idx, "dxo_v")
+    dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=_arows("b.dtd", n_v, r, dev))
+    probs, post = [G(dx_out, sd[m + "down_proj.weight"], b_t=True, a_rows=lang_idx),                            # dact  [n_l, I]
+                   G(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True)], []                                    # dactv [n_v, I]
+    for nm, dy_c, x_c in ((m + "vision_down_proj.weight_B", dxo_v, td), (m + "vision_down_proj.weight_A", dtd, actv)):
+        if w(nm):
+            probs.append(WG(dy_c, x_c, nm)); post.append(nm)
+    if w(m + "down_proj.weight"):
+        probs.append(WG(_compact(dx_out, lang_idx, "dxo_l"), sv["act"], m + "down_proj.weight")); post.append(m + "down_proj.weight")
+    outs = K.gemm_multi(probs)
+    dact, dactv = outs[0], outs[1]
+    for nm, o in zip(post, outs[2:]):
+        g[nm] = o
+    dgu = _arows("b.dgu", n_l, 2 * I, dev)
+    K.swiglu_bwd(dact, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
+    dguv = _arows("b.dguv", n_v, 2 * I, dev)
+    K.swiglu_bwd(dactv, guv[:, :I], guv[:, I:], dguv[:, :I], dguv[:, I:])
+    dtg = _arows("b.dtg", n_v, 2 * rg, dev)
+    probs, post = [G(dgu, pk["wgu"], b_t=True, out=dh2, c_rows=lang_idx),
+                   G(dguv[:, :I], sd[m + "vision_gate_proj.weight_B"], b_t=True, out=dtg[:, :rg]),
+                   G(dguv[:, I:], sd[m + "vision_up_proj.weight_B"], b_t=True, out=dtg[:, rg:])], []
+    for nm, dy_c, x_c in ((m + "vision_gate_proj.weight_B", dguv[:, :I], tg[:, :rg]), (m + "vision_up_proj.weight_B", dguv[:, I:], tg[:, rg:])):
+        if w(nm):
+            probs.append(WG(dy_c, x_c, nm)); post.append(nm)
+    want_gu = any_l([m + "gate_proj.weight", m + "up_proj.weight"])
+    if want_gu:
+        probs.append(WG(dgu, _compact(h2, lang_idx, "h2_l")))
+    outs = K.gemm_multi(probs)
+    for nm, o in zip(post, outs[3:]):
+        g[nm] = o
+    if want_gu:
+        g[m + "gate_proj.weight"], g[m + "up_proj.weight"] = outs[-1][:I], outs[-1][I:]
+    probs = [G(dtg, pk["agu"], b_t=True, out=dh2, c_rows=vis_idx)]
+    want_agu = any_l([m + "vision_gate_proj.weight_A", m + "vision_up_proj.weight_A"])
+    if want_agu:
+        probs.append(WG(dtg, _compact(h2, vis_idx, "h2_v")))
+    outs = K.gemm_multi(probs)
+    if want_agu:
+        g[m + "vision_gate_proj.weight_A"], g[m + "vision_up_proj.weight_A"] = outs[1][:rg], outs[1][rg:]
+    ln_l, ln_v = pre + "post_attention_layernorm.weight", pre + "vision_post_attention_layernorm.weight"
+    dx_mid = K.rmsnorm_routed_bwd(dh2, sv["x_mid"], sd[ln_l], sd[ln_v], flag, sv["rstd2"], dres=dx_out)
+    if w(ln_l) or w(ln_v):
+        g[ln_l], g[ln_v] = _norm_wgrad(dh2, sv["x_mid"], sv["rstd2"], flag, lang_idx, vis_idx, w(ln_l), w(ln_v), H)
+
+    # ================= attention =================
+    o = sv["o"]
+    do = torch.empty((N, H), dtype=BF16, device=dev)
+    dxm_v = _compact(dx_mid, vis_idx, "dxm_v")
+    dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=_arows("b.dto", n_v, r, dev))
+    probs, post = [G(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do),
+                   G(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx)], []
+    if w(a + "vision_o_proj.weight_B"):
+        probs.append(WG(dxm_v, sv["to"], a + "vision_o_proj.weight_B")); post.append(a + "vision_o_proj.weight_B")
+    if w(a + "vision_o_proj.weight_A"):
+        probs.append(WG(dto, _compact(o, vis_idx, "o_v"), a + "vision_o_proj.weight_A")); post.append(a + "vision_o_proj.weight_A")
+    if w(a + "o_proj.weight"):
+        probs.append(WG(_compact(dx_mid, lang_idx, "dxm_l"), _compact(o, lang_idx, "o_l"), a + "o_proj.weight")); post.append(a + "o_proj.weight")
+    outs = K.gemm_multi(probs)
+    for nm, o_ in zip(post, outs[2:]):
+        g[nm] = o_
+    qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
+    dq, dks, dkc, dvs, dvc = K.bridge_attn_bwd(qkv[:, :H], qkv[:, H:2 * H], kc, qkv[:, 2 * H:], vc, o, do, flag, lens,
+                                               sv["lse"], B, S, d.heads, (H // d.heads) ** -0.5, out_lo=sv["o_lo"])
+    dqkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)     # [dq | dk | dv | dt_k dt_v 0..], mirrors the forward's qkvt
+    dqkv, dtb = dqkvt[:, :3 * H], dqkvt[:, 3 * H:]
+    dtb.zero_()
+    dkb = torch.empty((N, H), dtype=BF16, device=dev)
+    K.rope_bridge_bwd(dq, dks, dkc, dvs, dvc, cos, sin, S, d.heads, dqkv, dkb,
+                      bridge_b=(pk["bkT_l"], pk["bkT_v"], pk["bvT_l"], pk["bvT_v"]), flag=flag, dtb=dtb, positions=positions)
+    dvb = dvc
+    h = sv["h"]
+    bnames = {kv: [a + f"vision_{kv}_bridge_on_{which}.weight_B" for which in ("language", "vision")] for kv in "kv"}
+    if d.rank == 8:
+        for kv, xg, col0 in (("k", dkb, 0), ("v", dvb, 8)):
+            nl_, nv_ = bnames[kv]
+            if w(nl_) or w(nv_):
+                gl_, gv_ = K.rank_outer_wgrad(xg, tb[:, col0:col0 + 8], flag, transpose_out=True, want_l=w(nl_), want_v=w(nv_))
+                if w(nl_):
+                    g[nl_] = gl_
+                if w(nv_):
+                    g[nv_] = gv_
+    else:
+        for wi, (idx, which) in enumerate(((lang_idx, "language"), (vis_idx, "vision"))):
+            nk, nv = bnames["k"][wi], bnames["v"][wi]
+            if w(nk) or w(nv):
+                tbc = _compact(tb, idx, "tb_" + which)
+                if w(nk):
+                    g[nk] = _wg(_compact(dkb, idx, "dkb_" + which), tbc[:, 0:8], post=lambda o_: o_[:, :d.rank].contiguous())
+                if w(nv):
+                    g[nv] = _wg(_compact(dvb, idx, "dvb_" + which), tbc[:, 8:16], post=lambda o_: o_[:, :d.rank].contiguous())
+    dh = torch.empty((N, H), dtype=BF16, device=dev)
+    dt_ext = _arows("b.dt_ext", n_v, 3 * r + 64, dev)                # [dt_q | dt_k | dt_v | dt_bridge], mirrors the forward's t_ext
+    K.copy_rows(dtb, vis_idx, n_v, dt_ext, 3 * r)                    # the vision rows' 64 bridge columns
+    t = sv["t"]
+    dqkv_v = _compact(dqkv, vis_idx, "dqkv_v")                        # [n_v, 3H]
+    dt = dt_ext[:, :3 * r]
+    bq = [a + f"vision_{nm}_proj.weight_B" for nm in ("q", "k", "v")]
+    probs, post = [G(dqkvt, pk["wqkv_ab"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=dh)] + \
+                  [G(dqkv_v[:, j * H:(j + 1) * H], sd[bq[j]], b_t=True, out=dt[:, j * r:(j + 1) * r]) for j in range(3)], []
+    for j, nm in enumerate(bq):
+        if w(nm):
+            probs.append(WG(dqkv_v[:, j * H:(j + 1) * H], t[:, j * r:(j + 1) * r], nm)); post.append(nm)
+    nk, nv = a + "vision_k_bridge_on_language.weight_A", a + "vision_v_bridge_on_language.weight_A"
+    want_txt = any_l([a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"])
+    if want_txt:
+        probs.append(WG(_compact(dqkvt, lang_idx, "dqkvt_l"), _compact(h, lang_idx, "h_l")))                   # [3H + 64, H]
+    outs = K.gemm_multi(probs)
+    for nm, o_ in zip(post, outs[4:]):
+        g[nm] = o_
+    if want_txt:
+        dw = outs[-1]
+        for j, nm in enumerate(("q", "k", "v")):
+            g[a + f"{nm}_proj.weight"] = dw[j * H:(j + 1) * H]
+        if w(nk) or w(nv):
+            g[nk], g[nv] = dw[3 * H:3 * H + d.rank].contiguous(), dw[3 * H + 8:3 * H + 8 + d.rank].contiguous()
+    elif (w(nk) or w(nv)) and d.rank == 8:
+        ga, _ = K.rank_outer_wgrad(h, dtb[:, 0:16], flag, transpose_out=False, want_l=True, want_v=False)
+        g[nk], g[nv] = ga[0:8], ga[8:16]
+    elif w(nk) or w(nv):
+        g[nk], g[nv] = _wg(_compact(dtb, lang_idx, "dtb_l"), _compact(h, lang_idx, "h_l"),                       # [64, H]
+                           post=lambda o_: (o_[0:d.rank].contiguous(), o_[8:8 + d.rank].contiguous()))
+    probs = [G(dt_ext, pk["aqkv_ab"], b_t=True, out=dh, c_rows=vis_idx)]                                          # K = 3r + 64
+    nk, nv = a + "vision_k_bridge_on_vision.weight_A", a + "vision_v_bridge_on_vision.weight_A"
+    want_a = any_l([a + f"vision_{nm}_proj.weight_A" for nm in "qkv"])
+    if want_a or w(nk) or w(nv):
+        probs.append(WG(dt_ext, _compact(h, vis_idx, "h_v")))                                                     # [3r + 64, H]
+    outs = K.gemm_multi(probs)
+    if want_a or w(nk) or w(nv):
+        da = outs[1]
+        if want_a:
+            for j, nm in enumerate(("q", "k", "v")):
+                g[a + f"vision_{nm}_proj.weight_A"] = da[j * r:(j + 1) * r]
+        if w(nk) or w(nv):
+            g[nk], g[nv] = da[3 * r:3 * r + d.rank].contiguous(), da[3 * r + 8:3 * r + 8 + d.rank].contiguous()
+    ln_l, ln_v = pre + "input_layernorm.weight", pre + "vision_input_layernorm.weight"
+    dx = K.rmsnorm_routed_bwd(dh, sv["x"], sd[ln_l], sd[ln_v], flag, sv["rstd1"], dres=dx_mid)
+    if w(ln_l) or w(ln_v):
+        g[ln_l], g[ln_v] = _norm_wgrad(dh, sv["x"], sv["rstd1"], flag, lang_idx, vis_idx, w(ln_l), w(ln_v), H)
+    return dx
+
+
 def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w, positions=None):
+    if _multi_ok(d, lang_idx.numel(), vis_idx.numel()):
+        return _layer_backward_multi(sd, pk, i, d, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w, positions)
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S
     dev = dx_out.device
