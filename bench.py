@@ -504,6 +504,56 @@ def timed(w, steps, warmup, world, device):
     return dt
 
 
+def capture_step(w):
+    """The step of `w` as ONE hipGraph (static shapes, no host read inside - true of the ViT + VQ fwd/bwd step): -> (Workload whose
+    step() replays the graph, None) or (None, reason).  Warm-up runs on a side stream first (allocator, autograd engine, first-launch
+    attribute calls), as torch.cuda.graph requires; gradients land in the graph's private pool and every replay refills them."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                w.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = w.step()
+        graph.replay()
+        torch.cuda.synchronize()
+    except Exception as e:
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return None, repr(e)[:200]
+    g = Workload()
+    g.named, g.graph, g.out = getattr(w, "named", None), graph, out
+
+    def step():
+        graph.replay()
+        return out
+    g.step = step
+    return g, None
+
+
+def grads_check(named):
+    """L2 norm of every gradient of `named` (libra_sumsq_bf16: deterministic - a checksum between runs / schedules) and finiteness."""
+    from libra_amd import kernels as K
+    acc, n_grad, first = None, 0, True
+    for _, p in named:
+        g = p.grad
+        if g is None:
+            continue
+        if acc is None:
+            acc = torch.zeros(1, dtype=torch.float32, device=g.device)
+        K.sumsq(g.contiguous().view(-1), acc, accumulate=not first)
+        first = False
+        n_grad += g.numel()
+    gn = float(acc.sqrt()) if acc is not None else float("nan")
+    return {"grad_norm": round(gn, 6), "grad_elements": n_grad, "finite": bool(gn == gn and gn != float("inf"))}
+
+
 def roofline(w, workload, ips_per_gpu, gflop_step_img, ms_step=None):
     """One instrumented step: HIP events around every GEMM launch on the launch stream (the whole step runs on one stream,
     so a bracket contains exactly its own launch)."""
@@ -837,11 +887,28 @@ def main():
         try:
             wv = make_vit(device, 32, 1, "allreduce")
             dtv = timed(wv, 20, 3, 1, device)
-            ipsv = 32 * 20 / dtv
-            extra["vit_leg"] = {"workload": names["vit"].replace(f"bs={args.batch}", "bs=32"), "images_per_s": round(ipsv, 2),
-                                "ms_per_step": round(dtv / 20 * 1e3, 3),
-                                "roofline": roofline(wv, "vit", ipsv, gflop_per_image("vit"))}
-            note(f"vit leg: {ipsv:.1f} images/s")
+            ips_eager = 32 * 20 / dtv
+            ids_eager = wv.step().clone()
+            chk = grads_check(wv.named)                  # the eager step's gradients: checksum + finiteness
+            chk["ids_checksum"] = int(ids_eager.sum())
+            leg = {"workload": names["vit"].replace(f"bs={args.batch}", "bs=32")}
+            # the same step as one hipGraph: ~1000 launches per 49 ms are close to the host's launch rate in eager mode, which made the
+            # eager number swing by 20 % between runs - the replayed graph measures the GPU
+            wg, why = capture_step(wv)
+            if wg is not None:
+                dtg = timed(wg, 20, 3, 1, device)
+                ipsv = 32 * 20 / dtg
+                chk_g = grads_check(wv.named)
+                chk["graph_replay_equals_eager"] = bool(chk_g["grad_norm"] == chk["grad_norm"] and torch.equal(wg.out, ids_eager))
+                leg.update(images_per_s=round(ipsv, 2), ms_per_step=round(dtg / 20 * 1e3, 3), launch="one hipGraph per step (replay)",
+                           eager_images_per_s=round(ips_eager, 2), eager_ms_per_step=round(dtv / 20 * 1e3, 3))
+            else:
+                ipsv = ips_eager
+                leg.update(images_per_s=round(ips_eager, 2), ms_per_step=round(dtv / 20 * 1e3, 3), launch="eager", graph_capture_failed=why)
+            leg["step_check"] = chk
+            leg["roofline"] = roofline(wv, "vit", ipsv, gflop_per_image("vit"))
+            extra["vit_leg"] = leg
+            note(f"vit leg: {ipsv:.1f} images/s ({leg['launch']}; eager {ips_eager:.1f}); check {chk}")
             del wv
             torch.cuda.empty_cache()
         except Exception as e:

@@ -383,6 +383,10 @@ _MULTI_WS = {}
 def _multi_ws(device) -> torch.Tensor:
     """The 64-byte tile-queue workspace of libra_gemm_bf16_multi: one per (device, stream), zeroed ONCE (the kernel leaves it zero)."""
     dev = torch.device(device)
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the launch belongs to the GRAPH, which may be replayed on any stream next to other graphs: it gets
+        # a workspace of its own from the graph's private pool (a 64-byte fill node per launch; nothing cached outside the graph)
+        return torch.zeros(16, dtype=torch.int32, device=dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
     ws = _MULTI_WS.get(key)
     if ws is None:

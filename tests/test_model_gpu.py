@@ -167,6 +167,51 @@ def test_vit_l_batch_consistency_and_determinism(vit_l):
     assert torch.isfinite(a[-1].float()).all()
 
 
+def test_vit_l_bs32_backward_step_properties(vit_l):
+    """configs[1] at its own batch (bs 32: M = 18 464 token rows), forward AND backward, inside a test (the bs-32 step
+    only ever ran in bench.py).  The oracle covers the backward at B = 1 (tests/test_parity_fullsize_gpu.py); here the
+    size-independent properties that a batch-dependent bug in the split-K weight gradients or the LayerNorm-parameter reductions
+    would break: (i) run-to-run bit-identical gradients, all finite; (ii) the pixel gradient of image 5 inside the batch equals the
+    one it gets alone (per-image chain; only the fp32 summation order of the K-sliced B = 1 dgrads differs); (iii) linearity over the
+    batch - every parameter gradient of the 32-image step equals the sum of the two 16-image halves' gradients."""
+    m, _, _ = vit_l
+    m.requires_grad_(True)
+    try:
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(32, 3, 336, 336, generator=g).to(BF).cuda()
+        ct = (torch.randn(32, 576, 2048, generator=g) * 0.05).to(BF).cuda()
+
+        def step(xs, cts):
+            for p in m.parameters():
+                p.grad = None
+            xin = xs.clone().requires_grad_(True)
+            hs = m(xin, output_hidden_states=True).hidden_states
+            torch.cat([hs[-2], hs[-3]], -1)[:, 1:].backward(cts)
+            return xin.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        dpix, grads = step(x, ct)
+        dpix2, grads2 = step(x, ct)
+        assert torch.equal(dpix, dpix2) and all(torch.equal(grads[n], grads2[n]) for n in grads), "the bs-32 step is not deterministic"
+        assert torch.isfinite(dpix.float()).all() and all(torch.isfinite(v.float()).all() for v in grads.values())
+        assert len(grads) >= 16 * 23 and float(dpix.float().abs().max()) > 0
+        dpix_one, _ = step(x[5:6], ct[5:6])
+        e5 = rel_err(dpix[5:6].float().cpu(), dpix_one.float().cpu())
+        assert e5 < 1e-2, ("pixel gradient of image 5: inside the batch vs alone", e5)
+        _, ga = step(x[:16], ct[:16])
+        _, gb = step(x[16:], ct[16:])
+        worst = ("", 0.0)
+        for n, v in grads.items():
+            e = rel_err(v.float().cpu(), (ga[n].float() + gb[n].float()).cpu())
+            if e > worst[1]:
+                worst = (n, e)
+        # bf16 storage of each half's gradient (2^-9 each) + fp32 summation order: well inside 2e-2 of the largest element
+        assert worst[1] < 2e-2, ("batch linearity of the weight gradients", worst)
+        print(f"ViT-L bs-32 backward: image-5 pixel gradient in-batch vs alone {e5:.2e}; worst half-batch linearity {worst[1]:.2e} ({worst[0]})")
+    finally:
+        m.requires_grad_(False)
+        for p in m.parameters():
+            p.grad = None
+
+
 def test_vq_full_size_roundtrip_properties(vit_l):
     """VQ encode at B=32, E=512: ids are framed, in range, and equal to offset + the packed sign bits of the
     reported pre-sign values (checksum over the whole batch)."""
