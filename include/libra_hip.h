@@ -93,6 +93,10 @@ int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* co
  * rows + the three LibraLinear.weight_B expansions of the vision rows, modeling_libra.py:192-199), and so do the weight
  * gradients of a layer, which nothing inside the layer waits for.  Per output element the arithmetic is that of
  * libra_gemm_bf16_nt_tile(..., LIBRA_GEMM_TILE_256), bit for bit.  No problem may read what another problem of the same call writes.
+ * splitk > 1: the problem's K range is cut into that many slices, each slice a tile-list entry of its own (a weight gradient with a
+ * few very long tiles becomes filler for the others' last wave); slab = fp32 [splitk][M][N] workspace (16-byte aligned), reduced
+ * to bf16 C by a second kernel in slice order (deterministic) - the arithmetic of libra_gemm_bf16_nt_splitk(_routed); only
+ * LIBRA_GEMM_RESIDUAL may be fused, N % 8 == 0.  splitk <= 1: slab is ignored.
  * queue_ws: 64 bytes of device memory, 16-byte aligned, ALL ZERO at the first use and owned by one stream - the kernel leaves it
  * zero again (its tile queues clear themselves), so it is allocated and cleared once, not per call.                              */
 #define LIBRA_GEMM_MULTI_MAX 12
@@ -102,6 +106,7 @@ typedef struct libra_gemm_problem {
     const void* bias; const void* resid; int64_t ldr; const void* aux; int64_t ldaux; void* preact; int64_t ldpre;
     float alpha; int32_t flags; int64_t alpha_cols;
     const int32_t* a_rows; int64_t a_phys_rows; const int32_t* c_rows;
+    int64_t splitk; void* slab;
 } libra_gemm_problem;
 int libra_gemm_bf16_multi(const libra_gemm_problem* problems, int64_t n_problems, void* queue_ws, void* stream);
 

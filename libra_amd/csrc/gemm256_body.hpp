@@ -196,8 +196,8 @@ __device__ __forceinline__ void gemm256_tile(const Gemm256Args& p, const bf16_t*
     // per-lane bound test and every scalar tail path folds away; > 98 % of the tiles of the hot shapes) and the generic
     // edge version.  The choice is wave-uniform (m0 / n0 come from blockIdx).
     float* ct = (float*)(smem + wave * 8192);
-    if (m0 + 256 <= p.M && n0 + 256 <= p.N) gemm_wave_epilogue<true>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
-    else gemm_wave_epilogue<false>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
+    if (m0 + 256 <= p.M && n0 + 256 <= p.N) gemm_wave_epilogue<true>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane, ky);
+    else gemm_wave_epilogue<false>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane, ky);
 }
 
 }  // namespace libra

@@ -92,6 +92,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 using namespace libra;
 
+// Second stage of a K-sliced launch (also used by gemm_bf16_multi.hip for its split problems): slab[S][M][N] fp32 -> bf16 C.
+extern "C" int libra_splitk_reduce_launch_(const float* slab, int S, int64_t M, int64_t N, void* C, int64_t ldc, const int* c_rows,
+                                           const void* resid, int64_t ldr, void* stream) {
+    const long MN = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       slab, S, MN, (int)N, (bf16_t*)C, (long)ldc, c_rows, (const bf16_t*)resid, (long)ldr);
+    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+}
+
 // Internal launcher (declared in gemm_bf16.hip): returns LIBRA_OK / LIBRA_ERR_LAUNCH. Arguments were validated.
 extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                      int64_t M, int64_t N, int64_t K, const void* bias, const void* resid,
@@ -130,12 +139,7 @@ extern "C" int libra_gemm256_launch_(const void* A, int64_t lda, const void* B, 
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)p.splitk, (unsigned)(groups < 1 ? 1 : groups)), dim3(G256_THREADS), G256_LDS,
                        (hipStream_t)stream, p);
     if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
-    if (slab) {
-        const long MN = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           slab, p.splitk, MN, (int)N, (bf16_t*)C, (long)ldc, c_rows, (flags & LIBRA_GEMM_RESIDUAL) ? (const bf16_t*)resid : nullptr,
-                           (long)ldr);
-        if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
-    }
+    if (slab)
+        return libra_splitk_reduce_launch_(slab, p.splitk, M, N, C, ldc, c_rows, (flags & LIBRA_GEMM_RESIDUAL) ? resid : nullptr, ldr, stream);
     return LIBRA_OK;
 }

@@ -40,10 +40,11 @@ struct GemmProb {                  // device view of one problem (kernel-argumen
     int tile0;                     // first entry of this problem in the launch's tile list (a multiple of 8)
     float alpha; int alpha_cols;
     int flags;
-    int pad_;
+    int splitk;                    // K slices (1 = none): slice ky of tile b is entry ky * tiles + b and writes slab[ky]
+    float* slab;                   // fp32 [splitk][M][N] partial results of a split problem (reduced by a second kernel)
 };
-static_assert(sizeof(GemmProb) == 136, "GemmProb layout");
-static_assert(sizeof(libra_gemm_problem) == 168, "libra_gemm_problem layout (tests/test_cabi_cpu.py checks the host side against it)");
+static_assert(sizeof(GemmProb) == 144, "GemmProb layout");
+static_assert(sizeof(libra_gemm_problem) == 184, "libra_gemm_problem layout (tests/test_cabi_cpu.py checks the host side against it)");
 struct GemmMultiArgs {
     GemmProb prob[MULTI_MAXP];
     int tile0[MULTI_MAXP];         // = prob[i].tile0 (unused slots: INT_MAX): the owner scan reads these with constant indices
@@ -85,7 +86,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
         const ProbPtr q = probs + g;
         const int bid = t - q->tile0;
         const int tiles_m = q->tiles_m, tiles_n = q->tiles_n;
-        if (bid < tiles_m * tiles_n) {                          // (else: one of the <= 7 pad entries behind a problem)
+        const int ntile = tiles_m * tiles_n, sk = q->splitk;
+        if (bid < ntile * sk) {                                 // (else: one of the <= 7 pad entries behind a problem)
+            const int ky = sk > 1 ? bid / ntile : 0;            // slice-major: consecutive entries = neighbouring tiles of one slice
+            const int bt_ = bid - ky * ntile;
             Gemm256Args a;
             a.A = q->A; a.B = q->B; a.C = q->C;
             a.bias = q->bias; a.resid = q->resid; a.aux = q->aux; a.preact = q->preact;
@@ -95,12 +99,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
             a.tiles_m = tiles_m; a.tiles_n = tiles_n;
             a.alpha = q->alpha; a.alpha_cols = q->alpha_cols;
             a.flags = q->flags;
-            a.slab = nullptr; a.splitk = 1;
+            a.slab = q->slab; a.splitk = sk;
             const int v = ((a.flags & LIBRA_GEMM_A_T) ? 2 : 0) | ((a.flags & LIBRA_GEMM_B_T) ? 1 : 0);
-            if ((VARIANTS & 1) && v == 0) gemm256_tile<false, false>(a, a.A, a.B, a.C, bid, 0, smem, tid0, wave, wr, wc);
-            if ((VARIANTS & 2) && v == 1) gemm256_tile<false, true>(a, a.A, a.B, a.C, bid, 0, smem, tid0, wave, wr, wc);
-            if ((VARIANTS & 4) && v == 2) gemm256_tile<true, false>(a, a.A, a.B, a.C, bid, 0, smem, tid0, wave, wr, wc);
-            if ((VARIANTS & 8) && v == 3) gemm256_tile<true, true>(a, a.A, a.B, a.C, bid, 0, smem, tid0, wave, wr, wc);
+            if ((VARIANTS & 1) && v == 0) gemm256_tile<false, false>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
+            if ((VARIANTS & 2) && v == 1) gemm256_tile<false, true>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
+            if ((VARIANTS & 4) && v == 2) gemm256_tile<true, false>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
+            if ((VARIANTS & 8) && v == 3) gemm256_tile<true, true>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
         }
         if (tid0 == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (after a tile: long complete; a pad entry: the fetch's round trip)
@@ -126,6 +130,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
 using namespace libra;
 
 static double tile_us(int64_t K) { return 1.48 * (double)K / 64.0 + 5.3; }    // gemm_bf16.hip cost256, per tile
+
+extern "C" int libra_splitk_reduce_launch_(const float* slab, int S, int64_t M, int64_t N, void* C, int64_t ldc, const int* c_rows,
+                                           const void* resid, int64_t ldr, void* stream);
 
 extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t nprob, void* queue_ws, void* stream) {
     if (nprob <= 0) return LIBRA_OK;
@@ -154,12 +161,18 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
         if ((flags & LIBRA_GEMM_STORE_PREACT) && (!q.preact || (q.ldpre % 8) || q.ldpre < N || ((uintptr_t)q.preact & 15))) return LIBRA_ERR_ALIGN;
         if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return LIBRA_ERR_SHAPE;
         if (q.ldc >= (1LL << 31) || q.ldr >= (1LL << 31) || q.ldaux >= (1LL << 31) || q.ldpre >= (1LL << 31)) return LIBRA_ERR_SHAPE;
+        if (q.splitk > 1) {            // K slices: raw fp32 slabs + the deterministic reduction; only a residual may be fused (as libra_gemm_bf16_nt_splitk_routed)
+            if (q.splitk > K / 64 || q.splitk > 64 || (N % 8)) return LIBRA_ERR_SHAPE;
+            if (flags & ~(LIBRA_GEMM_A_T | LIBRA_GEMM_B_T | LIBRA_GEMM_RESIDUAL)) return LIBRA_ERR_SHAPE;
+            if (!q.slab || ((uintptr_t)q.slab & 15)) return LIBRA_ERR_ALIGN;
+        } else if (q.splitk < 0) return LIBRA_ERR_SHAPE;
         order[n++] = i;
         variants |= 1 << (2 * at + bt);
     }
     if (n == 0) return LIBRA_OK;
     // longest tiles first (stable: equal K keeps the caller's order)
-    std::stable_sort(order, order + n, [&](int x, int y) { return probs[x].K > probs[y].K; });
+    auto slice_k = [&](int x) { return probs[x].K / (probs[x].splitk > 1 ? probs[x].splitk : 1); };
+    std::stable_sort(order, order + n, [&](int x, int y) { return slice_k(x) > slice_k(y); });
     GemmMultiArgs a;
     long entries = 0;
     for (int j = 0; j < n; ++j) {
@@ -173,8 +186,10 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
         d.tiles_m = (int)((q.M + 255) / 256); d.tiles_n = (int)((q.N + 255) / 256);
         d.tile0 = (int)entries;
         d.alpha = q.alpha; d.alpha_cols = (int)q.alpha_cols;
-        d.flags = q.flags; d.pad_ = 0;
-        entries += ((long)d.tiles_m * d.tiles_n + 7) / 8 * 8;
+        d.flags = q.flags;
+        d.splitk = q.splitk > 1 ? (int)q.splitk : 1;
+        d.slab = d.splitk > 1 ? (float*)q.slab : nullptr;
+        entries += ((long)d.tiles_m * d.tiles_n * d.splitk + 7) / 8 * 8;
         if (entries > 0x3fffffffL) return LIBRA_ERR_SHAPE;
     }
     for (int j = n; j < MULTI_MAXP; ++j) { a.prob[j] = GemmProb{}; a.prob[j].tile0 = 0x7fffffff; }
@@ -198,5 +213,14 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
     long nblk = persistent_grid(entries, 8);        // one workgroup per (budgeted) CU, a multiple of 8; entries is one too
     if (nblk < 8) nblk = 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(G256_THREADS), LDS, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? LIBRA_OK : LIBRA_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return LIBRA_ERR_LAUNCH;
+    for (int j = 0; j < n; ++j) {                   // second stage of the split problems
+        const libra_gemm_problem& q = probs[order[j]];
+        if (q.splitk > 1) {
+            const int rc = libra_splitk_reduce_launch_((const float*)q.slab, (int)q.splitk, q.M, q.N, q.C, q.ldc, q.c_rows,
+                                                       (q.flags & LIBRA_GEMM_RESIDUAL) ? q.resid : nullptr, q.ldr, stream);
+            if (rc != LIBRA_OK) return rc;
+        }
+    }
+    return LIBRA_OK;
 }

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(GW_THREADS, 2) void gemm_bf16_nt_w_kernel(const Gem
 
     // ---- epilogue (gemm_epilogue.hpp): each wave round-trips its own 32x64 fp32 slabs through a private 8 KiB LDS region
     float* ct = (float*)(smem + wave * 8192);
-    if (m0 + 256 <= p.M && n0 + GW_BN <= p.N) gemm_wave_epilogue<true>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
-    else gemm_wave_epilogue<false>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane);
+    if (m0 + 256 <= p.M && n0 + GW_BN <= p.N) gemm_wave_epilogue<true>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane, (int)blockIdx.y);
+    else gemm_wave_epilogue<false>(p, acc, Cp, ct, m0 + wr * 128, n0 + wc * 64, lane, (int)blockIdx.y);
 }
 
 }  // namespace libra

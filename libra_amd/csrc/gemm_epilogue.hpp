@@ -34,14 +34,14 @@ __device__ __forceinline__ float qgelu_grad(float x) {
 // ---- epilogue of ONE wave: its 128 x 64 block (acc[i][j] = 32 x 32 MFMA accumulators, i = 32-row slab, j = 32-column half) goes
 // through a private 8 KiB LDS region `ct` one 32 x 64 fp32 slab at a time and leaves as row-contiguous 16-byte bf16 stores with the
 // fused operands applied (bias, column scale, quick-GELU (+ pre-activation store), GELU', residual; or raw fp32 split-K slabs).
-// m0w / n0w: first output row / column of the wave's block.  Two instantiations of the same code: INTERIOR (the whole
+// m0w / n0w: first output row / column of the wave's block; ky: the K slice of a split-K launch (slab index).  Two instantiations of the same code: INTERIOR (the whole
 // workgroup tile lies inside C and N is a multiple of 8 - every per-lane bound test and every scalar tail path folds away; > 98 %
 // of the tiles of the hot shapes) and the generic edge version.  The choice is wave-uniform (it comes from blockIdx).
 // (NJ / J0: the accumulator array may be wider than the 64 columns handled here - gemm_bf16_x.hip's waves own 128 x 128 and call
 // this once per 64-column half, J0 = 0 / 2.)
 template <bool IN, int NJ = 2, int J0 = 0>
 __device__ __forceinline__ void gemm_wave_epilogue(const Gemm256Args& p, const f32x16 (&acc)[4][NJ], bf16_t* Cp, float* ct,
-                                                   const int m0w, const int n0w, const int lane) {
+                                                   const int m0w, const int n0w, const int lane, const int ky) {
     const int l31 = lane & 31, fk = lane >> 5;
     const int cg = lane & 7;                                   // 8-column group within the wave's 64 columns
     const int gn = n0w + cg * 8;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm_wave_epilogue(const Gemm256Args& p, const f
                 const f32x4 lo = *(const f32x4*)(ct + row * 64 + cg * 8);
                 const f32x4 hi = *(const f32x4*)(ct + row * 64 + cg * 8 + 4);
                 if (p.slab) {
-                    float* sd = p.slab + ((long)blockIdx.y * p.M + gm) * p.N + gn;   // slabs are never row-mapped
+                    float* sd = p.slab + ((long)ky * p.M + gm) * p.N + gn;   // (ky = K slice) slabs are never row-mapped
                     if (full8) { *(f32x4*)sd = lo; *(f32x4*)(sd + 4) = hi; }
                     else for (int e = 0; e < 8 && gn + e < p.N; ++e) sd[e] = e < 4 ? lo[e] : hi[e - 4];
                     continue;

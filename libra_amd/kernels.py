@@ -327,8 +327,10 @@ def gemm_spec(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] =
               resid: Optional[torch.Tensor] = None, quick_gelu: bool = False, qgelu_grad_of: Optional[torch.Tensor] = None,
               preact_out: Optional[torch.Tensor] = None, alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None,
               a_t: bool = False, b_t: bool = False, a_rows: Optional[torch.Tensor] = None,
-              c_rows: Optional[torch.Tensor] = None) -> GemmSpec:
-    """The operands of `gemm_nt(a, b, ...)` (same conventions, same checks) as one problem of a `gemm_multi` launch."""
+              c_rows: Optional[torch.Tensor] = None, splitk: int = 1) -> GemmSpec:
+    """The operands of `gemm_nt(a, b, ...)` (same conventions, same checks) as one problem of a `gemm_multi` launch.
+    splitk > 1: cut the reduction into that many slices, each a tile-list entry of its own, fp32 partial slabs reduced in slice
+    order by a second kernel (weight gradients: few tiles, very long K); at most a residual may be fused, N % 8 == 0."""
     _chk2d(a, "a"); _chk2d(b, "b")
     (Ka, M) = a.shape if a_t else a.shape[::-1]
     a_phys = a.shape[0]
@@ -367,12 +369,18 @@ def gemm_spec(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] =
         flags |= GEMM_STORE_PREACT; ldpre = preact_out.stride(0)
     if quick_gelu:
         flags |= GEMM_QUICK_GELU
+    slab = None
+    splitk = max(1, min(int(splitk), K // 64))
+    if splitk > 1:
+        if (flags & ~(GEMM_A_T | GEMM_B_T | GEMM_RESIDUAL)) or alpha_cols or N % 8:
+            raise ValueError("gemm_spec: a K-sliced problem may only fuse a residual (and needs N % 8 == 0)")
+        slab = torch.empty(splitk * M * N, dtype=torch.float32, device=a.device)
     sp = GemmSpec()
     sp.c = _lib.GemmProblem(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
                             _ptr(bias), _ptr(resid), ldr, _ptr(qgelu_grad_of), ldaux, _ptr(preact_out), ldpre, float(alpha), flags,
-                            int(alpha_cols), _ptr(a_rows), a_phys, _ptr(c_rows))
+                            int(alpha_cols), _ptr(a_rows), a_phys, _ptr(c_rows), splitk, _ptr(slab))
     sp.out = out
-    sp.keep = (a, b, out, bias, resid, qgelu_grad_of, preact_out, a_rows, c_rows)
+    sp.keep = (a, b, out, bias, resid, qgelu_grad_of, preact_out, a_rows, c_rows, slab)
     sp.work = (2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), f"{M}x{N}x{K}{' aT' if a_t else ''}{' bT' if b_t else ''}")
     return sp
 

@@ -174,6 +174,36 @@ def test_multi_decoder_stage_shapes_full_size(K):
     assert _ws_zero(K)
 
 
+def test_multi_k_sliced_problems(K):
+    """splitk > 1: a weight-gradient-shaped problem (few tiles, long K) cut into K slices that ride in the same tile list as an
+    unsplit problem; equal, bit for bit, to libra_gemm_bf16_nt_splitk with the same number of slices (same slices, same
+    slice-order fp32 reduction), and within the kernel tolerance of fp32 math."""
+    from libra_amd import _lib
+    M, N, Kd, S = 512, 1024, 8192, 4
+    a, b = rnd(M, Kd, seed=21, scale=0.5), rnd(N, Kd, seed=22, scale=0.5)
+    at, bt = a.t().contiguous(), b.t().contiguous()                    # reduction-major, as a weight gradient's operands
+    x, w = rnd(1000, 512, seed=23), rnd(768, 512, seed=24)
+    o_split = torch.zeros((M, N), dtype=BF, device="cuda")
+    o_plain = torch.zeros((1000, 768), dtype=BF, device="cuda")
+    r = rnd(M, N, seed=25)
+    o_res = torch.zeros((M, N), dtype=BF, device="cuda")
+    K.gemm_multi([K.gemm_spec(at, bt, out=o_split, a_t=True, b_t=True, splitk=S), K.gemm_spec(x, w, out=o_plain),
+                  K.gemm_spec(a, b, out=o_res, resid=r, splitk=3)])
+    ref = torch.zeros((M, N), dtype=BF, device="cuda")
+    nbytes = _lib.lib().libra_gemm_splitk_workspace_bytes(M, N, S)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+    rc = _lib.lib().libra_gemm_bf16_nt_splitk(at.data_ptr(), at.stride(0), bt.data_ptr(), bt.stride(0), ref.data_ptr(), ref.stride(0),
+                                              M, N, Kd, S, K.GEMM_A_T | K.GEMM_B_T, ws.data_ptr(), nbytes, K._stream())
+    assert rc == 0
+    assert torch.equal(o_split, ref)
+    close(o_split, a.float() @ b.float().t(), what="K-sliced problem vs fp32")
+    close(o_res, a.float() @ b.float().t() + r.float(), what="K-sliced problem with a residual vs fp32")
+    assert torch.equal(o_plain, K.gemm_nt(x, w))
+    assert _ws_zero(K)
+    with pytest.raises(ValueError):
+        K.gemm_spec(a, b, bias=rnd(N, seed=1), splitk=2)               # only a residual may be fused into a K-sliced problem
+
+
 def test_multi_rejects_bad_problems(K):
     a, b = rnd(256, 64, seed=1), rnd(256, 64, seed=2)
     with pytest.raises(ValueError):
