@@ -692,7 +692,13 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ViT leg, optimizer leg) at N=1")
     ap.add_argument("--no-multi", action="store_true",
                     help="A/B switch: the round-5 launch schedule (one launch per GEMM) instead of the multi-problem launches")
+    ap.add_argument("--chain", action="store_true",
+                    help="A/B switch: fold the first low-rank stage of each vision pair into the multi-problem launch of its second "
+                         "stage (device-side producer -> consumer wait; decoder_engine.CHAIN)")
     args = ap.parse_args()
+    if args.chain:
+        from libra_amd import decoder_engine as _DE
+        _DE.CHAIN = True
     if args.no_multi:
         from libra_amd import decoder_engine as _DE, vit_engine as _VE
         _DE.MULTI = False
@@ -860,7 +866,8 @@ def main():
                       "optimizer_in_step": bool(args.with_optimizer), "recompute": bool(args.recompute),
                       "full_finetune": bool(args.full_finetune),
                       "grad_accum": args.accum,
-                      "gemm_schedule": "one launch per GEMM (--no-multi)" if args.no_multi else "multi-problem launches (libra_gemm_bf16_multi)"},
+                      "gemm_schedule": "one launch per GEMM (--no-multi)" if args.no_multi else
+                                       "multi-problem launches (libra_gemm_bf16_multi)" + (" + chained low-rank stages" if args.chain else "")},
            "roofline": roof}
     if check is not None:
         out["step_check"] = check         # loss + gradient norm of exactly the timed step (tests/test_configs_gpu.py::test_headline_step_full_size_loss_and_recompute_identity bounds them)

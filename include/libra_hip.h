@@ -97,8 +97,14 @@ int libra_gemm_bf16_nt_grouped(const void* const* A, int64_t lda, const void* co
  * few very long tiles becomes filler for the others' last wave); slab = fp32 [splitk][M][N] workspace (16-byte aligned), reduced
  * to bf16 C by a second kernel in slice order (deterministic) - the arithmetic of libra_gemm_bf16_nt_splitk(_routed); only
  * LIBRA_GEMM_RESIDUAL may be fused, N % 8 == 0.  splitk <= 1: slab is ignored.
- * queue_ws: 64 bytes of device memory, 16-byte aligned, ALL ZERO at the first use and owned by one stream - the kernel leaves it
- * zero again (its tile queues clear themselves), so it is allocated and cleared once, not per call.                              */
+ * wait_on >= 0: this problem READS (as A, B, residual ...) the C of problems[wait_on] - the one exception to "independent": its tiles
+ * are listed behind the producer's and wait, on the device, until all of the producer's tiles are stored (release / acquire at
+ * agent scope).  The producer must be an unsplit problem that waits for nothing itself.  (The second low-rank stage of a LibraLinear
+ * pair, modeling_libra.py:192-199, behind its first stage, in the launch of the text GEMM that runs beside both.)  -1: none.
+ * queue_ws: 128 bytes of device memory, 16-byte aligned, ALL ZERO at the first use and owned by one stream - the kernel leaves it
+ * zero again (its counters clear themselves), so it is allocated and cleared once, not per call; word 10 turns non-zero, and stays
+ * so, if a device-side wait ever ran out (the results of that call are then invalid).
+ */
 #define LIBRA_GEMM_MULTI_MAX 12
 typedef struct libra_gemm_problem {
     const void* A; int64_t lda; const void* B; int64_t ldb; void* C; int64_t ldc;
@@ -107,6 +113,7 @@ typedef struct libra_gemm_problem {
     float alpha; int32_t flags; int64_t alpha_cols;
     const int32_t* a_rows; int64_t a_phys_rows; const int32_t* c_rows;
     int64_t splitk; void* slab;
+    int64_t wait_on;
 } libra_gemm_problem;
 int libra_gemm_bf16_multi(const libra_gemm_problem* problems, int64_t n_problems, void* queue_ws, void* stream);
 

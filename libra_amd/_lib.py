@@ -24,7 +24,7 @@ class GemmProblem(C.Structure):
                 ("M", _I64), ("N", _I64), ("K", _I64),
                 ("bias", _P), ("resid", _P), ("ldr", _I64), ("aux", _P), ("ldaux", _I64), ("preact", _P), ("ldpre", _I64),
                 ("alpha", _F), ("flags", C.c_int32), ("alpha_cols", _I64),
-                ("a_rows", _P), ("a_phys_rows", _I64), ("c_rows", _P), ("splitk", _I64), ("slab", _P)]
+                ("a_rows", _P), ("a_phys_rows", _I64), ("c_rows", _P), ("splitk", _I64), ("slab", _P), ("wait_on", _I64)]
 
 
 # name -> argtypes, exactly the prototypes of include/libra_hip.h

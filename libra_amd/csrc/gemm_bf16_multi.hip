@@ -19,6 +19,13 @@
 //     the LDS-DMA, DESIGN rule 1, and the compiler's waitcnt pass never sees it.)
 //   * the queue words live in a 64-byte caller-owned workspace that is all zero between launches: the last workgroup to leave
 //     clears it (no memset node per launch, no library-owned global state).  One workspace per stream.
+//   * a problem may READ the output of one other problem of the same launch (wait_on): its tiles are listed after the producer's,
+//     the producer's tiles count themselves done behind an agent-scope release, and a consumer tile that comes up early waits for
+//     the count behind an acquire (bounded: a wait that runs out sets a sticky word of the workspace instead of hanging the
+//     chip).  That folds the first low-rank stage of a LibraLinear pair (x A^T, 76 tiles = 0.3 waves as a launch of its own)
+//     into the launch that holds its second stage and the text GEMM beside it.  Every workgroup is resident (grid <= compute
+//     units, one workgroup each) and producers precede consumers in every queue, so a waiting tile always waits for work that is
+//     running or already done.
 // The tile itself is gemm256_body.hpp - the same code, bit for bit, as gemm_bf16_nt_256_kernel; the operand layout (A_T / B_T)
 // is a per-problem, wave-uniform branch around it.  Results do not depend on which workgroup computes a tile.
 #include <algorithm>
@@ -42,18 +49,24 @@ struct GemmProb {                  // device view of one problem (kernel-argumen
     int flags;
     int splitk;                    // K slices (1 = none): slice ky of tile b is entry ky * tiles + b and writes slab[ky]
     float* slab;                   // fp32 [splitk][M][N] partial results of a split problem (reduced by a second kernel)
+    int wait_on;                   // launch-order index of the problem whose C this problem reads (-1: none) ...
+    int wait_need;                 // ... and how many finished tiles of it make C complete
+    int signal;                    // some problem of the launch waits on this one: count finished tiles in queue[16 + own index]
+    int pad_;
 };
-static_assert(sizeof(GemmProb) == 144, "GemmProb layout");
-static_assert(sizeof(libra_gemm_problem) == 184, "libra_gemm_problem layout (tests/test_cabi_cpu.py checks the host side against it)");
+static_assert(sizeof(GemmProb) == 160, "GemmProb layout");
+static_assert(sizeof(libra_gemm_problem) == 192, "libra_gemm_problem layout (tests/test_cabi_cpu.py checks the host side against it)");
 struct GemmMultiArgs {
     GemmProb prob[MULTI_MAXP];
     int tile0[MULTI_MAXP];         // = prob[i].tile0 (unused slots: INT_MAX): the owner scan reads these with constant indices
-    unsigned* queue;               // [0..7] entries taken from queue x beyond the static first ones, [8] workgroups done
+    unsigned* queue;               // [0..7] entries taken from queue x beyond the static first ones, [8] workgroups done,
+                                   // [10] sticky: a bounded wait ran out, [16 + i] finished tiles of problem i (if signalled)
     int nprob; int nentries;
 };
 static_assert(offsetof(GemmMultiArgs, prob) == 0, "the kernel reads prob[] at the start of the kernel-argument segment");
 
 typedef const __attribute__((address_space(4))) GemmProb* ProbPtr;
+constexpr unsigned MULTI_SPIN_MAX = 1u << 21;   // x ~1 us of s_sleep: seconds, then give up loudly (queue[10]) instead of hanging
 
 // VARIANTS: bit (2 at + bt) set = that operand layout may occur in the launch (the launcher picks the smallest superset: a body
 // that cannot occur is not compiled in)
@@ -90,6 +103,19 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
         if (bid < ntile * sk) {                                 // (else: one of the <= 7 pad entries behind a problem)
             const int ky = sk > 1 ? bid / ntile : 0;            // slice-major: consecutive entries = neighbouring tiles of one slice
             const int bt_ = bid - ky * ntile;
+            const int wait_on = q->wait_on;
+            if (wait_on >= 0) {                                 // this problem reads another one's C: all of the producer's tiles done?
+                if (tid0 == 0) {
+                    const unsigned need = (unsigned)q->wait_need;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.queue + 16 + wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                        if (++spins > MULTI_SPIN_MAX) { __hip_atomic_store(p.queue + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (cache-level: the whole workgroup reads behind the barrier)
+                }
+                __syncthreads();
+            }
             Gemm256Args a;
             a.A = q->A; a.B = q->B; a.C = q->C;
             a.bias = q->bias; a.resid = q->resid; a.aux = q->aux; a.preact = q->preact;
@@ -105,6 +131,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
             if ((VARIANTS & 2) && v == 1) gemm256_tile<false, true>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
             if ((VARIANTS & 4) && v == 2) gemm256_tile<true, false>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
             if ((VARIANTS & 8) && v == 3) gemm256_tile<true, true>(a, a.A, a.B, a.C, bt_, ky, smem, tid0, wave, wr, wc);
+            if (q->signal) {                                    // someone waits for this problem: publish the tile, then count it
+                __syncthreads();                                // every wave's stores are issued and complete (workgroup release)
+                if (tid0 == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_fetch_add(p.queue + 16 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         if (tid0 == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (after a tile: long complete; a pad entry: the fetch's round trip)
@@ -121,6 +154,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
         if (done == gridDim.x - 1) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < MULTI_MAXP; ++i) __hip_atomic_store(p.queue + 16 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -166,6 +201,11 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
             if (flags & ~(LIBRA_GEMM_A_T | LIBRA_GEMM_B_T | LIBRA_GEMM_RESIDUAL)) return LIBRA_ERR_SHAPE;
             if (!q.slab || ((uintptr_t)q.slab & 15)) return LIBRA_ERR_ALIGN;
         } else if (q.splitk < 0) return LIBRA_ERR_SHAPE;
+        if (q.wait_on >= 0) {          // reads the C of problem wait_on: an unsplit, non-empty problem of this call that waits for nothing itself
+            if (q.wait_on >= nprob || q.wait_on == i) return LIBRA_ERR_SHAPE;
+            const libra_gemm_problem& w = probs[q.wait_on];
+            if (w.wait_on >= 0 || w.splitk > 1 || w.M <= 0 || w.N <= 0) return LIBRA_ERR_SHAPE;
+        }
         order[n++] = i;
         variants |= 1 << (2 * at + bt);
     }
@@ -173,6 +213,21 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
     // longest tiles first (stable: equal K keeps the caller's order)
     auto slice_k = [&](int x) { return probs[x].K / (probs[x].splitk > 1 ? probs[x].splitk : 1); };
     std::stable_sort(order, order + n, [&](int x, int y) { return slice_k(x) > slice_k(y); });
+    // a consumer goes behind its producer (producers wait for nothing: one pass; it keeps its place among the later problems)
+    for (int j = 0; j < n; ++j) {
+        const int c = order[j], w = (int)probs[c].wait_on;
+        if (w < 0) continue;
+        int pw = -1;
+        for (int k = 0; k < n; ++k) if (order[k] == w) pw = k;
+        if (pw > j) {                                   // producer currently later: rotate the consumer to just behind it
+            for (int k = j; k < pw; ++k) order[k] = order[k + 1];
+            order[pw] = c;
+            --j;                                        // the element that moved into slot j has not been looked at
+        }
+    }
+    int pos[MULTI_MAXP];
+    for (int i = 0; i < MULTI_MAXP; ++i) pos[i] = -1;
+    for (int j = 0; j < n; ++j) pos[order[j]] = j;
     GemmMultiArgs a;
     long entries = 0;
     for (int j = 0; j < n; ++j) {
@@ -189,10 +244,18 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
         d.flags = q.flags;
         d.splitk = q.splitk > 1 ? (int)q.splitk : 1;
         d.slab = d.splitk > 1 ? (float*)q.slab : nullptr;
+        d.wait_on = q.wait_on >= 0 ? pos[q.wait_on] : -1;
+        d.wait_need = 0; d.signal = 0; d.pad_ = 0;
         entries += ((long)d.tiles_m * d.tiles_n * d.splitk + 7) / 8 * 8;
         if (entries > 0x3fffffffL) return LIBRA_ERR_SHAPE;
     }
-    for (int j = n; j < MULTI_MAXP; ++j) { a.prob[j] = GemmProb{}; a.prob[j].tile0 = 0x7fffffff; }
+    for (int j = 0; j < n; ++j)
+        if (a.prob[j].wait_on >= 0) {
+            GemmProb& w = a.prob[a.prob[j].wait_on];
+            w.signal = 1;
+            a.prob[j].wait_need = w.tiles_m * w.tiles_n;
+        }
+    for (int j = n; j < MULTI_MAXP; ++j) { a.prob[j] = GemmProb{}; a.prob[j].tile0 = 0x7fffffff; a.prob[j].wait_on = -1; }
     for (int j = 0; j < MULTI_MAXP; ++j) a.tile0[j] = a.prob[j].tile0;
     a.queue = (unsigned*)queue_ws; a.nprob = n; a.nentries = (int)entries;
     (void)tile_us;

@@ -369,6 +369,9 @@ class KVCache:
 # instead of each paying their own.  False = the round-5 schedule (one launch per GEMM / grouped launch), kept for same-process A/Bs
 # (bench.py --no-multi) and as the schedule of addition_mode and of generation steps.
 MULTI = True
+# ... and the FIRST low-rank stage of a vision pair (x A^T: 76 tiles = 0.3 waves as a launch of its own) rides in the same launch as
+# its second stage, which waits for it on the device (gemm_spec(reads=...)).  Off until measured on the chip.
+CHAIN = False
 
 
 def _multi_ok(d: "DecDims", n_l: int, n_v: int) -> bool:
@@ -401,12 +404,15 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     G = K.gemm_spec
     if multi:
         # vision A stage first (the expansions need it); then text q|k|v (+ bridge A) and the three rank-r expansions together
-        t_ext = K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=_rows(n_v, 3 * r + 64, dev, save, "t_ext"))      # [n_v, 3r + 64]
+        t_ext = _rows(n_v, 3 * r + 64, dev, save, "t_ext")                                                         # [n_v, 3r + 64]
         t = t_ext[:, :3 * r]
+        pa = G(h, pk["aqkv_ab"], a_rows=vis_idx, out=t_ext) if CHAIN else None
+        if not CHAIN:                                            # (a launch of its own goes through the library's tile planner)
+            K.gemm_nt(h, pk["aqkv_ab"], a_rows=vis_idx, out=t_ext)
+        K.gemm_multi(([pa] if CHAIN else []) + [G(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)]
+                     + [G(t[:, j * r:(j + 1) * r], sd[a + f"vision_{nm}_proj.weight_B"], out=qkv[:, j * H:(j + 1) * H], c_rows=vis_idx,
+                          reads=pa if CHAIN else None) for j, nm in enumerate(("q", "k", "v"))])
         tb.index_copy_(0, vis_idx.long(), t_ext[:, 3 * r:])
-        K.gemm_multi([G(h, pk["wqkv_ab"], out=qkvt, a_rows=lang_idx, c_rows=lang_idx)]
-                     + [G(t[:, j * r:(j + 1) * r], sd[a + f"vision_{nm}_proj.weight_B"], out=qkv[:, j * H:(j + 1) * H], c_rows=vis_idx)
-                        for j, nm in enumerate(("q", "k", "v"))])
     elif d.addition:
         K.gemm_nt(h, pk["wqkv_ab"], out=qkvt)                        # language projections (+ language bridge A) on every row
     elif n_l:
@@ -449,9 +455,13 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     x_mid = torch.empty_like(x)
     to = None
     if multi:
-        to = K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=_rows(n_v, r, dev, save, "to"))
-        K.gemm_multi([G(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x),
-                      G(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x)])
+        to = _rows(n_v, r, dev, save, "to")
+        pa = G(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=to) if CHAIN else None
+        if not CHAIN:
+            K.gemm_nt(o, sd[a + "vision_o_proj.weight_A"], a_rows=vis_idx, out=to)
+        K.gemm_multi(([pa] if CHAIN else []) + [G(o, sd[a + "o_proj.weight"], out=x_mid, a_rows=lang_idx, c_rows=lang_idx, resid=x),
+                                                 G(to, sd[a + "vision_o_proj.weight_B"], out=x_mid, c_rows=vis_idx, resid=x,
+                                                   reads=pa if CHAIN else None)])
     elif d.addition:
         K.gemm_nt(o, sd[a + "o_proj.weight"], out=x_mid, resid=x)    # every row
     elif n_l:
@@ -465,17 +475,25 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     x_out = torch.empty_like(x) if need_out else None      # (a recompute pass stops before the last down projections)
     gu = act = tg = guv = actv = td = None
     if multi:
-        tg = K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=_rows(n_v, 2 * rg, dev, save, "tg"))               # [n_v, 2 rg]
+        tg = _rows(n_v, 2 * rg, dev, save, "tg")                                                               # [n_v, 2 rg]
         guv = torch.empty((n_v, 2 * I), dtype=BF16, device=dev)
-        gu = K.gemm_multi([G(h2, pk["wgu"], a_rows=lang_idx),                                               # [n_l, 2I]
-                           G(tg[:, :rg], sd[m + "vision_gate_proj.weight_B"], out=guv[:, :I]),
-                           G(tg[:, rg:], sd[m + "vision_up_proj.weight_B"], out=guv[:, I:])])[0]
+        pa = G(h2, pk["agu"], a_rows=vis_idx, out=tg) if CHAIN else None
+        if not CHAIN:
+            K.gemm_nt(h2, pk["agu"], a_rows=vis_idx, out=tg)
+        ptxt = G(h2, pk["wgu"], a_rows=lang_idx)                                                              # [n_l, 2I]
+        K.gemm_multi(([pa] if CHAIN else []) + [ptxt,
+                     G(tg[:, :rg], sd[m + "vision_gate_proj.weight_B"], out=guv[:, :I], reads=pa if CHAIN else None),
+                     G(tg[:, rg:], sd[m + "vision_up_proj.weight_B"], out=guv[:, I:], reads=pa if CHAIN else None)])
+        gu = ptxt.out
         act = K.swiglu(gu[:, :I], gu[:, I:], out=_rows(n_l, I, dev, save, "act"))
         actv = K.swiglu(guv[:, :I], guv[:, I:], out=_rows(n_v, I, dev, save, "actv"))
-        td = K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=_rows(n_v, r, dev, save, "td"))
+        td = _rows(n_v, r, dev, save, "td")
+        pa = G(actv, sd[m + "vision_down_proj.weight_A"], out=td) if CHAIN and need_out else None
+        if pa is None:
+            K.gemm_nt(actv, sd[m + "vision_down_proj.weight_A"], out=td)
         if need_out:
-            K.gemm_multi([G(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid),
-                          G(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid)])
+            K.gemm_multi(([pa] if CHAIN else []) + [G(act, sd[m + "down_proj.weight"], out=x_out, c_rows=lang_idx, resid=x_mid),
+                         G(td, sd[m + "vision_down_proj.weight_B"], out=x_out, c_rows=vis_idx, resid=x_mid, reads=pa if CHAIN else None)])
     elif n_l and n_l <= 16 and not save:                     # generation step: gate | up GEMM + SwiGLU as one weight-streaming launch
         act = K.gemm_swiglu_skinny(h2, pk["wgu"], a_rows=lang_idx)
     elif n_l:
@@ -1113,23 +1131,27 @@ def _layer_backward_multi(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis
     any_l = lambda names: any(w(n) for n in names)
     G = K.gemm_spec
 
-    def WG(dy_c, x_c, name=None):            # weight-gradient problem: dW[out, in] = dy^T x, straight into the bucket slot when capturing
-        return G(_full(dy_c), _full(x_c), a_t=True, b_t=True, out=dp.grad_out(name) if name is not None else None)
+    def WG(dy_c, x_c, name=None, reads=None):   # weight-gradient problem: dW[out, in] = dy^T x, straight into the bucket slot when capturing
+        return G(_full(dy_c), _full(x_c), a_t=True, b_t=True, out=dp.grad_out(name) if name is not None else None, reads=reads)
 
     # ================= MLP =================
     dh2 = torch.empty((N, H), dtype=BF16, device=dev)
     h2, gu = sv["h2"], sv["gu"]
     tg, guv, actv, td = sv["tg"], sv["guv"], sv["actv"], sv["td"]
     dxo_v = _compact(dx_out, vis_idx, "dxo_v")
-    dtd = K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=_arows("b.dtd", n_v, r, dev))
+    dtd = _arows("b.dtd", n_v, r, dev)
+    p0 = rd = G(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=dtd) if CHAIN else None
+    if not CHAIN:
+        K.gemm_nt(dxo_v, sd[m + "vision_down_proj.weight_B"], b_t=True, out=dtd)
     probs, post = [G(dx_out, sd[m + "down_proj.weight"], b_t=True, a_rows=lang_idx),                            # dact  [n_l, I]
-                   G(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True)], []                                    # dactv [n_v, I]
-    for nm, dy_c, x_c in ((m + "vision_down_proj.weight_B", dxo_v, td), (m + "vision_down_proj.weight_A", dtd, actv)):
-        if w(nm):
-            probs.append(WG(dy_c, x_c, nm)); post.append(nm)
+                   G(dtd, sd[m + "vision_down_proj.weight_A"], b_t=True, reads=rd)], []                          # dactv [n_v, I]
+    if w(m + "vision_down_proj.weight_B"):
+        probs.append(WG(dxo_v, td, m + "vision_down_proj.weight_B")); post.append(m + "vision_down_proj.weight_B")
+    if w(m + "vision_down_proj.weight_A"):
+        probs.append(WG(dtd, actv, m + "vision_down_proj.weight_A", reads=rd)); post.append(m + "vision_down_proj.weight_A")
     if w(m + "down_proj.weight"):
         probs.append(WG(_compact(dx_out, lang_idx, "dxo_l"), sv["act"], m + "down_proj.weight")); post.append(m + "down_proj.weight")
-    outs = K.gemm_multi(probs)
+    outs = K.gemm_multi(probs + ([p0] if CHAIN else []))
     dact, dactv = outs[0], outs[1]
     for nm, o in zip(post, outs[2:]):
         g[nm] = o
@@ -1168,16 +1190,19 @@ def _layer_backward_multi(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis
     o = sv["o"]
     do = torch.empty((N, H), dtype=BF16, device=dev)
     dxm_v = _compact(dx_mid, vis_idx, "dxm_v")
-    dto = K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=_arows("b.dto", n_v, r, dev))
+    dto = _arows("b.dto", n_v, r, dev)
+    p0 = rd = G(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=dto) if CHAIN else None
+    if not CHAIN:
+        K.gemm_nt(dxm_v, sd[a + "vision_o_proj.weight_B"], b_t=True, out=dto)
     probs, post = [G(dx_mid, sd[a + "o_proj.weight"], b_t=True, a_rows=lang_idx, c_rows=lang_idx, out=do),
-                   G(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx)], []
+                   G(dto, sd[a + "vision_o_proj.weight_A"], b_t=True, out=do, c_rows=vis_idx, reads=rd)], []
     if w(a + "vision_o_proj.weight_B"):
         probs.append(WG(dxm_v, sv["to"], a + "vision_o_proj.weight_B")); post.append(a + "vision_o_proj.weight_B")
     if w(a + "vision_o_proj.weight_A"):
-        probs.append(WG(dto, _compact(o, vis_idx, "o_v"), a + "vision_o_proj.weight_A")); post.append(a + "vision_o_proj.weight_A")
+        probs.append(WG(dto, _compact(o, vis_idx, "o_v"), a + "vision_o_proj.weight_A", reads=rd)); post.append(a + "vision_o_proj.weight_A")
     if w(a + "o_proj.weight"):
         probs.append(WG(_compact(dx_mid, lang_idx, "dxm_l"), _compact(o, lang_idx, "o_l"), a + "o_proj.weight")); post.append(a + "o_proj.weight")
-    outs = K.gemm_multi(probs)
+    outs = K.gemm_multi(probs + ([p0] if CHAIN else []))
     for nm, o_ in zip(post, outs[2:]):
         g[nm] = o_
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]

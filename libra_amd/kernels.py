@@ -320,17 +320,19 @@ def gemm_nt_grouped(a_list: Sequence[torch.Tensor], b_list: Sequence[torch.Tenso
 class GemmSpec:
     """One problem of a multi-problem launch (gemm_multi): the arguments of a gemm_nt call, validated, as the C ABI's
     `libra_gemm_problem` - plus the tensors it points into (kept alive until the launch is queued) and its work for the profile."""
-    __slots__ = ("c", "out", "keep", "work")
+    __slots__ = ("c", "out", "keep", "work", "reads")
 
 
 def gemm_spec(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
               resid: Optional[torch.Tensor] = None, quick_gelu: bool = False, qgelu_grad_of: Optional[torch.Tensor] = None,
               preact_out: Optional[torch.Tensor] = None, alpha: float = 1.0, alpha_cols: int = 0, k: Optional[int] = None,
               a_t: bool = False, b_t: bool = False, a_rows: Optional[torch.Tensor] = None,
-              c_rows: Optional[torch.Tensor] = None, splitk: int = 1) -> GemmSpec:
+              c_rows: Optional[torch.Tensor] = None, splitk: int = 1, reads: Optional["GemmSpec"] = None) -> GemmSpec:
     """The operands of `gemm_nt(a, b, ...)` (same conventions, same checks) as one problem of a `gemm_multi` launch.
     splitk > 1: cut the reduction into that many slices, each a tile-list entry of its own, fp32 partial slabs reduced in slice
-    order by a second kernel (weight gradients: few tiles, very long K); at most a residual may be fused, N % 8 == 0."""
+    order by a second kernel (weight gradients: few tiles, very long K); at most a residual may be fused, N % 8 == 0.
+    reads: another problem OF THE SAME gemm_multi CALL whose output this problem reads (as a, b or resid) - its tiles then wait on
+    the device until the producer's are stored (libra_gemm_problem.wait_on); the producer must be unsplit and read nothing itself."""
     _chk2d(a, "a"); _chk2d(b, "b")
     (Ka, M) = a.shape if a_t else a.shape[::-1]
     a_phys = a.shape[0]
@@ -378,7 +380,8 @@ def gemm_spec(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] =
     sp = GemmSpec()
     sp.c = _lib.GemmProblem(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
                             _ptr(bias), _ptr(resid), ldr, _ptr(qgelu_grad_of), ldaux, _ptr(preact_out), ldpre, float(alpha), flags,
-                            int(alpha_cols), _ptr(a_rows), a_phys, _ptr(c_rows), splitk, _ptr(slab))
+                            int(alpha_cols), _ptr(a_rows), a_phys, _ptr(c_rows), splitk, _ptr(slab), -1)
+    sp.reads = reads
     sp.out = out
     sp.keep = (a, b, out, bias, resid, qgelu_grad_of, preact_out, a_rows, c_rows, slab)
     sp.work = (2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), f"{M}x{N}x{K}{' aT' if a_t else ''}{' bT' if b_t else ''}")
@@ -389,16 +392,16 @@ _MULTI_WS = {}
 
 
 def _multi_ws(device) -> torch.Tensor:
-    """The 64-byte tile-queue workspace of libra_gemm_bf16_multi: one per (device, stream), zeroed ONCE (the kernel leaves it zero)."""
+    """The 128-byte tile-queue workspace of libra_gemm_bf16_multi: one per (device, stream), zeroed ONCE (the kernel leaves it zero)."""
     dev = torch.device(device)
     if torch.cuda.is_current_stream_capturing():
         # inside a hipGraph capture the launch belongs to the GRAPH, which may be replayed on any stream next to other graphs: it gets
         # a workspace of its own from the graph's private pool (a 64-byte fill node per launch; nothing cached outside the graph)
-        return torch.zeros(16, dtype=torch.int32, device=dev)
+        return torch.zeros(32, dtype=torch.int32, device=dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
     ws = _MULTI_WS.get(key)
     if ws is None:
-        ws = _MULTI_WS[key] = torch.zeros(16, dtype=torch.int32, device=dev)
+        ws = _MULTI_WS[key] = torch.zeros(32, dtype=torch.int32, device=dev)
     return ws
 
 
@@ -414,6 +417,13 @@ def gemm_multi(specs: Sequence[GemmSpec]) -> list:
     n_max = _lib.GEMM_MULTI_MAX
     for i0 in range(0, len(specs), n_max):
         chunk = specs[i0:i0 + n_max]
+        for sp in chunk:                                 # producer -> consumer edges, by position inside this launch
+            sp.c.wait_on = -1
+            if sp.reads is not None:
+                where = [j for j, other in enumerate(chunk) if other is sp.reads]
+                if not where:
+                    raise ValueError("gemm_multi: a problem `reads` a problem that is not part of the same launch")
+                sp.c.wait_on = where[0]
         arr = (_lib.GemmProblem * len(chunk))(*[sp.c for sp in chunk])
         prof = LaunchProfile.active
         if prof is not None:

@@ -153,6 +153,25 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, m_pad: int, name: Optional[str] = 
     return K.gemm_nt(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True, out=dp.grad_out(name) if name else None)
 
 
+# Round 6: each dgrad of the backward shares ONE multi-problem launch (K.gemm_multi) with the weight gradient that reads the same dY:
+# the weight gradient (64 / 16 / 48 tiles of 256^2 with an 18 496-step reduction at bs 32) is cut into K slices - tile-list entries of
+# its own - that fill the dgrad's last wave instead of a K-sliced launch of their own.  False = the round-5 schedule (bench.py --no-multi).
+MULTI = True
+
+
+def _wgrad_slices(n_out: int, n_in: int, k_tokens: int) -> int:
+    """K slices for a weight gradient inside a multi-problem launch: about one slice per compute unit, at least 8 K tiles each."""
+    tiles = ((n_out + 255) // 256) * ((n_in + 255) // 256)
+    if tiles >= 128 or n_in % 8:
+        return 1
+    return max(1, min(256 // tiles, (k_tokens // 64) // 8, 32))
+
+
+def _wgrad_spec(dy: torch.Tensor, x: torch.Tensor, m_pad: int, name: Optional[str] = None):
+    return K.gemm_spec(_full(dy, m_pad), _full(x, m_pad), a_t=True, b_t=True, out=dp.grad_out(name) if name else None,
+                       splitk=_wgrad_slices(dy.shape[1], x.shape[1], m_pad))
+
+
 def emit_group(name: str, n_layers: int) -> int:
     """Backward-order group of a parameter for the data-parallel bucket layout (dp.GradBuckets): the weight matrices of
     encoder layer i are finished at step L-1-i of the backward; every bias / LayerNorm vector (one fp32 arena converted at
@@ -200,16 +219,24 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
             small.append((name, o, n))
         return arena[o:o + n]
 
-    def param_grads(wname, bname, dy, x, nb, bias_slice=None):
+    def param_grads(wname, bname, dy, x, nb, bias_slice=None, dgrad=None):
         """weight gradient (+ the bias gradient = column sum of dy, unless the kernel that produced dy already summed it
-        into `bias_slice`)."""
+        into `bias_slice`).  dgrad: (weight, kwargs) of the dgrad GEMM that reads the same dy - with MULTI both go out as one
+        launch; -> the dgrad's result (or None)."""
         bslice = f32(nb, bname) if bias_slice is None else None
 
         # (Weight gradients used to run on a second stream; once the kernels were tuned that overlap measured as no gain -
         # 56.6 vs 56.5 ms/step - so the whole backward is one stream and per-launch timings mean what they say.)
-        grads[wname] = _wgrad(dy, x, m_pad, wname)
+        dx_ = None
+        if MULTI and dgrad is not None:
+            dx_, grads[wname] = K.gemm_multi([K.gemm_spec(dy, dgrad[0], b_t=True, **dgrad[1]), _wgrad_spec(dy, x, m_pad, wname)])
+        else:
+            grads[wname] = _wgrad(dy, x, m_pad, wname)
+            if dgrad is not None:
+                dx_ = K.gemm_nt(dy, dgrad[0], b_t=True, **dgrad[1])
         if bslice is not None:
             K.colsum(dy, bslice)
+        return dx_
 
     emitted: set = set()
     dx_sum = None          # fp32 column sum of dx when the LayerNorm backward that produced dx already took it
@@ -217,25 +244,25 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
         pre = f"{P}encoder.layers.{i}."
         s = saved["layers"][i]
         # ---- MLP: x_out = x_mid + fc2(quick_gelu(fc1(LN2(x_mid))))
-        param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dx, s["act"], D, bias_slice=dx_sum)
-        dh = K.gemm_nt(dx, params[pre + "mlp.fc2.weight"], b_t=True, qgelu_grad_of=s["hpre"], out=dh_buf)
-        param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dh, s["xn2"], I)
-        dxn2 = K.gemm_nt(dh, params[pre + "mlp.fc1.weight"], b_t=True)                       # [M, D]
+        dh = param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dx, s["act"], D, bias_slice=dx_sum,
+                         dgrad=(params[pre + "mlp.fc2.weight"], dict(qgelu_grad_of=s["hpre"], out=dh_buf)))
+        dxn2 = param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dh, s["xn2"], I,
+                           dgrad=(params[pre + "mlp.fc1.weight"], {}))                        # [M, D]
         dg2, dbt2 = f32(D, pre + "layer_norm2.weight"), f32(D, pre + "layer_norm2.bias")
         bo = f32(D, pre + "self_attn.out_proj.bias")              # = column sum of dx_mid, taken by the LN backward itself
         dx_mid = K.layernorm_bwd(dxn2, s["x_mid"], params[pre + "layer_norm2.weight"], s["m2"], s["r2"], dres=dx,
                                  dgamma=dg2, dbeta=dbt2, dxsum=bo, out=dxmid_buf)
         # ---- attention: x_mid = x + out_proj(attn(LN1(x)))
-        param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D, bias_slice=bo)
-        do = K.gemm_nt(dx_mid, params[pre + "self_attn.out_proj.weight"], b_t=True)            # [M, D]
+        do = param_grads(pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", dx_mid, s["o"], D, bias_slice=bo,
+                         dgrad=(params[pre + "self_attn.out_proj.weight"], {}))                # [M, D]
         dqkv = K.vit_attn_bwd(s["qkv"], s["o"], do, s["lse"], B, T, H, scale, out_dqkv=dqkv_buf, out_lo=s["o_lo"])
-        param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D)                   # [3D, D]
+        dxn1 = param_grads(pre + "self_attn.qkv_packed", None, dqkv, s["xn1"], 3 * D,            # [3D, D]
+                           dgrad=(packed["layers"][i]["wqkv"], {}))
         dwqkv = grads.pop(pre + "self_attn.qkv_packed")
         o0 = cursor[0] - 3 * D
         for j, n in enumerate("qkv"):
             grads[pre + f"self_attn.{n}_proj.weight"] = dwqkv[j * D:(j + 1) * D]
             small.append((pre + f"self_attn.{n}_proj.bias", o0 + j * D, D))
-        dxn1 = K.gemm_nt(dqkv, packed["layers"][i]["wqkv"], b_t=True)
         dg1, dbt1 = f32(D, pre + "layer_norm1.weight"), f32(D, pre + "layer_norm1.bias")
         # this dx is the dY of layer i-1's fc2: its column sum is that bias gradient, unless a hidden-state cotangent is
         # still to be added to dx below (then the separate column-sum pass runs on the final dx)

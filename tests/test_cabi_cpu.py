@@ -86,7 +86,7 @@ def test_gemm_problem_struct_matches_header():
     ctype = {"const void*": ctypes.c_void_p, "void*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p, "int64_t": ctypes.c_int64,
              "int32_t": ctypes.c_int32, "float": ctypes.c_float}
     assert [(n, ctype[t]) for n, t in fields] == list(_lib.GemmProblem._fields_)
-    assert ctypes.sizeof(_lib.GemmProblem) == 184          # = static_assert in gemm_bf16_multi.hip
+    assert ctypes.sizeof(_lib.GemmProblem) == 192          # = static_assert in gemm_bf16_multi.hip
     assert int(re.search(r"#define LIBRA_GEMM_MULTI_MAX (\d+)", src).group(1)) == _lib.GEMM_MULTI_MAX
 
 

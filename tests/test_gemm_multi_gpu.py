@@ -204,6 +204,51 @@ def test_multi_k_sliced_problems(K):
         K.gemm_spec(a, b, bias=rnd(N, seed=1), splitk=2)               # only a residual may be fused into a K-sliced problem
 
 
+def test_multi_producer_consumer_inside_one_launch(K):
+    """`reads=`: the second stage of a low-rank pair y = (x A^T) B^T waits, on the device, for the first stage of the SAME launch
+    (LibraLinear, modeling_libra.py:192-199), next to an independent dense GEMM - forward shapes (vision o_proj beside the text
+    o_proj), then the dgrad chain with a weight gradient that reads the produced tensor as its reduction-major operand.
+    Bit-equal to three separate launches; run several times (the wait is a race if it is wrong)."""
+    nv, nl, H, r = 4624, 3000, 1024, 256
+    n = nv + nl
+    g = torch.Generator().manual_seed(9)
+    perm = torch.randperm(n, generator=g)
+    lang, vis = perm[:nl].sort().values.to(torch.int32).cuda(), perm[nl:].sort().values.to(torch.int32).cuda()
+    o, x = rnd(n, H, seed=1, scale=0.5), rnd(n, H, seed=2)
+    wo, wa, wb = rnd(H, H, seed=3, scale=0.03), rnd(r, H, seed=4, scale=0.03), rnd(H, r, seed=5, scale=0.06)
+    ref = torch.zeros((n, H), dtype=BF, device="cuda")
+    t_ref = K.gemm_nt(o, wa, a_rows=vis, tile=K.GEMM_TILE_256)
+    K.gemm_nt(o, wo, out=ref, a_rows=lang, c_rows=lang, resid=x, tile=K.GEMM_TILE_256)
+    K.gemm_nt(t_ref, wb, out=ref, c_rows=vis, resid=x, tile=K.GEMM_TILE_256)
+    for _ in range(5):
+        out = torch.zeros((n, H), dtype=BF, device="cuda")
+        t = torch.zeros((nv, r), dtype=BF, device="cuda")
+        first = K.gemm_spec(o, wa, out=t, a_rows=vis)
+        K.gemm_multi([K.gemm_spec(t, wb, out=out, c_rows=vis, resid=x, reads=first),         # listed first on purpose: the launcher reorders
+                      K.gemm_spec(o, wo, out=out, a_rows=lang, c_rows=lang, resid=x), first])
+        assert torch.equal(t, t_ref) and torch.equal(out, ref)
+    # backward-shaped: dt = dy W_B (bT), then dx = dt W_A (bT) and dW_A = dt^T h both read dt
+    dy = rnd(nv, H, seed=6, scale=0.5)
+    hv = K.alloc_rows(nv, H, "cuda")[:nv]; hv.copy_(rnd(nv, H, seed=7, scale=0.5))
+    full = lambda tt: torch.as_strided(tt, (K.round_up(tt.shape[0], 64), tt.shape[1]), tt.stride(), tt.storage_offset())
+    dt_ref = K.gemm_nt(dy, wb, b_t=True, tile=K.GEMM_TILE_256, out=K.alloc_rows(nv, r, "cuda")[:nv])
+    dx_ref = K.gemm_nt(dt_ref, wa, b_t=True, tile=K.GEMM_TILE_256)
+    dw_ref = K.gemm_nt(full(dt_ref), full(hv), a_t=True, b_t=True, tile=K.GEMM_TILE_256)
+    for _ in range(5):
+        dt = K.alloc_rows(nv, r, "cuda")[:nv]
+        p0 = K.gemm_spec(dy, wb, b_t=True, out=dt)
+        dx, dw, _ = K.gemm_multi([K.gemm_spec(dt, wa, b_t=True, reads=p0), K.gemm_spec(full(dt), full(hv), a_t=True, b_t=True, reads=p0), p0])
+        assert torch.equal(dt, dt_ref) and torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref)
+    assert _ws_zero(K), "queue workspace not clear (word 10 = a device-side wait ran out)"
+    with pytest.raises(ValueError):                                    # the producer must be part of the same launch
+        K.gemm_multi([K.gemm_spec(t, wb, reads=K.gemm_spec(o, wa, a_rows=vis))])
+    with pytest.raises(ValueError):                                    # ... and must not wait for anything itself (one level)
+        a1 = K.gemm_spec(o, wa, out=t, a_rows=vis)
+        a2 = K.gemm_spec(t, wb, reads=a1)
+        K.gemm_multi([a1, a2, K.gemm_spec(a2.out, wa, reads=a2)])
+    assert _ws_zero(K)
+
+
 def test_multi_rejects_bad_problems(K):
     a, b = rnd(256, 64, seed=1), rnd(256, 64, seed=2)
     with pytest.raises(ValueError):

@@ -662,3 +662,81 @@ def test_gemm_tile_order_model_is_a_bijection_with_compact_xcd_patches():
     for x, tiles in rows.items():
         ms, ns = sorted({t[0] for t in tiles}), sorted({t[1] for t in tiles})
         assert len(tiles) == 32 and ms == list(range(4 * (x % 4), 4 * (x % 4) + 4)) and ns == list(range(8 * (x // 4), 8 * (x // 4) + 8))
+
+
+def test_gemm_multi_tile_list_model_covers_every_tile_slice_exactly_once():
+    """gemm_bf16_multi.hip restated in Python (the device code is exercised bit for bit by tests/test_gemm_multi_gpu.py; this pins
+    the INDEX MATH on the CPU): the launcher lays the problems out longest slice first, each starting at a multiple of 8 entries;
+    workgroup b takes entry b, then entries (static_x + c) * 8 + x of queue x = b % 8 for c = 0, 1, ... as its atomic counter hands them
+    out; the owner scan + (slice, tile) split must visit every (problem, K slice, tile) exactly once, for any grid that is a
+    multiple of 8, in any interleaving of the workgroups of one queue."""
+    import random
+
+    def layout(probs, waits=None):           # probs: (tiles_m, tiles_n, K, splitk) -> device records in launch order
+        order = sorted(range(len(probs)), key=lambda i: -(probs[i][2] // max(probs[i][3], 1)))       # (stable, as std::stable_sort)
+        waits = waits or {}
+        j = 0
+        while j < len(order):                # a consumer goes behind its producer (the launcher's rotation)
+            c = order[j]
+            w = waits.get(c, -1)
+            if w >= 0 and order.index(w) > j:
+                pw = order.index(w)
+                order[j:pw + 1] = order[j + 1:pw + 1] + [c]
+                continue
+            j += 1
+        recs, entries = [], 0
+        for i in order:
+            tm, tn, K, sk = probs[i]
+            recs.append(dict(src=i, tile0=entries, ntile=tm * tn, sk=max(sk, 1)))
+            entries += (tm * tn * max(sk, 1) + 7) // 8 * 8
+        return recs, entries
+
+    def owner(t, recs):                      # the kernel's scan: last record whose tile0 <= t
+        g = 0
+        for i in range(1, len(recs)):
+            g = i if t >= recs[i]["tile0"] else g
+        return g
+
+    rng = random.Random(5)
+    cases = [[(46, 49, 4096, 1), (19, 16, 1024, 1), (19, 16, 1024, 1), (19, 16, 1024, 1)],            # text q|k|v + 3 vision expansions
+             [(73, 16, 1024, 1), (4, 16, 18496, 4)],                                                   # ViT dgrad + K-sliced weight gradient
+             [(3, 3, 8192, 1), (3, 3, 1024, 1), (2, 4, 8192, 3), (1, 1, 64, 1)],
+             [(1, 1, 64, 1)]]
+    for probs in cases:
+        recs, entries = layout(probs)
+        assert all(r["tile0"] % 8 == 0 for r in recs) and entries % 8 == 0
+        assert [r["tile0"] for r in recs] == sorted(r["tile0"] for r in recs)
+        for G in (8, 64, 224, 256):
+            G = min(G, entries)
+            seen = {}
+            static = [(G - x + 7) >> 3 for x in range(8)]
+            counters = [0] * 8
+            pending = list(range(G))                                     # every workgroup starts with its static entry
+            rng.shuffle(pending)
+            work = [(b, b) for b in pending]                             # (workgroup, entry)
+            while work:
+                b, t = work.pop(rng.randrange(len(work)))                # any interleaving
+                x = b & 7
+                if t >= entries:
+                    continue                                             # this workgroup leaves
+                c = counters[x]; counters[x] += 1                        # the fetch of the NEXT entry (issued at the top of the tile)
+                g = owner(t, recs)
+                bid = t - recs[g]["tile0"]
+                if bid < recs[g]["ntile"] * recs[g]["sk"]:
+                    ky, bt = divmod(bid, recs[g]["ntile"])
+                    key = (recs[g]["src"], ky, bt)
+                    assert key not in seen, (probs, G, key)
+                    seen[key] = b
+                work.append((b, (static[x] + c) * 8 + x))
+            want = {(i, ky, bt) for i, (tm, tn, K, sk) in enumerate(probs) for ky in range(max(sk, 1)) for bt in range(tm * tn)}
+            assert set(seen) == want, (probs, G, len(seen), len(want))
+    # producer -> consumer edges (wait_on): whatever the K order says, every tile of a consumer sits behind every tile of its producer
+    # in the list - so in each queue the producer's entries are handed out first and a waiting tile never waits for undealt work
+    probs = [(19, 16, 1024, 1), (46, 16, 4096, 1), (19, 4, 4096, 1), (4, 16, 4672, 1)]     # vision B stage | text o | vision A stage | dW of the A stage
+    waits = {0: 2, 3: 2}
+    recs, entries = layout(probs, waits)
+    first = {r["src"]: r["tile0"] for r in recs}
+    last = {r["src"]: r["tile0"] + r["ntile"] * r["sk"] for r in recs}
+    for c, w in waits.items():
+        assert first[c] >= last[w], (c, w, recs)
+    assert [r["src"] for r in recs][:2] == [2, 3] or first[2] < first[3]                        # the long-K weight gradient moved behind its producer
