@@ -114,3 +114,38 @@ def test_error_codes_map_to_the_reference_exception_types():
         _lib.check(ERR_ALIGN, "x")
     with pytest.raises(_lib.LibraHipError):
         _lib.check(-3, "x")
+
+
+def test_gemm_multi_argument_validation(L):
+    """libra_gemm_bf16_multi validates EVERY problem before anything is enqueued (and reads the ctypes records at the offsets
+    the header's struct defines: a field that landed in the wrong place would not produce these verdicts)."""
+    from libra_amd import _lib
+    fake = 0x10000
+
+    def prob(**kw):
+        d = dict(A=fake, lda=128, B=fake, ldb=128, C=fake, ldc=128, M=256, N=128, K=128, bias=None, resid=None, ldr=0, aux=None,
+                 ldaux=0, preact=None, ldpre=0, alpha=1.0, flags=0, alpha_cols=0, a_rows=None, a_phys_rows=256, c_rows=None,
+                 splitk=1, slab=None, wait_on=-1)
+        d.update(kw)
+        return _lib.GemmProblem(**d)
+
+    def call(ps, ws=FAKE):
+        arr = (_lib.GemmProblem * len(ps))(*ps)
+        return L.libra_gemm_bf16_multi(arr, len(ps), ws, None)
+    assert call([prob(M=0), prob(N=0)]) == OK                              # only empty problems: nothing to do, nothing launched
+    assert call([]) == OK
+    assert call([prob()], ws=None) == ERR_ALIGN                            # the queue workspace is mandatory
+    assert call([prob()] * (_lib.GEMM_MULTI_MAX + 1)) == ERR_SHAPE
+    assert call([prob(), prob(K=100)]) == ERR_SHAPE                        # one bad problem refuses the whole launch
+    assert call([prob(lda=64)]) == ERR_SHAPE
+    assert call([prob(A=0x10002)]) == ERR_ALIGN
+    assert call([prob(flags=4)]) == ERR_ALIGN                              # LIBRA_GEMM_RESIDUAL without a residual
+    assert call([prob(flags=32, M=100, lda=128)]) == ERR_SHAPE             # A_T: M % 8
+    assert call([prob(a_rows=fake, flags=32)]) == ERR_SHAPE                # a row gather needs a K-contiguous A
+    assert call([prob(splitk=2)]) == ERR_ALIGN                             # K slices without a slab
+    assert call([prob(splitk=4, slab=fake)]) == ERR_SHAPE                  # more slices than K tiles (K = 128 -> 2)
+    assert call([prob(splitk=2, slab=fake, flags=1, bias=fake)]) == ERR_SHAPE      # only a residual may ride on a K-sliced problem
+    assert call([prob(wait_on=1)]) == ERR_SHAPE                            # the producer must be a problem of this call ...
+    assert call([prob(wait_on=0)]) == ERR_SHAPE                            # ... other than itself ...
+    assert call([prob(), prob(wait_on=0), prob(wait_on=1)]) == ERR_SHAPE   # ... that waits for nothing itself ...
+    assert call([prob(splitk=2, slab=fake), prob(wait_on=0)]) == ERR_SHAPE # ... and is not K-sliced (its C is complete only after the reduction)
