@@ -1151,7 +1151,7 @@ def _layer_backward_multi(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis
         probs.append(WG(dtd, actv, m + "vision_down_proj.weight_A", reads=rd)); post.append(m + "vision_down_proj.weight_A")
     if w(m + "down_proj.weight"):
         probs.append(WG(_compact(dx_out, lang_idx, "dxo_l"), sv["act"], m + "down_proj.weight")); post.append(m + "down_proj.weight")
-    outs = K.gemm_multi(probs + ([p0] if CHAIN else []))
+    outs = K.gemm_multi(([p0] if CHAIN else []) + probs)[1 if CHAIN else 0:]     # (the producer first: its tiles lead the equal-K group)
     dact, dactv = outs[0], outs[1]
     for nm, o in zip(post, outs[2:]):
         g[nm] = o
@@ -1202,7 +1202,7 @@ def _layer_backward_multi(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis
         probs.append(WG(dto, _compact(o, vis_idx, "o_v"), a + "vision_o_proj.weight_A", reads=rd)); post.append(a + "vision_o_proj.weight_A")
     if w(a + "o_proj.weight"):
         probs.append(WG(_compact(dx_mid, lang_idx, "dxm_l"), _compact(o, lang_idx, "o_l"), a + "o_proj.weight")); post.append(a + "o_proj.weight")
-    outs = K.gemm_multi(probs + ([p0] if CHAIN else []))
+    outs = K.gemm_multi(([p0] if CHAIN else []) + probs)[1 if CHAIN else 0:]
     for nm, o_ in zip(post, outs[2:]):
         g[nm] = o_
     qkv, kc, vc, tb = sv["qkv"], sv["kc"], sv["vc"], sv["tb"]
