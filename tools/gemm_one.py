@@ -1,4 +1,5 @@
-"""Time one bf16 GEMM shape: python tools/gemm_one.py M N K [a_t b_t] [iters]   (GEMM_TILE=1|2|3 = 128 / 256 / W tile structure)"""
+"""Time one bf16 GEMM shape: python tools/gemm_one.py M N K [a_t b_t] [iters]   (GEMM_TILE=1|2|3 = 128 / 256 / W tile structure;
+GEMM_ZERO=1: zero-filled operands - the data-dependent power draw of the MFMA datapath is then near its minimum, rule 25 of the guide)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +11,8 @@ it = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 TILE = int(os.environ.get("GEMM_TILE", 0))
 a = torch.randn((Kd, M) if a_t else (M, Kd), device="cuda").to(torch.bfloat16)
 b = torch.randn((Kd, N) if b_t else (N, Kd), device="cuda").to(torch.bfloat16)
+if os.environ.get("GEMM_ZERO") == "1":
+    a.zero_(); b.zero_()
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     K.gemm_nt(a, b, out=out, a_t=a_t, b_t=b_t, tile=TILE)
