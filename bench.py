@@ -344,7 +344,7 @@ def hbm_traffic(workload):
     """Mean HBM bytes per GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/) -> (bytes, file name,
     provenance dict); (None, None, None) if absent.  The PMC passes cannot run inside the timed command (they serialise kernels),
     so the number is read from the newest committed file and marked `stale` when the GEMM sources changed since it was measured."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{workload}.json")
         try:
             with open(path) as f:
@@ -600,9 +600,10 @@ def roofline(w, workload, ips_per_gpu, gflop_step_img, ms_step=None):
     by_kernel["launches_bracketed"] = len(recs)
     if ms_step is not None:
         by_kernel["unbracketed_ms"] = round(ms_step - bracketed, 2)      # (bracket times come from one extra step; ms_step from the timed region)
-    return {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (256x256x64 tiles; + gemm_bf16_nt_w_kernel 256x128 two per CU / "
+    return {"bound": "mfma", "kernel": "gemm_bf16_multi_kernel / gemm_bf16_nt_256_kernel (one 256x256x64 tile body, gemm256_body.hpp: multi-problem "
+                                       "persistent launches and single launches; + gemm_bf16_nt_w_kernel 256x128 two per CU / "
                                        "gemm_bf16_nt_kernel 128x128 for tail rows and small problems, split-K wgrad slabs): every "
-                                       "launch made through libra_gemm_bf16_nt*",
+                                       "launch made through libra_gemm_bf16_nt* / libra_gemm_bf16_multi",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": f"HBM bytes / launch (PMC, profiles/{src})" if src else None, "traffic_provenance": prov,

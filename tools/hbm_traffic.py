@@ -21,7 +21,7 @@ g = {"n": 0, "rd": 0.0, "wr": 0.0, "nw": 0}
 for k, a in tot[:30]:
     n, nw = max(a["n"], 1), max(a["nw"], 1)
     print(f"{k:60s} {a['n']:8d} {a['rd'] / n / 1e6:15.2f} {a['wr'] / nw / 1e6:16.2f}")
-    if "gemm_bf16_nt" in k:
+    if "gemm_bf16_nt" in k or "gemm_bf16_multi" in k:        # (round 6: the multi-problem launches are GEMM launches too)
         for f in g: g[f] += a[f]
 out = {"workload": wl, "gemm_launches": g["n"], "gemm_read_bytes_per_launch": g["rd"] / max(g["n"], 1),
        "gemm_write_bytes_per_launch": g["wr"] / max(g["nw"], 1),
