@@ -164,8 +164,6 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm_bf16_multi_kernel(const 
 
 using namespace libra;
 
-static double tile_us(int64_t K) { return 1.48 * (double)K / 64.0 + 5.3; }    // gemm_bf16.hip cost256, per tile
-
 extern "C" int libra_splitk_reduce_launch_(const float* slab, int S, int64_t M, int64_t N, void* C, int64_t ldc, const int* c_rows,
                                            const void* resid, int64_t ldr, void* stream);
 
@@ -258,7 +256,6 @@ extern "C" int libra_gemm_bf16_multi(const libra_gemm_problem* probs, int64_t np
     for (int j = n; j < MULTI_MAXP; ++j) { a.prob[j] = GemmProb{}; a.prob[j].tile0 = 0x7fffffff; a.prob[j].wait_on = -1; }
     for (int j = 0; j < MULTI_MAXP; ++j) a.tile0[j] = a.prob[j].tile0;
     a.queue = (unsigned*)queue_ws; a.nprob = n; a.nentries = (int)entries;
-    (void)tile_us;
 
     // the smallest compiled superset of the operand layouts that occur
     static const int sets[] = {1, 2, 8, 10, 15};

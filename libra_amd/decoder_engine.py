@@ -374,8 +374,9 @@ MULTI = True
 CHAIN = False
 
 
-def _multi_ok(d: "DecDims", n_l: int, n_v: int) -> bool:
-    return MULTI and not d.addition and n_l > 16 and n_v > 0
+def _multi_ok(d: "DecDims", n_l: int, n_v: int, dev=None) -> bool:
+    # (K.gemm_multi_ok: one-time on-device acceptance check of the launch mechanism, cached per device)
+    return MULTI and not d.addition and n_l > 16 and n_v > 0 and (dev is None or K.gemm_multi_ok(dev))
 
 
 def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, cos, sin, B: int, S: int, sv=None, *,
@@ -400,7 +401,7 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     qkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)       # [q | k | v | bridge low-rank activations t_k t_v 0..]
     qkv, tb = qkvt[:, :3 * H], qkvt[:, 3 * H:]
     t = None
-    multi = _multi_ok(d, n_l, n_v) and slot is None              # (a cached decode step keeps its own, graph-captured schedule)
+    multi = _multi_ok(d, n_l, n_v, dev) and slot is None         # (a cached decode step keeps its own, graph-captured schedule)
     G = K.gemm_spec
     if multi:
         # vision A stage first (the expansions need it); then text q|k|v (+ bridge A) and the three rank-r expansions together
@@ -1287,7 +1288,7 @@ def _layer_backward_multi(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis
 
 
 def layer_backward(sd, pk, i, d: DecDims, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w, positions=None):
-    if _multi_ok(d, lang_idx.numel(), vis_idx.numel()):
+    if _multi_ok(d, lang_idx.numel(), vis_idx.numel(), dx_out.device):
         return _layer_backward_multi(sd, pk, i, d, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, g, w, positions)
     H, I, r, rg = d.hidden, d.inter, d.r, d.rg
     N = B * S

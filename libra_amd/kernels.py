@@ -437,6 +437,61 @@ def gemm_multi(specs: Sequence[GemmSpec]) -> list:
     return [sp.out for sp in specs]
 
 
+_MULTI_CHECKED = {}
+
+
+def gemm_multi_ok(device) -> bool:
+    """One-time, on-device acceptance check of the multi-problem launch on THIS device (cached): four small problems - routed with a
+    residual, reduction-major B, both operands reduction-major, K-sliced - through `gemm_multi` and through their own `gemm_nt`
+    launches must agree bit for bit and the queue workspace must come back zero.  The engines ask before they switch their launch
+    schedule to multi-problem launches (decoder_engine.MULTI / vit_engine.MULTI): the kernel's hand-out of tiles leans on
+    properties of the running system (every workgroup resident, round-robin XCD placement only for speed), and a schedule
+    switch is a pure speed choice - so a device where the check fails keeps the one-launch-per-GEMM schedule, with a warning,
+    instead of training on wrong numbers.  One host synchronisation, at the first call per device; inside a graph capture the
+    answer is the cached one (or True: a capture is always preceded by eager warm-up steps)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _MULTI_CHECKED:
+        return _MULTI_CHECKED[key]
+    if torch.cuda.is_current_stream_capturing():
+        return True
+    g = torch.Generator().manual_seed(1234)
+    rn = lambda *shape: (torch.randn(*shape, generator=g) * 0.5).to(BF16).to(dev)
+    ok = True
+    try:
+        rows = torch.randperm(340, generator=g)[:300].to(torch.int32).to(dev)
+        a0, b0, r0 = rn(340, 192), rn(264, 192), rn(340, 264)
+        a1, b1 = rn(520, 256), rn(256, 136)
+        a2, b2 = rn(128, 256), rn(128, 264)
+        a3, b3 = rn(256, 1024), rn(264, 1024)
+        cases = [dict(a=a0, b=b0, a_rows=rows, c_rows=rows, resid=r0), dict(a=a1, b=b1, b_t=True), dict(a=a2, b=b2, a_t=True, b_t=True),
+                 dict(a=a3, b=b3)]
+        outs_m = [torch.zeros((340, 264), dtype=BF16, device=dev), None, None, None]
+        outs_s = [torch.zeros((340, 264), dtype=BF16, device=dev), None, None, None]
+        specs = []
+        for i, c in enumerate(cases):
+            kw = {k: v for k, v in c.items() if k not in ("a", "b")}
+            specs.append(gemm_spec(c["a"], c["b"], out=outs_m[i], splitk=4 if i == 3 else 1, **kw))
+        res_m = gemm_multi(specs)
+        for i, c in enumerate(cases[:3]):
+            kw = {k: v for k, v in c.items() if k not in ("a", "b")}
+            outs_s[i] = gemm_nt(c["a"], c["b"], out=outs_s[i], **kw)
+        ref3 = a3.float() @ b3.float().t()                          # the K-sliced one against fp32 math (1e-3 + 1 ulp, as the kernel tests)
+        ok = all(torch.equal(res_m[i], outs_s[i]) for i in range(3))
+        err = (res_m[3].float() - ref3).abs()
+        ok = ok and bool((err <= 1e-3 * ref3.abs().max() + 2.0 ** -8 * ref3.abs()).all())
+        ok = ok and int(_multi_ws(dev).abs().sum()) == 0
+    except Exception as e:                                           # a launch error is a failed check too
+        warnings.warn(f"libra_amd: gemm_multi self-check raised {e!r}", RuntimeWarning)
+        ok = False
+    if not ok:
+        _multi_ws(dev).zero_()
+        warnings.warn("libra_amd: the multi-problem GEMM launch FAILED its on-device self-check on this device; the engines keep the "
+                      "one-launch-per-GEMM schedule (slower, same results). Please report this.", RuntimeWarning)
+    _MULTI_CHECKED[key] = ok
+    return ok
+
+
 def _tag_counts(tags):
     out, seen = [], {}
     for t in tags:

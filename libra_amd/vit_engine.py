@@ -228,7 +228,7 @@ def backward(params, packed, saved, dhs: Sequence[Optional[torch.Tensor]], dims:
         # (Weight gradients used to run on a second stream; once the kernels were tuned that overlap measured as no gain -
         # 56.6 vs 56.5 ms/step - so the whole backward is one stream and per-launch timings mean what they say.)
         dx_ = None
-        if MULTI and dgrad is not None:
+        if MULTI and dgrad is not None and K.gemm_multi_ok(dy.device):
             dx_, grads[wname] = K.gemm_multi([K.gemm_spec(dy, dgrad[0], b_t=True, **dgrad[1]), _wgrad_spec(dy, x, m_pad, wname)])
         else:
             grads[wname] = _wgrad(dy, x, m_pad, wname)

@@ -178,6 +178,7 @@ def _fake_kernels(real_K, log):
             res.append(None if g is None else (g.t() if transpose_out else g).contiguous().to(BF))
         return tuple(res)
     F.f32_to_bf16 = lambda t: t.to(BF)
+    F.gemm_multi_ok = lambda dev: True
     for k, v in dict(gemm_nt=gemm_nt, gemm_nt_grouped=gemm_nt_grouped, gemm_spec=gemm_spec, gemm_multi=gemm_multi,
                      rmsnorm_routed=rmsnorm_routed, rmsnorm_routed_bwd=rmsnorm_routed_bwd, rmsnorm_routed_wgrad=rmsnorm_routed_wgrad,
                      rope_bridge=rope_bridge, bridge_attn_fwd=bridge_attn_fwd, bridge_attn_bwd=bridge_attn_bwd,

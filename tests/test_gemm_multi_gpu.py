@@ -249,6 +249,13 @@ def test_multi_producer_consumer_inside_one_launch(K):
     assert _ws_zero(K)
 
 
+def test_multi_on_device_self_check_passes(K):
+    """The one-time acceptance check the engines run before they switch to multi-problem launches (kernels.gemm_multi_ok)."""
+    K._MULTI_CHECKED.clear()
+    assert K.gemm_multi_ok("cuda") is True
+    assert K._MULTI_CHECKED == {torch.cuda.current_device(): True} and _ws_zero(K)
+
+
 def test_multi_rejects_bad_problems(K):
     a, b = rnd(256, 64, seed=1), rnd(256, 64, seed=2)
     with pytest.raises(ValueError):
