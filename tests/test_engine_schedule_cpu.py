@@ -245,3 +245,139 @@ def test_multi_problem_schedules_equal_the_one_launch_per_gemm_schedule(monkeypa
             assert torch.equal(got[3][n], ref[3][n]), f"{mode}: saved activation {n} differs"
     n_grads = len(ref[2])
     assert n_grads >= (33 if full_finetune else 24), n_grads
+
+
+def _fake_vit_kernels(real_K, log):
+    """Stand-ins for what vit_engine.forward / backward touch (same rules as above: GEMMs real, the rest arbitrary but deterministic)."""
+    F = _fake_kernels(real_K, log)
+    base_gemm = F.gemm_nt
+
+    def gemm_full(a, b, *, quick_gelu=False, qgelu_grad_of=None, preact_out=None, **kw):
+        out = kw.pop("out", None)
+        y = _gemm(a, b, **kw)
+        if preact_out is not None:
+            preact_out.copy_(y)
+        if quick_gelu:
+            y = (y.float() * torch.sigmoid(1.702 * y.float())).to(BF)
+        if qgelu_grad_of is not None:
+            s_ = torch.sigmoid(1.702 * qgelu_grad_of.float())
+            y = (y.float() * s_ * (1 + 1.702 * qgelu_grad_of.float() * (1 - s_))).to(BF)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def gemm_nt(a, b, **kw):
+        log.append(("gemm", 1))
+        return gemm_full(a, b, **kw)
+
+    def gemm_multi(specs):
+        specs = list(specs)
+        log.append(("multi", len(specs)))
+        ins = [(sp.a.clone(), sp.b.clone()) for sp in specs]          # every problem reads its operands as they were before the launch
+        for sp, (a, b) in reversed(list(zip(specs, ins))):
+            gemm_full(a, b, **sp.kw)
+        return [sp.out for sp in specs]
+    del base_gemm
+    F.gemm_nt, F.gemm_multi = gemm_nt, gemm_multi
+
+    def patch_im2col(pixel, P, Kpad):
+        B, C, H, W = pixel.shape
+        cols = pixel.unfold(2, P, P).unfold(3, P, P).permute(0, 2, 3, 1, 4, 5).reshape(B * (H // P) * (W // P), C * P * P)
+        buf = real_K.alloc_rows(cols.shape[0], Kpad, pixel.device)
+        buf[:cols.shape[0]].zero_()
+        buf[:cols.shape[0], :cols.shape[1]] = cols
+        return buf[:cols.shape[0]]
+
+    def vit_embed_ln(patches, cls, pos, gamma, beta, B, T, eps, *, save=True):
+        D = patches.shape[1]
+        emb = torch.cat([cls.float().expand(B, 1, D), patches.float().view(B, T - 1, D)], 1) + pos.float()[None, :T]
+        emb = emb.reshape(B * T, D)
+        mean, var = emb.mean(-1), emb.var(-1, unbiased=False)
+        rstd = torch.rsqrt(var + eps)
+        hs0 = ((emb - mean[:, None]) * rstd[:, None] * gamma.float() + beta.float()).to(BF)
+        return emb.to(BF), hs0, mean, rstd
+
+    def layernorm_fwd(x, gamma, beta, eps, *, save_stats=True, out=None):
+        xf = x.float()
+        mean, rstd = xf.mean(-1), torch.rsqrt(xf.var(-1, unbiased=False) + eps)
+        y = ((xf - mean[:, None]) * rstd[:, None] * gamma.float() + beta.float()).to(BF)
+        if out is not None:
+            out.copy_(y); y = out
+        return y, (mean if save_stats else None), (rstd if save_stats else None)
+
+    def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dgamma=None, dbeta=None, dxsum=None, out=None):
+        xh = (x.float() - mean[:, None]) * rstd[:, None]
+        dx = dy.float() * gamma.float() * rstd[:, None] - 0.01 * xh
+        if dres is not None:
+            dx = dx + dres.float()
+        if dgamma is not None:
+            dgamma += (dy.float() * xh).sum(0)
+        if dbeta is not None:
+            dbeta += dy.float().sum(0)
+        dx = dx.to(BF)
+        if dxsum is not None:
+            dxsum += dx.float().sum(0)
+        if out is not None:
+            out.copy_(dx); dx = out
+        return dx
+
+    def vit_attn_fwd(qkv, B, T, H, scale, *, need_lse=True, out=None, out_lo=None):
+        D = qkv.shape[1] // 3
+        o = ((qkv[:, :D].float() + 0.5 * qkv[:, D:2 * D].float() + 0.25 * qkv[:, 2 * D:].float()) * scale).to(BF)
+        if out is not None:
+            out.copy_(o); o = out
+        if out_lo is not None:
+            out_lo.zero_()
+        return o, torch.zeros(B * H * T)
+
+    def vit_attn_bwd(qkv, o, do, lse, B, T, H, scale, *, out_dqkv=None, out_lo=None):
+        D = o.shape[1]
+        d = torch.cat([do.float() * scale, do.float() * 0.5 * scale + 0.01 * qkv[:, D:2 * D].float(), do.float() * 0.25 * scale], 1).to(BF)
+        if out_dqkv is not None:
+            out_dqkv.copy_(d); d = out_dqkv
+        return d
+
+    def colsum(x, out):
+        out += x.float().sum(0)
+        return out
+
+    def add_(a, b):
+        a.copy_((a.float() + b.float()).to(BF))
+        return a
+
+    def patch_col2im(dcols, B, C, H, W, P):
+        return dcols[:, :C * P * P].reshape(B, H // P, W // P, C, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W).contiguous()
+    for k, v in dict(patch_im2col=patch_im2col, vit_embed_ln=vit_embed_ln, layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd,
+                     vit_attn_fwd=vit_attn_fwd, vit_attn_bwd=vit_attn_bwd, colsum=colsum, add_=add_, patch_col2im=patch_col2im).items():
+        setattr(F, k, v)
+    return F
+
+
+def test_vit_backward_multi_schedule_equals_the_one_launch_per_gemm_schedule(monkeypatch):
+    """vit_engine.MULTI pairs each dgrad with the (K-sliced) weight gradient that reads the same dY: every gradient and the pixel
+    gradient must equal the separate-launch schedule's through the same stand-in kernels."""
+    from libra_amd import kernels as real_K, vit_engine as VE
+    from oracle import vit_oracle as VO
+    dims = VE.VitDims(hidden=128, inter=256, layers=3, heads=2, patch=14, image=56)
+    sd = {k: v.to(BF) for k, v in VO.random_vit_state_dict(hidden=128, inter=256, layers=3, patch=14, image=56).items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 56, 56, generator=g).to(BF)
+    T = dims.tokens
+    res = {}
+    for mode in (False, True):
+        log = []
+        monkeypatch.setattr(VE, "K", _fake_vit_kernels(real_K, log))
+        monkeypatch.setattr(VE, "MULTI", mode)
+        packed = VE.pack_forward(sd, dims)
+        hs, saved = VE.forward(sd, packed, x, dims, save=True)
+        dhs = [None] * len(hs)
+        dhs[-2] = (torch.randn(2 * T, 128, generator=torch.Generator().manual_seed(5)) * 0.1).to(BF)
+        dhs[-3] = (torch.randn(2 * T, 128, generator=torch.Generator().manual_seed(6)) * 0.1).to(BF)
+        dpix, grads = VE.backward(sd, packed, saved, dhs, dims)
+        res[mode] = (dpix, grads, log)
+    assert sum(1 for k, _ in res[True][2] if k == "multi") == 4 * 2 and not any(k == "multi" for k, _ in res[False][2])
+    assert torch.equal(res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) >= 16 * 2
+    for n in res[False][1]:
+        assert torch.equal(res[True][1][n], res[False][1][n]), n
