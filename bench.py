@@ -693,6 +693,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ViT leg, optimizer leg) at N=1")
     ap.add_argument("--no-multi", action="store_true",
                     help="A/B switch: the round-5 launch schedule (one launch per GEMM) instead of the multi-problem launches")
+    ap.add_argument("--graph", action="store_true", help="--workload vit only: time the step as one replayed hipGraph")
     ap.add_argument("--chain", action="store_true",
                     help="A/B switch: fold the first low-rank stage of each vision pair into the multi-problem launch of its second "
                          "stage (device-side producer -> consumer wait; decoder_engine.CHAIN)")
@@ -812,7 +813,15 @@ def main():
             extra["exchange_probe_failed"] = failed
         note(f"exchange probe {extra['exchange_probe_ms_per_step']} -> {mode}" + (f" (failed: {failed})" if failed else ""))
 
-    dt = timed(w, args.steps, args.warmup, world, device)
+    w_timed = w
+    if args.graph:
+        if args.workload != "vit" or world > 1:
+            raise SystemExit("--graph: only the single-GPU ViT step has no host read inside (the headline step reads the placeholder plan)")
+        w_timed, why = capture_step(w)
+        if w_timed is None:
+            raise SystemExit(f"--graph: capture failed: {why}")
+        extra["launch"] = "one hipGraph per step (replay)"
+    dt = timed(w_timed, args.steps, args.warmup, world, device)
     ms = dt / args.steps * 1e3
     ips = args.batch * args.accum * world * args.steps / dt
     note(f"timed {args.steps} steps: {ms:.2f} ms/step, {ips:.2f} images/s")
@@ -870,6 +879,11 @@ def main():
                       "gemm_schedule": "one launch per GEMM (--no-multi)" if args.no_multi else
                                        "multi-problem launches (libra_gemm_bf16_multi)" + (" + chained low-rank stages" if args.chain else "")},
            "roofline": roof}
+    try:                                                 # which launch schedule actually ran (the engines ask the device once, K.gemm_multi_ok)
+        from libra_amd import kernels as _K
+        out["config"]["gemm_multi_selfcheck"] = _K._MULTI_CHECKED.get(device.index if device.index is not None else 0)
+    except Exception:
+        pass
     if check is not None:
         out["step_check"] = check         # loss + gradient norm of exactly the timed step (tests/test_configs_gpu.py::test_headline_step_full_size_loss_and_recompute_identity bounds them)
 
