@@ -55,3 +55,11 @@ for name, probs, launches in fwd + bwd:
     print(f"{name:48s} one-per-GEMM {s:8.1f} us   multi {m:8.1f} us   (perfectly packed {ideal:8.1f})   {m - s:+7.1f}")
 print(f"{'per layer':48s} one-per-GEMM {tot_s:8.1f} us   multi {tot_m:8.1f} us   (perfectly packed {tot_i:8.1f})   {tot_m - tot_s:+7.1f} us "
       f"= {(tot_m - tot_s) * 32 / 1e3:+.1f} ms per 32-layer step")
+
+# decoder_engine.CHAIN: the first low-rank stage joins the launch of its second stage (its tiles lead the list; the wait is free
+# in this model because consumers sit at the end of the list)
+chain = [("a + F2", fwd[0][1] + fwd[1][1]), ("c + F4", fwd[2][1] + fwd[3][1]), ("e + F6", fwd[4][1] + fwd[5][1]), ("g + F8", fwd[6][1] + fwd[7][1]),
+         ("dtd + B1", bwd[0][1] + bwd[1][1]), ("B2", bwd[2][1]), ("B3", bwd[3][1]), ("dto + B4", bwd[4][1] + bwd[5][1]), ("B5", bwd[6][1]), ("B6", bwd[7][1])]
+tot_c = sum(multi(p)[0] for _, p in chain)
+print(f"{'per layer, chained first stages':48s} multi+chain {tot_c:8.1f} us   {tot_c - tot_s:+7.1f} us vs one-per-GEMM = {(tot_c - tot_s) * 32 / 1e3:+.1f} ms per step "
+      f"({(tot_c - tot_m) * 32 / 1e3:+.1f} ms vs multi)")
