@@ -401,7 +401,7 @@ def layer_forward(sd, pk, i: int, d: DecDims, x, flag, lang_idx, vis_idx, lens, 
     qkvt = torch.empty((N, 3 * H + 64), dtype=BF16, device=dev)       # [q | k | v | bridge low-rank activations t_k t_v 0..]
     qkv, tb = qkvt[:, :3 * H], qkvt[:, 3 * H:]
     t = None
-    multi = _multi_ok(d, n_l, n_v, dev) and slot is None         # (a cached decode step keeps its own, graph-captured schedule)
+    multi = slot is None and _multi_ok(d, n_l, n_v, dev)         # (a cached decode step keeps its own, graph-captured schedule)
     G = K.gemm_spec
     if multi:
         # vision A stage first (the expansions need it); then text q|k|v (+ bridge A) and the three rank-r expansions together
