@@ -461,7 +461,7 @@ def gemm_multi_ok(device) -> bool:
     try:
         rows = torch.randperm(340, generator=g)[:300].to(torch.int32).to(dev)
         a0, b0, r0 = rn(340, 192), rn(264, 192), rn(340, 264)
-        a1, b1 = rn(520, 256), rn(256, 136)
+        a1, b1 = rn(520, 256), rn(256, 264)
         a2, b2 = rn(128, 256), rn(128, 264)
         a3, b3 = rn(256, 1024), rn(264, 1024)
         cases = [dict(a=a0, b=b0, a_rows=rows, c_rows=rows, resid=r0), dict(a=a1, b=b1, b_t=True), dict(a=a2, b=b2, a_t=True, b_t=True),
@@ -475,7 +475,7 @@ def gemm_multi_ok(device) -> bool:
         res_m = gemm_multi(specs)
         for i, c in enumerate(cases[:3]):
             kw = {k: v for k, v in c.items() if k not in ("a", "b")}
-            outs_s[i] = gemm_nt(c["a"], c["b"], out=outs_s[i], **kw)
+            outs_s[i] = gemm_nt(c["a"], c["b"], out=outs_s[i], tile=GEMM_TILE_256, **kw)      # (every case is >= 256 x 256: the same tile body)
         ref3 = a3.float() @ b3.float().t()                          # the K-sliced one against fp32 math (1e-3 + 1 ulp, as the kernel tests)
         ok = all(torch.equal(res_m[i], outs_s[i]) for i in range(3))
         err = (res_m[3].float() - ref3).abs()
