@@ -126,8 +126,8 @@ def test_multi_disjoint_row_scatter_into_one_tensor(K):
     K.gemm_multi([K.gemm_spec(h, w, out=out, a_rows=lang, c_rows=lang, resid=x),
                   K.gemm_spec(t, wb, out=out, c_rows=vis, resid=x)])
     ref = torch.zeros((n, H), dtype=BF, device="cuda")
-    K.gemm_nt(h, w, out=ref, a_rows=lang, c_rows=lang, resid=x)
-    K.gemm_nt(t, wb, out=ref, c_rows=vis, resid=x)
+    K.gemm_nt(h, w, out=ref, a_rows=lang, c_rows=lang, resid=x, tile=K.GEMM_TILE_256)
+    K.gemm_nt(t, wb, out=ref, c_rows=vis, resid=x, tile=K.GEMM_TILE_256)
     assert torch.equal(out, ref)
     close(out[lang.long()], h[lang.long()].float() @ w.float().t() + x[lang.long()].float(), what="text rows")
     close(out[vis.long()], t.float() @ wb.float().t() + x[vis.long()].float(), what="vision rows")
@@ -155,7 +155,7 @@ def test_multi_decoder_stage_shapes_full_size(K):
             K.gemm_multi([K.gemm_spec(p.pop("a"), p.pop("b"), **p) for p in probs])
         else:
             for p in probs:
-                K.gemm_nt(p.pop("a"), p.pop("b"), **p)
+                K.gemm_nt(p.pop("a"), p.pop("b"), tile=K.GEMM_TILE_256, **p)
         outs.append(qkv)
     assert torch.equal(outs[0], outs[1])
     # dgrad (bT) + weight gradient (aT bT) in one launch
