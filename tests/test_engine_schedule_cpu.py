@@ -214,7 +214,7 @@ def _run_layer(DE, sd, d, mode, monkeypatch, full_finetune):
     want = (lambda n: True) if full_finetune else (lambda n: "vision" in n)
     dx = DE.layer_backward(sd, pk, 0, d, sv, dx_out, flag, lang_idx, vis_idx, lens, cos, sin, B, S, grads, want)
     acts = {k: v.clone() for k, v in sv.items() if isinstance(v, torch.Tensor)}
-    return x_out, dx, {k: v.clone() for k, v in grads.items() if v is not None}, acts, log
+    return x_out, dx, {k: v.clone() for k, v in grads.items() if v is not None}, acts, log, grads
 
 
 @pytest.mark.parametrize("full_finetune", [False, True])
@@ -245,6 +245,41 @@ def test_multi_problem_schedules_equal_the_one_launch_per_gemm_schedule(monkeypa
             assert torch.equal(got[3][n], ref[3][n]), f"{mode}: saved activation {n} differs"
     n_grads = len(ref[2])
     assert n_grads >= (33 if full_finetune else 24), n_grads
+
+
+def test_multi_schedule_under_a_capturing_gradient_store_writes_every_slot_directly(monkeypatch):
+    """Data parallel: while a `dp.GradBuckets` captures, the weight-gradient problems of the multi schedule take the bucket slots
+    as their outputs - including the packed [gate_A; up_A] and [q_A; k_A; v_A | bridge] gradients, which go out as one problem
+    per parameter instead of being re-packed by a copy.  The bucket contents must equal the gradients of the plain run, and every
+    vision weight matrix must have been written in place (the view handed to the store IS the slot)."""
+    from libra_amd import decoder_engine as DE, dp
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    sd = {k: torch.nn.Parameter(v.to(BF), requires_grad="vision" in k) for k, v in sub_params(t, "w.").items()}
+    d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
+                   heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
+                   codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
+                   signal=c["contiguous_signal_size"], rank=c["bridge_rank"], down_ratio=c["vision_down_ratio"])
+    sdd = {k: v.detach() for k, v in sd.items()}
+    ref = _run_layer(DE, sdd, d, "multi", monkeypatch, False)
+    named = [(n, p) for n, p in sd.items() if p.requires_grad and n.startswith("model.layers.0.")]
+    st = dp.GradBuckets(named, bucket_bytes=1 << 14)
+    captured = {}
+    real_add = st.add
+
+    def spy(grads):
+        for n, g in grads.items():
+            if g is not None and n in st.where:
+                captured[n] = g.data_ptr() == st.view(n).data_ptr()
+        return real_add(grads)
+    monkeypatch.setattr(st, "add", spy)
+    with st.capture():
+        got = _run_layer(DE, sdd, d, "multi", monkeypatch, False)
+        dp.emit(got[5])                                              # the engine's own tensors (bucket views where it wrote in place)
+    for n, _ in named:
+        assert torch.equal(st.view(n), ref[2][n]), n
+    mats = [n for n, p in named if p.ndim == 2 and "bridge" not in n]
+    assert mats and all(captured[n] for n in mats), [n for n in mats if not captured[n]]
 
 
 def _fake_vit_kernels(real_K, log):
