@@ -913,22 +913,27 @@ def main():
             ids_eager = wv.step().clone()
             chk = grads_check(wv.named)                  # the eager step's gradients: checksum + finiteness
             chk["ids_checksum"] = int(ids_eager.sum())
-            leg = {"workload": names["vit"].replace(f"bs={args.batch}", "bs=32")}
+            leg = {"workload": names["vit"].replace(f"bs={args.batch}", "bs=32"), "images_per_s": round(ips_eager, 2),
+                   "ms_per_step": round(dtv / 20 * 1e3, 3), "launch": "eager", "step_check": chk,
+                   "roofline": roofline(wv, "vit", ips_eager, gflop_per_image("vit"))}
+            extra["vit_leg"] = leg                       # (the eager result stands whatever happens to the capture below)
             # the same step as one hipGraph: ~1000 launches per 49 ms are close to the host's launch rate in eager mode, which made the
             # eager number swing by 20 % between runs - the replayed graph measures the GPU
-            wg, why = capture_step(wv)
-            if wg is not None:
-                dtg = timed(wg, 20, 3, 1, device)
-                ipsv = 32 * 20 / dtg
-                chk_g = grads_check(wv.named)
-                chk["graph_replay_equals_eager"] = bool(chk_g["grad_norm"] == chk["grad_norm"] and torch.equal(wg.out, ids_eager))
-                leg.update(images_per_s=round(ipsv, 2), ms_per_step=round(dtg / 20 * 1e3, 3), launch="one hipGraph per step (replay)",
-                           eager_images_per_s=round(ips_eager, 2), eager_ms_per_step=round(dtv / 20 * 1e3, 3))
-            else:
-                ipsv = ips_eager
-                leg.update(images_per_s=round(ips_eager, 2), ms_per_step=round(dtv / 20 * 1e3, 3), launch="eager", graph_capture_failed=why)
-            leg["step_check"] = chk
-            leg["roofline"] = roofline(wv, "vit", ipsv, gflop_per_image("vit"))
+            ipsv = ips_eager
+            try:
+                wg, why = capture_step(wv)
+                if wg is not None:
+                    dtg = timed(wg, 20, 3, 1, device)
+                    ipsv = 32 * 20 / dtg
+                    chk_g = grads_check(wv.named)
+                    chk["graph_replay_equals_eager"] = bool(chk_g["grad_norm"] == chk["grad_norm"] and torch.equal(wg.out, ids_eager))
+                    leg.update(images_per_s=round(ipsv, 2), ms_per_step=round(dtg / 20 * 1e3, 3), launch="one hipGraph per step (replay)",
+                               eager_images_per_s=round(ips_eager, 2), eager_ms_per_step=round(dtv / 20 * 1e3, 3))
+                    leg["roofline"]["whole_step_frac"] = round(ipsv * gflop_per_image("vit") / 1e3 / PEAK_BF16_TFLOPS, 4)
+                else:
+                    leg["graph_capture_failed"] = why
+            except Exception as e:
+                leg["graph_capture_failed"] = repr(e)[:200]
             extra["vit_leg"] = leg
             note(f"vit leg: {ipsv:.1f} images/s ({leg['launch']}; eager {ips_eager:.1f}); check {chk}")
             del wv
