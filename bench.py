@@ -537,6 +537,27 @@ def capture_step(w):
     return g, None
 
 
+def vit_graph_leg(batch=32, steps=20, warmup=3):
+    """Child-process entry (`bench.py --vit-graph-leg`): the configs[1] step captured as ONE hipGraph and replayed - in a process of its
+    own because a capture that goes wrong can take the HIP context with it, and the parent still has the headline line to print.
+    Prints one JSON object: replay throughput, the eager step's gradient checksum and whether the replay reproduces it."""
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    wv = make_vit(device, batch, 1, "allreduce")
+    for _ in range(2):
+        ids_eager = wv.step().clone()
+    chk = grads_check(wv.named)
+    wg, why = capture_step(wv)
+    if wg is None:
+        print(json.dumps({"graph_capture_failed": why}), flush=True)
+        return
+    dtg = timed(wg, steps, warmup, 1, device)
+    chk_g = grads_check(wv.named)
+    print(json.dumps({"images_per_s": round(batch * steps / dtg, 2), "ms_per_step": round(dtg / steps * 1e3, 3),
+                      "graph_replay_equals_eager": bool(chk_g["grad_norm"] == chk["grad_norm"] and torch.equal(wg.out, ids_eager)),
+                      "grad_norm": chk_g["grad_norm"]}), flush=True)
+
+
 def grads_check(named):
     """L2 norm of every gradient of `named` (libra_sumsq_bf16: deterministic - a checksum between runs / schedules) and finiteness."""
     from libra_amd import kernels as K
@@ -689,6 +710,7 @@ def main():
     ap.add_argument("--fallback-from", default=None, help=argparse.SUPPRESS)   # set by the watchdog's re-exec: what hung
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)         # child-process entry of cpu_baseline()
+    ap.add_argument("--vit-graph-leg", action="store_true", help=argparse.SUPPRESS)   # child-process entry of the ViT leg's hipGraph replay
     ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ViT leg, optimizer leg) at N=1")
     ap.add_argument("--no-multi", action="store_true",
@@ -710,6 +732,12 @@ def main():
         args.workload = "bridge"
     if args.cpu_leg:
         cpu_leg(args.cpu_leg, args.seq, args.cpu_threads)
+        return
+    if args.vit_graph_leg:
+        if args.no_multi:
+            from libra_amd import vit_engine as _VE
+            _VE.MULTI = False
+        vit_graph_leg()
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -920,24 +948,29 @@ def main():
             # the same step as one hipGraph: ~1000 launches per 49 ms are close to the host's launch rate in eager mode, which made the
             # eager number swing by 20 % between runs - the replayed graph measures the GPU
             ipsv = ips_eager
+            del wv
+            torch.cuda.empty_cache()
             try:
-                wg, why = capture_step(wv)
-                if wg is not None:
-                    dtg = timed(wg, 20, 3, 1, device)
-                    ipsv = 32 * 20 / dtg
-                    chk_g = grads_check(wv.named)
-                    chk["graph_replay_equals_eager"] = bool(chk_g["grad_norm"] == chk["grad_norm"] and torch.equal(wg.out, ids_eager))
-                    leg.update(images_per_s=round(ipsv, 2), ms_per_step=round(dtg / 20 * 1e3, 3), launch="one hipGraph per step (replay)",
-                               eager_images_per_s=round(ips_eager, 2), eager_ms_per_step=round(dtv / 20 * 1e3, 3))
-                    leg["roofline"]["whole_step_frac"] = round(ipsv * gflop_per_image("vit") / 1e3 / PEAK_BF16_TFLOPS, 4)
+                import subprocess
+                cmd = [sys.executable, os.path.abspath(__file__), "--vit-graph-leg"] + (["--no-multi"] if args.no_multi else [])
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    leg["graph_capture_failed"] = f"child rc={r.returncode}: {r.stderr[-200:]}"
                 else:
-                    leg["graph_capture_failed"] = why
+                    gl = json.loads(lines[-1])
+                    if "images_per_s" in gl:
+                        ipsv = gl["images_per_s"]
+                        chk["graph_replay_equals_eager"] = gl["graph_replay_equals_eager"]
+                        leg.update(images_per_s=ipsv, ms_per_step=gl["ms_per_step"], launch="one hipGraph per step (replay, child process)",
+                                   eager_images_per_s=round(ips_eager, 2), eager_ms_per_step=round(dtv / 20 * 1e3, 3))
+                        leg["roofline"]["whole_step_frac"] = round(ipsv * gflop_per_image("vit") / 1e3 / PEAK_BF16_TFLOPS, 4)
+                    else:
+                        leg.update(gl)
             except Exception as e:
                 leg["graph_capture_failed"] = repr(e)[:200]
             extra["vit_leg"] = leg
             note(f"vit leg: {ipsv:.1f} images/s ({leg['launch']}; eager {ips_eager:.1f}); check {chk}")
-            del wv
-            torch.cuda.empty_cache()
         except Exception as e:
             extra["vit_leg"] = {"error": repr(e)[:200]}
     if cu is not None:                                   # leave the CU-masked stream: restore the persistent-grid budget, destroy the stream
