@@ -17,7 +17,7 @@
 //     issued before the tile's prologue loads and read after its epilogue: no fetch latency on the critical path.  (The atomic
 //     is the oldest VMEM operation of the tile, so the prologue's own counted wait covers it: it is issued from inline asm like
 //     the LDS-DMA, DESIGN rule 1, and the compiler's waitcnt pass never sees it.)
-//   * the queue words live in a 64-byte caller-owned workspace that is all zero between launches: the last workgroup to leave
+//   * the queue words live in a 128-byte caller-owned workspace that is all zero between launches: the last workgroup to leave
 //     clears it (no memset node per launch, no library-owned global state).  One workspace per stream.
 //   * a problem may READ the output of one other problem of the same launch (wait_on): its tiles are listed after the producer's,
 //     the producer's tiles count themselves done behind an agent-scope release, and a consumer tile that comes up early waits for

@@ -396,7 +396,7 @@ def _multi_ws(device) -> torch.Tensor:
     dev = torch.device(device)
     if torch.cuda.is_current_stream_capturing():
         # inside a hipGraph capture the launch belongs to the GRAPH, which may be replayed on any stream next to other graphs: it gets
-        # a workspace of its own from the graph's private pool (a 64-byte fill node per launch; nothing cached outside the graph)
+        # a workspace of its own from the graph's private pool (a 128-byte fill node per launch; nothing cached outside the graph)
         return torch.zeros(32, dtype=torch.int32, device=dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
     ws = _MULTI_WS.get(key)

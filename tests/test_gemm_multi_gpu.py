@@ -2,7 +2,7 @@
 
 The contract is "each problem computes what its own libra_gemm_bf16_nt_routed call would, bit for bit" - so the gate is
 `torch.equal` against the single-problem launches (whose own parity against fp32 math is tests/test_kernels_gpu.py), plus the
-1e-3 + 1 ulp bound against fp32 math directly, plus the properties of the tile queue: the 64-byte workspace is all zero again
+1e-3 + 1 ulp bound against fp32 math directly, plus the properties of the tile queue: the 128-byte workspace is all zero again
 after every launch, results do not change from launch to launch, and a launch with fewer tiles than compute units works."""
 import pytest
 import torch
