@@ -247,6 +247,28 @@ def test_multi_problem_schedules_equal_the_one_launch_per_gemm_schedule(monkeypa
     assert n_grads >= (33 if full_finetune else 24), n_grads
 
 
+def test_a_device_that_fails_the_self_check_keeps_the_one_launch_per_gemm_schedule(monkeypatch):
+    """kernels.gemm_multi_ok is the engines' gate: False (the on-device acceptance check of the multi-problem launch failed) must leave
+    MULTI = True engines on the old schedule - no multi launch is ever issued."""
+    from libra_amd import decoder_engine as DE, kernels as real_K
+    t, meta = load_golden("libra_tiny.safetensors")
+    c = meta["cfg"]
+    sd = {k: v.to(BF) for k, v in sub_params(t, "w.").items()}
+    d = DE.DecDims(hidden=c["hidden_size"], inter=c["intermediate_size"], layers=c["num_hidden_layers"],
+                   heads=c["num_attention_heads"], vocab=c["vocab_size"], vision_vocab=c["vision_vocab_size"],
+                   codebooks=c["vision_codebook_num"], max_vision_len=c["max_vision_token_length"],
+                   signal=c["contiguous_signal_size"], rank=c["bridge_rank"], down_ratio=c["vision_down_ratio"])
+    orig = _fake_kernels
+
+    def failing(real, log):
+        F = orig(real, log)
+        F.gemm_multi_ok = lambda dev: False
+        return F
+    monkeypatch.setitem(globals(), "_fake_kernels", failing)
+    got = _run_layer(DE, sd, d, "multi", monkeypatch, False)
+    assert not any(k == "multi" for k, _ in got[4]) and any(k == "grouped" for k, _ in got[4])
+
+
 def test_multi_schedule_under_a_capturing_gradient_store_writes_every_slot_directly(monkeypatch):
     """Data parallel: while a `dp.GradBuckets` captures, the weight-gradient problems of the multi schedule take the bucket slots
     as their outputs - including the packed [gate_A; up_A] and [q_A; k_A; v_A | bridge] gradients, which go out as one problem
