@@ -440,54 +440,98 @@ def gemm_multi(specs: Sequence[GemmSpec]) -> list:
 _MULTI_CHECKED = {}
 
 
+def _multi_selfcheck_inline(device) -> bool:
+    """The acceptance check itself, in THIS process: four small problems - routed with a residual, reduction-major B, both operands
+    reduction-major, K-sliced - through `gemm_multi` and through single launches of the same tile body must agree bit for bit
+    (the K-sliced one: within the kernel tolerance of fp32 math) and the queue workspace must come back zero."""
+    dev = torch.device(device)
+    g = torch.Generator().manual_seed(1234)
+    rn = lambda *shape: (torch.randn(*shape, generator=g) * 0.5).to(BF16).to(dev)
+    rows = torch.randperm(340, generator=g)[:300].to(torch.int32).to(dev)
+    a0, b0, r0 = rn(340, 192), rn(264, 192), rn(340, 264)
+    a1, b1 = rn(520, 256), rn(256, 264)
+    a2, b2 = rn(128, 256), rn(128, 264)
+    a3, b3 = rn(256, 1024), rn(264, 1024)
+    cases = [dict(a=a0, b=b0, a_rows=rows, c_rows=rows, resid=r0), dict(a=a1, b=b1, b_t=True), dict(a=a2, b=b2, a_t=True, b_t=True),
+             dict(a=a3, b=b3)]
+    outs_m = [torch.zeros((340, 264), dtype=BF16, device=dev), None, None, None]
+    outs_s = [torch.zeros((340, 264), dtype=BF16, device=dev), None, None, None]
+    specs = []
+    for i, c in enumerate(cases):
+        kw = {k: v for k, v in c.items() if k not in ("a", "b")}
+        specs.append(gemm_spec(c["a"], c["b"], out=outs_m[i], splitk=4 if i == 3 else 1, **kw))
+    res_m = gemm_multi(specs)
+    for i, c in enumerate(cases[:3]):
+        kw = {k: v for k, v in c.items() if k not in ("a", "b")}
+        outs_s[i] = gemm_nt(c["a"], c["b"], out=outs_s[i], tile=GEMM_TILE_256, **kw)      # (every case is >= 256 x 256: the same tile body)
+    ref3 = a3.float() @ b3.float().t()
+    ok = all(torch.equal(res_m[i], outs_s[i]) for i in range(3))
+    err = (res_m[3].float() - ref3).abs()
+    ok = ok and bool((err <= 1e-3 * ref3.abs().max() + 2.0 ** -8 * ref3.abs()).all())
+    return ok and int(_multi_ws(dev).abs().sum()) == 0
+
+
+def _multi_verdict_file(key: int):
+    """Where the verdict of the acceptance check is remembered across processes: keyed by this build of the library and the device
+    model (as MIOpen's find-db or an autotuner's cache: a property of (kernel binary, chip), not of a process)."""
+    import hashlib
+    import os
+    try:
+        st = os.stat(_lib.LIB_PATH)
+        tag = f"{st.st_size}-{int(st.st_mtime)}-{_lib.ABI_VERSION}-{torch.cuda.get_device_name(key)}"
+        d = os.path.join(os.path.expanduser("~"), ".cache", "libra_amd")
+        return os.path.join(d, "gemm_multi_ok_" + hashlib.sha256(tag.encode()).hexdigest()[:16])
+    except Exception:
+        return None
+
+
 def gemm_multi_ok(device) -> bool:
-    """One-time, on-device acceptance check of the multi-problem launch on THIS device (cached): four small problems - routed with a
-    residual, reduction-major B, both operands reduction-major, K-sliced - through `gemm_multi` and through their own `gemm_nt`
-    launches must agree bit for bit and the queue workspace must come back zero.  The engines ask before they switch their launch
-    schedule to multi-problem launches (decoder_engine.MULTI / vit_engine.MULTI): the kernel's hand-out of tiles leans on
-    properties of the running system (every workgroup resident, round-robin XCD placement only for speed), and a schedule
-    switch is a pure speed choice - so a device where the check fails keeps the one-launch-per-GEMM schedule, with a warning,
-    instead of training on wrong numbers.  One host synchronisation, at the first call per device; inside a graph capture the
-    answer is the cached one (or True: a capture is always preceded by eager warm-up steps)."""
+    """May the engines use multi-problem launches on this device?  One-time acceptance check of `libra_gemm_bf16_multi` (cached per
+    process and, through a one-line file under ~/.cache/libra_amd, per library build and device model).  The engines ask before
+    they switch their launch schedule (decoder_engine.MULTI / vit_engine.MULTI): a schedule switch is a pure speed choice and the
+    kernel's hand-out of tiles leans on properties of the running system, so a device where the check fails keeps the
+    one-launch-per-GEMM schedule, with a warning, instead of training on wrong numbers.  The check (`_multi_selfcheck_inline`) runs
+    in a CHILD process the first time: a kernel that faulted would take the caller's HIP context - i.e. the training job - with it;
+    a child that crashes is just a failed check.  Inside a graph capture the answer is the cached one (or True: a capture is always
+    preceded by eager warm-up steps)."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key in _MULTI_CHECKED:
         return _MULTI_CHECKED[key]
     if torch.cuda.is_current_stream_capturing():
         return True
-    g = torch.Generator().manual_seed(1234)
-    rn = lambda *shape: (torch.randn(*shape, generator=g) * 0.5).to(BF16).to(dev)
-    ok = True
-    try:
-        rows = torch.randperm(340, generator=g)[:300].to(torch.int32).to(dev)
-        a0, b0, r0 = rn(340, 192), rn(264, 192), rn(340, 264)
-        a1, b1 = rn(520, 256), rn(256, 264)
-        a2, b2 = rn(128, 256), rn(128, 264)
-        a3, b3 = rn(256, 1024), rn(264, 1024)
-        cases = [dict(a=a0, b=b0, a_rows=rows, c_rows=rows, resid=r0), dict(a=a1, b=b1, b_t=True), dict(a=a2, b=b2, a_t=True, b_t=True),
-                 dict(a=a3, b=b3)]
-        outs_m = [torch.zeros((340, 264), dtype=BF16, device=dev), None, None, None]
-        outs_s = [torch.zeros((340, 264), dtype=BF16, device=dev), None, None, None]
-        specs = []
-        for i, c in enumerate(cases):
-            kw = {k: v for k, v in c.items() if k not in ("a", "b")}
-            specs.append(gemm_spec(c["a"], c["b"], out=outs_m[i], splitk=4 if i == 3 else 1, **kw))
-        res_m = gemm_multi(specs)
-        for i, c in enumerate(cases[:3]):
-            kw = {k: v for k, v in c.items() if k not in ("a", "b")}
-            outs_s[i] = gemm_nt(c["a"], c["b"], out=outs_s[i], tile=GEMM_TILE_256, **kw)      # (every case is >= 256 x 256: the same tile body)
-        ref3 = a3.float() @ b3.float().t()                          # the K-sliced one against fp32 math (1e-3 + 1 ulp, as the kernel tests)
-        ok = all(torch.equal(res_m[i], outs_s[i]) for i in range(3))
-        err = (res_m[3].float() - ref3).abs()
-        ok = ok and bool((err <= 1e-3 * ref3.abs().max() + 2.0 ** -8 * ref3.abs()).all())
-        ok = ok and int(_multi_ws(dev).abs().sum()) == 0
-    except Exception as e:                                           # a launch error is a failed check too
-        warnings.warn(f"libra_amd: gemm_multi self-check raised {e!r}", RuntimeWarning)
-        ok = False
-    if not ok:
-        _multi_ws(dev).zero_()
-        warnings.warn("libra_amd: the multi-problem GEMM launch FAILED its on-device self-check on this device; the engines keep the "
-                      "one-launch-per-GEMM schedule (slower, same results). Please report this.", RuntimeWarning)
+    import os
+    import subprocess
+    import sys
+    path = _multi_verdict_file(key)
+    ok = None
+    if path is not None and os.path.exists(path):
+        try:
+            ok = open(path).read().strip() == "ok"
+        except OSError:
+            ok = None
+    if ok is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = (f"import sys; sys.path.insert(0, {root!r}); import torch; from libra_amd import kernels as K; "
+                f"torch.cuda.set_device({key}); sys.exit(0 if K._multi_selfcheck_inline('cuda:{key}') else 3)")
+        remember = True
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+            ok = r.returncode == 0
+            why = f"child exit code {r.returncode}: {r.stderr.strip()[-300:]}"
+        except Exception as e:                                       # (timeout, no interpreter, ...): not a verdict about the kernel
+            ok, why, remember = False, repr(e), False
+        if not ok:
+            warnings.warn("libra_amd: the multi-problem GEMM launch FAILED its on-device acceptance check on this device "
+                          f"({why}); the engines keep the one-launch-per-GEMM schedule (slower, same results). Please report this.",
+                          RuntimeWarning)
+        if path is not None and remember:
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as f:
+                    f.write("ok" if ok else "failed")
+            except OSError:
+                pass
     _MULTI_CHECKED[key] = ok
     return ok
 

@@ -4,6 +4,8 @@ The contract is "each problem computes what its own libra_gemm_bf16_nt_routed ca
 `torch.equal` against the single-problem launches (whose own parity against fp32 math is tests/test_kernels_gpu.py), plus the
 1e-3 + 1 ulp bound against fp32 math directly, plus the properties of the tile queue: the 128-byte workspace is all zero again
 after every launch, results do not change from launch to launch, and a launch with fewer tiles than compute units works."""
+import os
+
 import pytest
 import torch
 
@@ -255,9 +257,14 @@ def test_multi_producer_consumer_inside_one_launch(K):
 
 def test_multi_on_device_self_check_passes(K):
     """The one-time acceptance check the engines run before they switch to multi-problem launches (kernels.gemm_multi_ok)."""
+    assert K._multi_selfcheck_inline("cuda") is True and _ws_zero(K)          # the check itself, in this process
     K._MULTI_CHECKED.clear()
-    assert K.gemm_multi_ok("cuda") is True
-    assert K._MULTI_CHECKED == {torch.cuda.current_device(): True} and _ws_zero(K)
+    path = K._multi_verdict_file(torch.cuda.current_device())
+    if path is not None and os.path.exists(path):
+        os.remove(path)
+    assert K.gemm_multi_ok("cuda") is True                                     # through the child process + the verdict file
+    assert K._MULTI_CHECKED == {torch.cuda.current_device(): True}
+    assert path is None or open(path).read() == "ok"
 
 
 def test_multi_rejects_bad_problems(K):
