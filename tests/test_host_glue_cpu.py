@@ -665,7 +665,7 @@ def test_gemm_tile_order_model_is_a_bijection_with_compact_xcd_patches():
 
 
 def test_gemm_multi_tile_list_model_covers_every_tile_slice_exactly_once():
-    """gemm_bf16_multi.hip restated in Python (the device code is exercised bit for bit by tests/test_gemm_multi_gpu.py; this pins
+    """gemm_bf16_multi.hip restated in Python (the device code is exercised bit for bit by tests/test_zz_gemm_multi_gpu.py; this pins
     the INDEX MATH on the CPU): the launcher lays the problems out longest slice first, each starting at a multiple of 8 entries;
     workgroup b takes entry b, then entries (static_x + c) * 8 + x of queue x = b % 8 for c = 0, 1, ... as its atomic counter hands them
     out; the owner scan + (slice, tile) split must visit every (problem, K slice, tile) exactly once, for any grid that is a

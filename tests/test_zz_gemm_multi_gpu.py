@@ -3,7 +3,10 @@
 The contract is "each problem computes what its own libra_gemm_bf16_nt_routed call would, bit for bit" - so the gate is
 `torch.equal` against the single-problem launches (whose own parity against fp32 math is tests/test_kernels_gpu.py), plus the
 1e-3 + 1 ulp bound against fp32 math directly, plus the properties of the tile queue: the 128-byte workspace is all zero again
-after every launch, results do not change from launch to launch, and a launch with fewer tiles than compute units works."""
+after every launch, results do not change from launch to launch, and a launch with fewer tiles than compute units works.
+
+(File name: the `zz` sorts these tests LAST.  The kernel was written in a round whose GPU pool was closed from the first call on, so
+its first execution anywhere is this file; should it fault, it must not take the rest of `pytest -m gpu -x` down with it.)"""
 import os
 
 import pytest

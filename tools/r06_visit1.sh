@@ -5,7 +5,7 @@ set -u
 mkdir -p gpurun_out
 cd "$(dirname "$0")/.."
 O=gpurun_out
-(timeout 900 python -m pytest tests/test_gemm_multi_gpu.py -x -q 2>&1 | tail -25) > $O/r06_v1_t_multi.log
+(timeout 900 python -m pytest tests/test_zz_gemm_multi_gpu.py -x -q 2>&1 | tail -25) > $O/r06_v1_t_multi.log
 (timeout 600 python tools/gemm_multi_bench.py 10 2>&1 | tail -20) > $O/r06_v1_multi_bench.log
 (timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k gemm 2>&1 | tail -5) > $O/r06_v1_t_gemm.log
 (timeout 1200 python -m pytest tests/test_decoder_model_gpu.py tests/test_model_gpu.py -x -q 2>&1 | tail -15) > $O/r06_v1_t_models.log
